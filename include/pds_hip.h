@@ -1,0 +1,158 @@
+/*
+ * pds_hip.h -- C ABI of libpds_hip.so: the MI355X (gfx950) implementation of the
+ * Practical Deep Stereo cost-volume hot path (Matching -> Regularization -> SubpixelMap).
+ *
+ * The reference has no FFI on this path: the seam is Python constructor injection
+ * (reference practical_deep_stereo/network.py:17-24) and the modules are torch.nn code.
+ * The entry points below are therefore what a ctypes/cffi binding of each reference
+ * module's forward would call; every prototype cites the reference code it replaces.
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions (all entry points):
+ *  - plain C: raw device pointers, ints, one opaque stream handle (a hipStream_t).
+ *    No torch types.  All tensors are contiguous fp32, NCHW / NCDHW like the reference.
+ *  - the library never allocates, frees or synchronises: every buffer (inputs, outputs,
+ *    workspace, packed weights) belongs to the caller; all work is enqueued on `stream`;
+ *    calls are re-entrant and hipGraph-capturable.
+ *  - return value 0 = enqueued; non-zero = error (negative: bad argument, positive:
+ *    hipError_t).  pds_last_error() gives a thread-local message.  Nothing throws.
+ *  - argument validation that the reference does in Python (the ValueErrors of
+ *    estimator.py:34-41, network.py:28-31) stays in the Python mirror.
+ */
+#ifndef PDS_HIP_H
+#define PDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDS_ABI_VERSION 1
+
+typedef void* pds_stream_t; /* hipStream_t */
+
+int pds_abi_version(void);
+const char* pds_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Layer parameters in the reference's own (PyTorch) layouts.
+ *   conv   weight [Cout, Cin, kD, kH, kW]  (Conv2d: kD == 1)   network_blocks.py:9-24
+ *   deconv weight [Cin, Cout, kD, kH, kW]                      network_blocks.py:37-44, 75-85
+ *   gamma/beta: InstanceNorm affine (NULL for a bare conv)     network_blocks.py:58,72,85
+ * ---------------------------------------------------------------------------------- */
+typedef struct PdsConvBlockParams {
+    const float* weight;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+} PdsConvBlockParams;
+
+/* ------------------------------------------------------------------------------------
+ * SubpixelMap.__call__                      reference estimator.py:45-91
+ * similarities [batch, planes, height, width] -> disparities [batch, height, width].
+ * First-occurrence arg-max, taps j in range(-hw // step, hw // step + 1) (Python floor
+ * division), invalid taps get probability 0, result = sum softmax * step * index.
+ * ---------------------------------------------------------------------------------- */
+int pds_subpixel_map_fwd(const float* similarities, float* disparities,
+                         int batch, int planes, int height, int width,
+                         int half_support_window, int disparity_step,
+                         pds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Matching.forward, generic-operation path  reference matching.py:12-13, 50-61
+ * Builds cat([left, S_d(right)], dim=1) for disparities d_begin .. d_begin+d_count-1:
+ * out [d_count, batch, 2*channels, h, w]; S_d(R)[x] = R[x-d] for x >= d else 0.
+ * The Python mirror then applies the user's arbitrary `operation` per plane.
+ * ---------------------------------------------------------------------------------- */
+int pds_shift_concat_fwd(const float* left, const float* right, float* out,
+                         int batch, int channels, int h, int w,
+                         int d_begin, int d_count, pds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Matching(maximum_disparity, MatchingOperation()).forward, fused fast path
+ *                                           reference matching.py:34-63 + :66-112
+ * left/right [batch, features, h, w] -> signatures [batch, sig, d_count, h, w] holding
+ * disparities d_begin .. d_begin+d_count-1 (d_begin/d_count shard the disparity axis
+ * across GPUs; the whole range is d_begin=0, d_count=maximum_disparity+1).
+ * `first` is the bare conv 2*features->features, `blocks` holds 2*residual_blocks
+ * conv+LeakyReLU+InstanceNorm2d blocks (ResidualBlock, network_blocks.py:134-144),
+ * `last` the bare conv features->sig.  InstanceNorm statistics are per (batch, channel,
+ * disparity plane), as in the reference's per-disparity calls.
+ * ---------------------------------------------------------------------------------- */
+typedef struct PdsMatchingParams {
+    int features;            /* 64  */
+    int signature_features;  /* 8   */
+    int residual_blocks;     /* 2   */
+    PdsConvBlockParams first;
+    const PdsConvBlockParams* blocks; /* [2 * residual_blocks] */
+    PdsConvBlockParams last;
+} PdsMatchingParams;
+
+size_t pds_matching_workspace_bytes(const PdsMatchingParams* params, int batch, int h, int w,
+                                    int d_count);
+int pds_matching_fwd(const PdsMatchingParams* params,
+                     const float* left, const float* right, float* signatures,
+                     int batch, int h, int w, int d_begin, int d_count,
+                     void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
+/* MatchingOperation.forward on an already concatenated tensor [n, 2*features, h, w]
+ * -> [n, sig, h, w]                          reference matching.py:97-112 */
+size_t pds_matching_operation_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w);
+int pds_matching_operation_fwd(const PdsMatchingParams* params,
+                               const float* concatenated, float* signature,
+                               int n, int h, int w,
+                               void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Regularization.forward                    reference regularization.py:94-126
+ * signatures [batch, F, D, h, w] + left shortcut [batch, F, h, w] -> cost
+ * [batch, 2*D, 4*h, 4*w].  D, h, w must be multiples of 16 (four stride-2 levels).
+ * ---------------------------------------------------------------------------------- */
+typedef struct PdsRegularizationParams {
+    int features;                        /* 8 */
+    PdsConvBlockParams smoothing;        /* regularization.py:77-78 */
+    PdsConvBlockParams contraction[4][2];/* [level][0=_downsampling_2x, 1=_smoothing]  :79-82 */
+    PdsConvBlockParams expansion[4][2];  /* [level][0=_upsampling_2x,   1=_smoothing]  :83-86 */
+    PdsConvBlockParams upsample_half;    /* :87-89 */
+    PdsConvBlockParams upsample_full;    /* bare deconv (3,4,4)/(1,2,2), :90-92 */
+} PdsRegularizationParams;
+
+size_t pds_regularization_workspace_bytes(const PdsRegularizationParams* params,
+                                          int batch, int d, int h, int w);
+int pds_regularization_fwd(const PdsRegularizationParams* params,
+                           const float* signatures, const float* left_shortcut, float* cost,
+                           int batch, int d, int h, int w,
+                           void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
+/* Eval-mode fusion of Regularization's last layer with SubpixelMap (network.py:50-51):
+ * the full-resolution cost volume is never written.  disparities [batch, 4*h, 4*w]. */
+int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params,
+                                        const float* signatures, const float* left_shortcut,
+                                        float* disparities,
+                                        int batch, int d, int h, int w,
+                                        int half_support_window, int disparity_step,
+                                        void* workspace, size_t workspace_bytes,
+                                        pds_stream_t stream);
+
+/* ContractionBlock3d.forward                reference regularization.py:28-31
+ * x [batch, C, D, H, W] -> down, smooth [batch, 2C, D/2, H/2, W/2] (ceil for odd sizes). */
+size_t pds_contraction_block_workspace_bytes(int batch, int c, int d, int h, int w);
+int pds_contraction_block_fwd(const PdsConvBlockParams* downsampling, const PdsConvBlockParams* smoothing,
+                              const float* x, float* down, float* smooth,
+                              int batch, int c, int d, int h, int w,
+                              void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
+/* ExpansionBlock3d.forward                  reference regularization.py:54-57
+ * x [batch, C, D, H, W], shortcut [batch, C/2, 2D, 2H, 2W] -> out like shortcut. */
+size_t pds_expansion_block_workspace_bytes(int batch, int c, int d, int h, int w);
+int pds_expansion_block_fwd(const PdsConvBlockParams* upsampling, const PdsConvBlockParams* smoothing,
+                            const float* x, const float* shortcut, float* out,
+                            int batch, int c, int d, int h, int w,
+                            void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDS_HIP_H */

@@ -1,0 +1,13 @@
+"""MI355X-native cost-volume hot path of Practical Deep Stereo (NeurIPS 2018).
+
+Matching -> Regularization -> SubpixelMap behind the reference's module surfaces, computed by
+hand-written HIP kernels for gfx950 (libpds_hip.so, C ABI in include/pds_hip.h).
+"""
+from practicaldeepstereo_nips2018_amd.estimator import SubpixelMap
+from practicaldeepstereo_nips2018_amd.matching import Matching, MatchingOperation
+from practicaldeepstereo_nips2018_amd.network import PdsNetwork
+from practicaldeepstereo_nips2018_amd.regularization import (ContractionBlock3d, ExpansionBlock3d,
+                                                            Regularization)
+
+__all__ = ['SubpixelMap', 'Matching', 'MatchingOperation', 'PdsNetwork', 'ContractionBlock3d',
+           'ExpansionBlock3d', 'Regularization']

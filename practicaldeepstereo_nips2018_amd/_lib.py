@@ -1,0 +1,166 @@
+"""ctypes binding of libpds_hip.so (C ABI: include/pds_hip.h).
+
+The library is built in-tree by ``build_library()`` (``hipcc --offload-arch=gfx950``) and loaded
+from this package directory.  There is NO fallback: if the shared object is missing or a tensor is
+not a contiguous fp32 GPU tensor, the call raises.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG_DIR, 'csrc')
+LIB_PATH = os.path.join(_PKG_DIR, 'libpds_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'pds_hip.h')
+
+_lock = threading.Lock()
+_lib = None
+
+
+class ConvBlockParams(ctypes.Structure):
+    """struct PdsConvBlockParams"""
+    _fields_ = [('weight', ctypes.c_void_p), ('bias', ctypes.c_void_p),
+                ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p)]
+
+
+class MatchingParams(ctypes.Structure):
+    """struct PdsMatchingParams"""
+    _fields_ = [('features', ctypes.c_int), ('signature_features', ctypes.c_int),
+                ('residual_blocks', ctypes.c_int),
+                ('first', ConvBlockParams),
+                ('blocks', ctypes.POINTER(ConvBlockParams)),
+                ('last', ConvBlockParams)]
+
+
+class RegularizationParams(ctypes.Structure):
+    """struct PdsRegularizationParams"""
+    _fields_ = [('features', ctypes.c_int),
+                ('smoothing', ConvBlockParams),
+                ('contraction', (ConvBlockParams * 2) * 4),
+                ('expansion', (ConvBlockParams * 2) * 4),
+                ('upsample_half', ConvBlockParams),
+                ('upsample_full', ConvBlockParams)]
+
+
+def sources():
+    return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hip'))
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into libpds_hip.so (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hpp')] + [HEADER_PATH]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_VP = ctypes.c_void_p
+_I = ctypes.c_int
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/pds_hip.h declares
+SIGNATURES = {
+    'pds_abi_version': (_I, []),
+    'pds_last_error': (ctypes.c_char_p, []),
+    'pds_subpixel_map_fwd': (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
+    'pds_shift_concat_fwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
+    'pds_matching_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
+    'pds_matching_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I,
+                              _VP, _SZ, _VP]),
+    'pds_matching_operation_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I]),
+    'pds_matching_operation_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _I, _I, _I,
+                                        _VP, _SZ, _VP]),
+    'pds_regularization_workspace_bytes': (_SZ, [ctypes.POINTER(RegularizationParams), _I, _I, _I, _I]),
+    'pds_regularization_fwd': (_I, [ctypes.POINTER(RegularizationParams), _VP, _VP, _VP,
+                                    _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_regularization_subpixel_map_fwd': (_I, [ctypes.POINTER(RegularizationParams), _VP, _VP, _VP,
+                                                 _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_contraction_block_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
+    'pds_contraction_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), ctypes.POINTER(ConvBlockParams),
+                                       _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_expansion_block_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
+    'pds_expansion_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), ctypes.POINTER(ConvBlockParams),
+                                     _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+}
+
+
+def load():
+    """Returns the loaded library; raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    'libpds_hip.so is missing (%s). Build it with '
+                    '`python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback.'
+                    % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, load().pds_last_error().decode()))
+
+
+def require_gpu_tensor(t, name, dims=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on an MI355X (cuda) device: the HIP path has no CPU fallback' % name)
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    if dims is not None and t.dim() != dims:
+        raise ValueError('%s must have %d dimensions, got %d' % (name, dims, t.dim()))
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def conv_block_params(conv, norm=None):
+    """PdsConvBlockParams from a conv module (and its InstanceNorm, if any)."""
+    p = ConvBlockParams()
+    p.weight = conv.weight.data_ptr()
+    p.bias = conv.bias.data_ptr()
+    p.gamma = norm.weight.data_ptr() if norm is not None else None
+    p.beta = norm.bias.data_ptr() if norm is not None else None
+    return p
+
+
+class Workspace(object):
+    """Grow-only device scratch buffer reused across calls of one module (same stream => safe)."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes, device):
+        if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
+            self._buf = None
+            self._buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self._buf
+
+
+def not_differentiable(name):
+    raise NotImplementedError(
+        '%s: backward kernels of the HIP path are not built yet; run under torch.no_grad()' % name)

@@ -1,0 +1,438 @@
+// C ABI of libpds_hip.so (include/pds_hip.h): argument checks, workspace carving and the
+// per-module launch sequences.  No allocation, no synchronisation: everything is enqueued on the
+// caller's stream into caller-owned memory.
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace pds {
+
+static thread_local char g_error[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s);        // conv2d_mfma.hip
+bool conv2d_mfma_supported(const ConvLayer& L);
+int conv2d_mfma_tiles(const Geom& out_g);
+
+// ---- workspace arena: plan mode only measures ---------------------------------------------------
+struct Ctx {
+    char* base;
+    size_t off = 0;
+    bool plan;
+    hipStream_t s;
+    int err = 0;
+
+    template <class T>
+    T* get(size_t count) {
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        T* p = plan ? nullptr : reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+    void run(int rc) {
+        if (!err && rc) err = rc;
+    }
+};
+
+// A tensor whose InstanceNorm is deferred to its consumers.
+struct DT {
+    float* raw = nullptr;
+    float* scale = nullptr;
+    float* shift = nullptr;
+    Geom g{0, 0, 0, 0, 0};
+    int per_plane = 0;
+    Src src() const { return Src{raw, scale, shift, per_plane, 0}; }
+};
+
+static Geom conv_out_geom(const Geom& in, int cout, int kd, int stride) {
+    Geom o = in;
+    o.c = cout;
+    if (stride == 2) {
+        if (kd == 3) o.d = (in.d + 1) / 2;
+        o.h = (in.h + 1) / 2;
+        o.w = (in.w + 1) / 2;
+    }
+    return o;
+}
+
+// conv (+ LeakyReLU + deferred InstanceNorm when P.gamma) ; out_raw may be caller-provided
+static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvBlockParams& P, int cout,
+                     int kd, int stride, int per_plane, float* out_raw = nullptr, bool allow_mfma = true) {
+    DT o;
+    o.g = conv_out_geom(in, cout, kd, stride);
+    o.per_plane = per_plane;
+    o.raw = out_raw ? out_raw : c.get<float>(o.g.numel());
+    const bool norm = P.gamma != nullptr;
+    ConvLayer L;
+    L.a = a;
+    L.b = b;
+    L.in = in;
+    L.weight = P.weight;
+    L.bias = P.bias;
+    L.out = o.raw;
+    L.out_g = o.g;
+    L.kd = kd;
+    L.stride = stride;
+    L.lrelu = norm ? 1 : 0;
+    L.stat_per_plane = per_plane;
+    L.partials = nullptr;
+    const bool mfma = allow_mfma && conv2d_mfma_supported(L);
+    const int tiles = mfma ? conv2d_mfma_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
+    if (norm) {
+        const size_t records = (size_t)o.g.n * o.g.c * o.g.d * tiles;
+        L.partials = c.get<double>(records * 2);
+        const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
+        o.scale = c.get<float>(groups);
+        o.shift = c.get<float>(groups);
+        if (!c.plan) {
+            c.run(mfma ? launch_conv2d_mfma(L, c.s) : launch_conv_direct(L, c.s));
+            const int per_group = tiles * (per_plane ? 1 : o.g.d);
+            const double count = (double)o.g.h * o.g.w * (per_plane ? 1 : o.g.d);
+            c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
+                                     per_plane ? o.g.d : 1, o.scale, o.shift, c.s));
+        }
+    } else if (!c.plan) {
+        c.run(mfma ? launch_conv2d_mfma(L, c.s) : launch_conv_direct(L, c.s));
+    }
+    return o;
+}
+
+static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvBlockParams& P, int cout,
+                       int kd, float* out_raw = nullptr) {
+    DT o;
+    o.g = in;
+    o.g.c = cout;
+    o.g.d = (kd == 4) ? in.d * 2 : in.d;
+    o.g.h = in.h * 2;
+    o.g.w = in.w * 2;
+    o.per_plane = 0;
+    o.raw = out_raw ? out_raw : c.get<float>(o.g.numel());
+    const bool norm = P.gamma != nullptr;
+    DeconvLayer L;
+    L.a = a;
+    L.b = b;
+    L.in = in;
+    L.weight = P.weight;
+    L.bias = P.bias;
+    L.out = o.raw;
+    L.out_g = o.g;
+    L.kd = kd;
+    L.lrelu = norm ? 1 : 0;
+    L.partials = nullptr;
+    const int tiles = deconv_direct_tiles(o.g);
+    if (norm) {
+        const size_t records = (size_t)o.g.n * o.g.c * o.g.d * tiles;
+        L.partials = c.get<double>(records * 2);
+        const int groups = o.g.n * o.g.c;
+        o.scale = c.get<float>(groups);
+        o.shift = c.get<float>(groups);
+        if (!c.plan) {
+            c.run(launch_deconv_direct(L, c.s));
+            c.run(launch_in_finalize(L.partials, groups, tiles * o.g.d, (double)o.g.volume(), P.gamma, P.beta,
+                                     o.g.c, 1, o.scale, o.shift, c.s));
+        }
+    } else if (!c.plan) {
+        c.run(launch_deconv_direct(L, c.s));
+    }
+    return o;
+}
+
+// ---- MatchingOperation after layer 0: residual blocks + last conv ---------------------------------
+// x0 plain [n, F, d, h, w]; kernel depth 1, InstanceNorm statistics per (n, c, d) plane.
+static void operation_tail(Ctx& c, const PdsMatchingParams& P, float* x0, const Geom& g, float* signature) {
+    const int F = P.features;
+    float* cur = x0;
+    DT t2;
+    for (int r = 0; r < P.residual_blocks; ++r) {
+        DT t1 = conv_block(c, plain_src(cur), no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
+        t2 = conv_block(c, t1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
+        if (r + 1 < P.residual_blocks) {
+            float* nxt = c.get<float>(g.numel());
+            if (!c.plan) c.run(launch_materialize(t2.src(), plain_src(cur), g, nxt, c.s));
+            cur = nxt;
+        }
+    }
+    if (P.residual_blocks > 0)
+        conv_block(c, t2.src(), plain_src(cur), g, P.last, P.signature_features, 1, 1, 1, signature);
+    else
+        conv_block(c, plain_src(cur), no_src(), g, P.last, P.signature_features, 1, 1, 1, signature);
+}
+
+static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* left, const float* right,
+                              float* signatures, int batch, int h, int w, int d_begin, int d_count) {
+    const int F = P.features;
+    const Geom g2{batch, F, 1, h, w};
+    const Geom g2p{batch, F, 1, h, w + 1};
+    const size_t wn = (size_t)F * F * 9;
+    float* wl = c.get<float>(wn);
+    float* wr = c.get<float>(wn);
+    float* wr2 = c.get<float>(wn);
+    float* rp = c.get<float>(g2p.numel());
+    if (!c.plan) {
+        c.run(launch_split_first_weights(P.first.weight, wl, wr, wr2, F, F, c.s));
+        c.run(launch_pad_left1(right, rp, (size_t)batch * F * h, w, c.s));
+    }
+    PdsConvBlockParams pl{wl, P.first.bias, nullptr, nullptr};
+    PdsConvBlockParams pr{wr, nullptr, nullptr, nullptr};
+    PdsConvBlockParams pr2{wr2, nullptr, nullptr, nullptr};
+    DT A = conv_block(c, plain_src(left), no_src(), g2, pl, F, 1, 1, 1);
+    DT G = conv_block(c, plain_src(rp), no_src(), g2p, pr, F, 1, 1, 1);
+    DT G2 = conv_block(c, plain_src(rp), no_src(), g2p, pr2, F, 1, 1, 1);
+    const Geom g{batch, F, d_count, h, w};
+    float* x0 = c.get<float>(g.numel());
+    if (!c.plan) c.run(launch_l0_combine(A.raw, G.raw, G2.raw, x0, batch, F, h, w, d_begin, d_count, c.s));
+    operation_tail(c, P, x0, g, signatures);
+}
+
+static void operation_pipeline(Ctx& c, const PdsMatchingParams& P, const float* concatenated, float* signature,
+                               int n, int h, int w) {
+    const Geom gin{n, 2 * P.features, 1, h, w};
+    DT x0 = conv_block(c, plain_src(concatenated), no_src(), gin, P.first, P.features, 1, 1, 1);
+    operation_tail(c, P, x0.raw, x0.g, signature);
+}
+
+// ---- Regularization (reference regularization.py:94-126) -----------------------------------------
+static DT regularization_trunk(Ctx& c, const PdsRegularizationParams& P, const float* ms, const float* left,
+                               int batch, int d, int h, int w) {
+    const int F = P.features;
+    const Geom g0{batch, F, d, h, w};
+    DT out = conv_block(c, plain_src(ms), no_src(), g0, P.smoothing, F, 3, 1, 0);
+    DT pushed[4];
+    Src shortcut = plain_src(left);
+    shortcut.bcast_d = 1;
+    for (int i = 0; i < 4; ++i) {
+        pushed[i] = out;
+        const int cin = out.g.c;
+        // contraction_block(shortcut + output): a = output, b = shortcut (b may broadcast along D)
+        DT down = conv_block(c, out.src(), shortcut, out.g, P.contraction[i][0], 2 * cin, 3, 2, 0);
+        DT smooth = conv_block(c, down.src(), no_src(), down.g, P.contraction[i][1], 2 * cin, 3, 1, 0);
+        shortcut = down.src();
+        out = smooth;
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int cin = out.g.c;
+        DT up = deconv_block(c, out.src(), no_src(), out.g, P.expansion[i][0], cin / 2, 4);
+        out = conv_block(c, up.src(), pushed[3 - i].src(), up.g, P.expansion[i][1], cin / 2, 3, 1, 0);
+    }
+    return deconv_block(c, out.src(), no_src(), out.g, P.upsample_half, F / 2, 4);
+}
+
+static void regularization_pipeline(Ctx& c, const PdsRegularizationParams& P, const float* ms, const float* left,
+                                    float* cost, int batch, int d, int h, int w) {
+    DT half = regularization_trunk(c, P, ms, left, batch, d, h, w);
+    deconv_block(c, half.src(), no_src(), half.g, P.upsample_full, 1, 3, cost);
+}
+
+}  // namespace pds
+
+using namespace pds;
+
+// ====================================================================================================
+extern "C" {
+
+int pds_abi_version(void) { return PDS_ABI_VERSION; }
+const char* pds_last_error(void) { return g_error; }
+
+int pds_subpixel_map_fwd(const float* similarities, float* disparities, int batch, int planes, int height,
+                         int width, int half_support_window, int disparity_step, pds_stream_t stream) {
+    PDS_REQUIRE(similarities && disparities, "subpixel_map: null pointer");
+    PDS_REQUIRE(batch > 0 && planes > 0 && height > 0 && width > 0, "subpixel_map: bad shape");
+    PDS_REQUIRE(disparity_step >= 1 && half_support_window >= 1 && half_support_window % disparity_step == 0,
+                "subpixel_map: bad window/step");
+    // Python floor division of the negated window (estimator.py:66-68)
+    const int hi = half_support_window / disparity_step;
+    const int lo = -((half_support_window + disparity_step - 1) / disparity_step);
+    return launch_subpixel_map(similarities, disparities, batch, planes, height, width, lo, hi, disparity_step,
+                               (hipStream_t)stream);
+}
+
+int pds_shift_concat_fwd(const float* left, const float* right, float* out, int batch, int channels, int h, int w,
+                         int d_begin, int d_count, pds_stream_t stream) {
+    PDS_REQUIRE(left && right && out, "shift_concat: null pointer");
+    PDS_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0,
+                "shift_concat: bad shape");
+    return launch_shift_concat(left, right, out, batch, channels, h, w, d_begin, d_count, (hipStream_t)stream);
+}
+
+static int check_matching_params(const PdsMatchingParams* P) {
+    PDS_REQUIRE(P, "matching: null params");
+    PDS_REQUIRE(P->features > 0 && P->signature_features > 0 && P->residual_blocks >= 0, "matching: bad params");
+    PDS_REQUIRE(P->first.weight && P->first.bias && P->last.weight && P->last.bias, "matching: null weights");
+    for (int i = 0; i < 2 * P->residual_blocks; ++i)
+        PDS_REQUIRE(P->blocks && P->blocks[i].weight && P->blocks[i].bias && P->blocks[i].gamma && P->blocks[i].beta,
+                    "matching: null residual-block weights");
+    return 0;
+}
+
+size_t pds_matching_workspace_bytes(const PdsMatchingParams* params, int batch, int h, int w, int d_count) {
+    if (check_matching_params(params)) return 0;
+    Ctx c{nullptr, 0, true, nullptr};
+    matching_pipeline(c, *params, nullptr, nullptr, nullptr, batch, h, w, 0, d_count);
+    return c.off;
+}
+
+int pds_matching_fwd(const PdsMatchingParams* params, const float* left, const float* right, float* signatures,
+                     int batch, int h, int w, int d_begin, int d_count, void* workspace, size_t workspace_bytes,
+                     pds_stream_t stream) {
+    if (int rc = check_matching_params(params)) return rc;
+    PDS_REQUIRE(left && right && signatures && workspace, "matching: null pointer");
+    PDS_REQUIRE(batch > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0, "matching: bad shape");
+    const size_t need = pds_matching_workspace_bytes(params, batch, h, w, d_count);
+    PDS_REQUIRE(workspace_bytes >= need, "matching: workspace too small (%zu < %zu)", workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    matching_pipeline(c, *params, left, right, signatures, batch, h, w, d_begin, d_count);
+    return c.err;
+}
+
+size_t pds_matching_operation_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w) {
+    if (check_matching_params(params)) return 0;
+    Ctx c{nullptr, 0, true, nullptr};
+    operation_pipeline(c, *params, nullptr, nullptr, n, h, w);
+    return c.off;
+}
+
+int pds_matching_operation_fwd(const PdsMatchingParams* params, const float* concatenated, float* signature, int n,
+                               int h, int w, void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_matching_params(params)) return rc;
+    PDS_REQUIRE(concatenated && signature && workspace, "matching_operation: null pointer");
+    PDS_REQUIRE(n > 0 && h > 0 && w > 0, "matching_operation: bad shape");
+    const size_t need = pds_matching_operation_workspace_bytes(params, n, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "matching_operation: workspace too small (%zu < %zu)", workspace_bytes,
+                need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    operation_pipeline(c, *params, concatenated, signature, n, h, w);
+    return c.err;
+}
+
+static int check_block(const PdsConvBlockParams& b, bool norm, const char* name) {
+    PDS_REQUIRE(b.weight && b.bias, "%s: null weight/bias", name);
+    if (norm) PDS_REQUIRE(b.gamma && b.beta, "%s: null InstanceNorm affine", name);
+    return 0;
+}
+
+static int check_regularization(const PdsRegularizationParams* P, int batch, int d, int h, int w) {
+    PDS_REQUIRE(P, "regularization: null params");
+    PDS_REQUIRE(P->features >= 2 && P->features % 2 == 0, "regularization: features must be even");
+    PDS_REQUIRE(batch > 0 && d > 0 && h > 0 && w > 0, "regularization: bad shape");
+    PDS_REQUIRE(d % 16 == 0 && h % 16 == 0 && w % 16 == 0,
+                "regularization: D, h, w must be multiples of 16 (got %d, %d, %d)", d, h, w);
+    PDS_REQUIRE((d / 16) * (h / 16) * (w / 16) > 1,
+                "regularization: InstanceNorm needs more than one element at 1/16 scale");
+    if (int rc = check_block(P->smoothing, true, "regularization._smoothing")) return rc;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+            if (int rc = check_block(P->contraction[i][j], true, "regularization._contraction_blocks")) return rc;
+            if (int rc = check_block(P->expansion[i][j], true, "regularization._expansion_blocks")) return rc;
+        }
+    if (int rc = check_block(P->upsample_half, true, "regularization._upsample_to_halfsize")) return rc;
+    return check_block(P->upsample_full, false, "regularization._upsample_to_fullsize");
+}
+
+size_t pds_regularization_workspace_bytes(const PdsRegularizationParams* params, int batch, int d, int h, int w) {
+    if (check_regularization(params, batch, d, h, w)) return 0;
+    Ctx c{nullptr, 0, true, nullptr};
+    regularization_pipeline(c, *params, nullptr, nullptr, nullptr, batch, d, h, w);
+    // the fused eval entry point additionally stages the cost volume in the workspace
+    c.get<float>((size_t)batch * 2 * d * 4 * h * 4 * w);
+    return c.off;
+}
+
+int pds_regularization_fwd(const PdsRegularizationParams* params, const float* signatures,
+                           const float* left_shortcut, float* cost, int batch, int d, int h, int w, void* workspace,
+                           size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_regularization(params, batch, d, h, w)) return rc;
+    PDS_REQUIRE(signatures && left_shortcut && cost && workspace, "regularization: null pointer");
+    const size_t need = pds_regularization_workspace_bytes(params, batch, d, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "regularization: workspace too small (%zu < %zu)", workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
+    return c.err;
+}
+
+int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, const float* signatures,
+                                        const float* left_shortcut, float* disparities, int batch, int d, int h,
+                                        int w, int half_support_window, int disparity_step, void* workspace,
+                                        size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_regularization(params, batch, d, h, w)) return rc;
+    PDS_REQUIRE(signatures && left_shortcut && disparities && workspace, "regularization_subpixel_map: null pointer");
+    PDS_REQUIRE(disparity_step >= 1 && half_support_window >= 1 && half_support_window % disparity_step == 0,
+                "regularization_subpixel_map: bad window/step");
+    const size_t need = pds_regularization_workspace_bytes(params, batch, d, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "regularization_subpixel_map: workspace too small (%zu < %zu)",
+                workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    float* cost = c.get<float>((size_t)batch * 2 * d * 4 * h * 4 * w);
+    regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
+    if (c.err) return c.err;
+    return pds_subpixel_map_fwd(cost, disparities, batch, 2 * d, 4 * h, 4 * w, half_support_window, disparity_step,
+                                stream);
+}
+
+size_t pds_contraction_block_workspace_bytes(int batch, int c_, int d, int h, int w) {
+    Ctx c{nullptr, 0, true, nullptr};
+    PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
+    const Geom g{batch, c_, d, h, w};
+    DT down = conv_block(c, plain_src(nullptr), no_src(), g, dummy, 2 * c_, 3, 2, 0);
+    conv_block(c, down.src(), no_src(), down.g, dummy, 2 * c_, 3, 1, 0);
+    return c.off;
+}
+
+int pds_contraction_block_fwd(const PdsConvBlockParams* downsampling, const PdsConvBlockParams* smoothing,
+                              const float* x, float* down_out, float* smooth_out, int batch, int c_, int d, int h,
+                              int w, void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(downsampling && smoothing && x && down_out && smooth_out && workspace, "contraction: null pointer");
+    PDS_REQUIRE(batch > 0 && c_ > 0 && d > 0 && h > 0 && w > 0, "contraction: bad shape");
+    if (int rc = check_block(*downsampling, true, "contraction._downsampling_2x")) return rc;
+    if (int rc = check_block(*smoothing, true, "contraction._smoothing")) return rc;
+    const size_t need = pds_contraction_block_workspace_bytes(batch, c_, d, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "contraction: workspace too small (%zu < %zu)", workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    const Geom g{batch, c_, d, h, w};
+    DT down = conv_block(c, plain_src(x), no_src(), g, *downsampling, 2 * c_, 3, 2, 0);
+    DT smooth = conv_block(c, down.src(), no_src(), down.g, *smoothing, 2 * c_, 3, 1, 0);
+    c.run(launch_materialize(down.src(), no_src(), down.g, down_out, c.s));
+    c.run(launch_materialize(smooth.src(), no_src(), smooth.g, smooth_out, c.s));
+    return c.err;
+}
+
+size_t pds_expansion_block_workspace_bytes(int batch, int c_, int d, int h, int w) {
+    Ctx c{nullptr, 0, true, nullptr};
+    PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
+    const Geom g{batch, c_, d, h, w};
+    DT up = deconv_block(c, plain_src(nullptr), no_src(), g, dummy, c_ / 2, 4);
+    conv_block(c, up.src(), no_src(), up.g, dummy, c_ / 2, 3, 1, 0);
+    return c.off;
+}
+
+int pds_expansion_block_fwd(const PdsConvBlockParams* upsampling, const PdsConvBlockParams* smoothing, const float* x,
+                            const float* shortcut, float* out, int batch, int c_, int d, int h, int w,
+                            void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(upsampling && smoothing && x && shortcut && out && workspace, "expansion: null pointer");
+    PDS_REQUIRE(batch > 0 && c_ >= 2 && c_ % 2 == 0 && d > 0 && h > 0 && w > 0, "expansion: bad shape");
+    if (int rc = check_block(*upsampling, true, "expansion._upsampling_2x")) return rc;
+    if (int rc = check_block(*smoothing, true, "expansion._smoothing")) return rc;
+    const size_t need = pds_expansion_block_workspace_bytes(batch, c_, d, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "expansion: workspace too small (%zu < %zu)", workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    const Geom g{batch, c_, d, h, w};
+    DT up = deconv_block(c, plain_src(x), no_src(), g, *upsampling, c_ / 2, 4);
+    DT sm = conv_block(c, up.src(), plain_src(shortcut), up.g, *smoothing, c_ / 2, 3, 1, 0);
+    c.run(launch_materialize(sm.src(), no_src(), sm.g, out, c.s));
+    return c.err;
+}
+
+}  // extern "C"

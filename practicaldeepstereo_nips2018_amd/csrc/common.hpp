@@ -1,0 +1,114 @@
+// Shared declarations of libpds_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/pds_hip.h"
+
+namespace pds {
+
+constexpr float kLeakySlope = 0.1f;  // reference network_blocks.py:57,71,84
+constexpr double kInEps = 1e-5;      // torch InstanceNorm default eps
+
+// ---- error reporting across the C ABI ------------------------------------------------
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PDS_REQUIRE(cond, ...)                       \
+    do {                                             \
+        if (!(cond)) return pds::set_error(-1, __VA_ARGS__); \
+    } while (0)
+
+// ---- a "deferred-normalisation" input source -------------------------------------------
+// Convolution kernels read their input as  scale * raw + shift  where (scale, shift) fold the
+// InstanceNorm of the PRODUCING layer (conv -> LeakyReLU -> IN, network_blocks.py:50-58): the
+// producer stores LeakyReLU(conv) plus per-group partial sums; in_finalize turns them into
+// scale = gamma * rstd, shift = beta - mean * scale.  A plain tensor has scale == nullptr.
+struct Src {
+    const float* p;      // NCDHW (or NCHW when bcast_d)
+    const float* scale;  // [N*C] or [N*C*D] (per_plane)
+    const float* shift;
+    int per_plane;       // statistics per (n, c, d) -- Matching's per-disparity InstanceNorm2d
+    int bcast_d;         // tensor has no D axis and is broadcast along it (regularization.py:115)
+};
+
+inline Src plain_src(const float* p) { return Src{p, nullptr, nullptr, 0, 0}; }
+inline Src no_src() { return Src{nullptr, nullptr, nullptr, 0, 0}; }
+
+// Activation tensor geometry (contiguous NCDHW).
+struct Geom {
+    int n, c, d, h, w;
+    __host__ __device__ size_t plane() const { return (size_t)h * w; }
+    __host__ __device__ size_t volume() const { return (size_t)d * h * w; }
+    __host__ __device__ size_t numel() const { return (size_t)n * c * d * h * w; }
+};
+
+// ---- launchers (defined in the .hip files) -------------------------------------------------
+struct ConvLayer {
+    Src a, b;            // input = a (+ b)
+    Geom in;             // geometry of a
+    const float* weight; // PyTorch layout
+    const float* bias;
+    float* out;          // raw output: conv + bias (+ LeakyReLU)
+    Geom out_g;
+    int kd;              // 1 or 3 (kH = kW = 3)
+    int stride;          // 1 or 2 (all convolved dims)
+    int lrelu;
+    int stat_per_plane;  // statistics grouping of THIS layer's InstanceNorm
+    double* partials;    // nullptr: no statistics wanted
+};
+
+// direct VALU convolution, any channel count
+int launch_conv_direct(const ConvLayer& L, hipStream_t s);
+int conv_direct_tiles_for(const Geom& out_g, int stride);  // tiles per output plane (partials sizing)
+
+struct DeconvLayer {
+    Src a, b;
+    Geom in;
+    const float* weight;  // [Cin, Cout, kD, 4, 4]
+    const float* bias;
+    float* out;
+    Geom out_g;
+    int kd;       // 4 (stride 2 in D) or 3 (stride 1 in D)
+    int lrelu;
+    double* partials;
+};
+int launch_deconv_direct(const DeconvLayer& L, hipStream_t s);
+int deconv_direct_tiles(const Geom& out_g);
+
+// partial sums -> (scale, shift).  groups = N*C*(per_plane ? D : 1); each group reduces
+// `per_group` consecutive partial records of (sum, sumsq); count = elements per group.
+int launch_in_finalize(const double* partials, int groups, int per_group, double count,
+                       const float* gamma, const float* beta, int channels, int groups_per_channel_block,
+                       float* scale, float* shift, hipStream_t s);
+
+// out = a (+ b), both deferred-normalised
+int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s);
+
+int launch_subpixel_map(const float* sim, float* disp, int batch, int planes, int height, int width,
+                        int taps_lo, int taps_hi, int step, hipStream_t s);
+
+int launch_shift_concat(const float* left, const float* right, float* out, int batch, int channels,
+                        int h, int w, int d_begin, int d_count, hipStream_t s);
+
+// Matching layer 0, factorised: x0[b,c,d,y,x] = A[b,c,y,x] + G[b,c,y,x-d] with the
+// right-edge fix.  A = conv_L(L)+bias [B,C,h,w]; G, G2 [B,C,h,w+1] indexed by u+1, u = x-d.
+int launch_l0_combine(const float* A, const float* G, const float* G2, float* x0, int batch,
+                      int channels, int h, int w, int d_begin, int d_count, hipStream_t s);
+
+// small utility: zero-pad one column on the left ([.., w] -> [.., w+1]); split conv0 weights
+int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_t s);
+int launch_split_first_weights(const float* w0, float* wl, float* wr, float* wr2, int cout, int cin_half,
+                               hipStream_t s);
+
+// ---- wave helpers ------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+}  // namespace pds

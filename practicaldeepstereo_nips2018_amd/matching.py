@@ -1,0 +1,188 @@
+"""Matching and MatchingOperation on MI355X.
+
+Drop-in mirrors of reference practical_deep_stereo/matching.py:16-63 (``Matching``) and :66-112
+(``MatchingOperation``): same constructor arguments, ``set_maximum_disparity``, ``forward``
+signature, output layout ``[batch, features, disparity, y, x]`` and state-dict keys
+(``_operation._matching_operation_modules.{0..3}...``).  The arithmetic runs in libpds_hip.so:
+
+* ``Matching`` with a ``MatchingOperation`` takes the fused path ``pds_matching_fwd``: the linear
+  first convolution is factorised into conv_L(left) + shift_d(conv_R(right)) so the right
+  descriptor is convolved once for all disparities, the 64->64 convolutions run as exact-fp32 MFMA
+  implicit GEMMs over all disparity planes at once with LeakyReLU and the per-plane InstanceNorm
+  statistics fused, and the last convolution writes straight into the stacked layout.
+* ``Matching`` with any other callable builds cat([left, S_d(right)]) for all disparities with one
+  HIP kernel (``pds_shift_concat_fwd``) and applies the callable per plane, like the reference.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from practicaldeepstereo_nips2018_amd import _lib
+from practicaldeepstereo_nips2018_amd import network_blocks
+
+
+class MatchingOperation(nn.Module):
+    """Operation applied to concatenated left / right descriptors (matching.py:66-112)."""
+
+    def __init__(self,
+                 number_of_concatenated_descriptor_features=128,
+                 number_of_features=64,
+                 number_of_compact_matching_signature_features=8,
+                 number_of_residual_blocks=2):
+        super(MatchingOperation, self).__init__()
+        if number_of_concatenated_descriptor_features % 2 != 0:
+            raise ValueError('"number_of_concatenated_descriptor_features" should be even.')
+        self._number_of_residual_blocks = number_of_residual_blocks
+        layers = [network_blocks.convolution_3x3(number_of_concatenated_descriptor_features,
+                                                 number_of_features)]
+        for _ in range(number_of_residual_blocks):
+            layers.append(network_blocks.ResidualBlock(number_of_features))
+        layers.append(network_blocks.convolution_3x3(
+            number_of_features, number_of_compact_matching_signature_features))
+        self._matching_operation_modules = nn.ModuleList(layers)
+        self._workspace = _lib.Workspace()
+
+    # -- geometry ------------------------------------------------------------------------------
+    @property
+    def number_of_features(self):
+        return self._matching_operation_modules[0].out_channels
+
+    @property
+    def number_of_descriptor_features(self):
+        return self._matching_operation_modules[0].in_channels // 2
+
+    @property
+    def number_of_signature_features(self):
+        return self._matching_operation_modules[-1].out_channels
+
+    def supports_fused_matching(self):
+        """The factorised first layer needs the descriptor width to equal the feature width
+        (128 -> 64 in the reference: two 64-channel descriptors)."""
+        return self.number_of_descriptor_features == self.number_of_features
+
+    def native_params(self):
+        """(PdsMatchingParams, keep-alive list) pointing at this module's parameters."""
+        mods = self._matching_operation_modules
+        blocks = []
+        for residual in mods[1:-1]:
+            for block in residual.convolutions:
+                blocks.append(_lib.conv_block_params(block.conv, block.norm))
+        array = (_lib.ConvBlockParams * max(len(blocks), 1))(*blocks)
+        params = _lib.MatchingParams()
+        params.features = self.number_of_features
+        params.signature_features = self.number_of_signature_features
+        params.residual_blocks = self._number_of_residual_blocks
+        params.first = _lib.conv_block_params(mods[0])
+        params.blocks = ctypes.cast(array, ctypes.POINTER(_lib.ConvBlockParams))
+        params.last = _lib.conv_block_params(mods[-1])
+        return params, array
+
+    def forward(self, concatenated_descriptors):
+        """[batch, 128, h, w] -> compact matching signature [batch, 8, h, w] (matching.py:97-112)."""
+        x = _lib.require_gpu_tensor(concatenated_descriptors, 'concatenated_descriptors', 4)
+        if x.size(1) != self._matching_operation_modules[0].in_channels:
+            raise ValueError('expected %d concatenated descriptor features, got %d' %
+                             (self._matching_operation_modules[0].in_channels, x.size(1)))
+        return _MatchingOperationFunction.apply(self, x, *self.parameters())
+
+
+class _MatchingOperationFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *unused_parameters):
+        lib = _lib.load()
+        n, _, h, w = x.shape
+        params, keep = module.native_params()
+        out = torch.empty((n, module.number_of_signature_features, h, w), dtype=torch.float32,
+                          device=x.device)
+        nbytes = lib.pds_matching_operation_workspace_bytes(ctypes.byref(params), n, h, w)
+        ws = module._workspace.get(nbytes, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pds_matching_operation_fwd(
+                ctypes.byref(params), _lib.ptr(x), _lib.ptr(out), n, h, w,
+                _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)), 'pds_matching_operation_fwd')
+        del keep
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _lib.not_differentiable('MatchingOperation')
+
+
+class Matching(nn.Module):
+    """Applies ``operation`` to cat([left, right shifted by d]) for d in [0, maximum_disparity]
+    and stacks the results on dim 2 (matching.py:16-63)."""
+
+    def __init__(self, maximum_disparity, operation):
+        super(Matching, self).__init__()
+        self._maximum_disparity = maximum_disparity
+        self._operation = operation
+        self._workspace = _lib.Workspace()
+        # [begin, count) of the disparity planes this process computes; None = all
+        self._disparity_shard = None
+
+    def set_maximum_disparity(self, maximum_disparity):
+        self._maximum_disparity = maximum_disparity
+
+    def set_disparity_shard(self, shard):
+        """shard = (first_plane, number_of_planes) or None; used by the multi-GPU wrapper."""
+        self._disparity_shard = shard
+
+    def _plane_range(self):
+        if self._disparity_shard is None:
+            return 0, self._maximum_disparity + 1
+        begin, count = self._disparity_shard
+        if begin < 0 or count < 1 or begin + count > self._maximum_disparity + 1:
+            raise ValueError('disparity shard (%d, %d) outside [0, %d]' %
+                             (begin, count, self._maximum_disparity))
+        return begin, count
+
+    def forward(self, left_embedding, right_embedding):
+        """left/right [batch, features, y, x] -> [batch, op features, disparity, y, x]."""
+        left = _lib.require_gpu_tensor(left_embedding, 'left_embedding', 4)
+        right = _lib.require_gpu_tensor(right_embedding, 'right_embedding', 4)
+        if left.shape != right.shape:
+            raise ValueError('left and right embeddings differ in shape: %s vs %s' %
+                             (tuple(left.shape), tuple(right.shape)))
+        begin, count = self._plane_range()
+        operation = self._operation
+        if (isinstance(operation, MatchingOperation) and operation.supports_fused_matching()
+                and left.size(1) == operation.number_of_descriptor_features):
+            return _FusedMatchingFunction.apply(self, left, right, begin, count,
+                                                *operation.parameters())
+        return self._forward_generic(left, right, begin, count)
+
+    def _forward_generic(self, left, right, begin, count):
+        lib = _lib.load()
+        batch, channels, h, w = left.shape
+        concatenated = torch.empty((count, batch, 2 * channels, h, w), dtype=torch.float32,
+                                   device=left.device)
+        with torch.cuda.device(left.device):
+            _lib.check(lib.pds_shift_concat_fwd(
+                _lib.ptr(left), _lib.ptr(right), _lib.ptr(concatenated), batch, channels, h, w,
+                begin, count, _lib.stream_handle(left.device)), 'pds_shift_concat_fwd')
+        return torch.stack([self._operation(plane) for plane in concatenated.unbind(0)], dim=2)
+
+
+class _FusedMatchingFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, left, right, begin, count, *unused_parameters):
+        lib = _lib.load()
+        operation = module._operation
+        batch, _, h, w = left.shape
+        params, keep = operation.native_params()
+        out = torch.empty((batch, operation.number_of_signature_features, count, h, w),
+                          dtype=torch.float32, device=left.device)
+        nbytes = lib.pds_matching_workspace_bytes(ctypes.byref(params), batch, h, w, count)
+        ws = module._workspace.get(nbytes, left.device)
+        with torch.cuda.device(left.device):
+            _lib.check(lib.pds_matching_fwd(
+                ctypes.byref(params), _lib.ptr(left), _lib.ptr(right), _lib.ptr(out),
+                batch, h, w, begin, count, _lib.ptr(ws), ws.numel(),
+                _lib.stream_handle(left.device)), 'pds_matching_fwd')
+        del keep
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _lib.not_differentiable('Matching')

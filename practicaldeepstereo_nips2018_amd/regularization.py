@@ -1,0 +1,200 @@
+"""3-D hourglass regularization of the matching cost volume on MI355X.
+
+Drop-in mirrors of reference practical_deep_stereo/regularization.py: ``ContractionBlock3d``
+(:11-31), ``ExpansionBlock3d`` (:34-57) and ``Regularization`` (:60-126) with the same constructor
+arguments, call signatures and state-dict keys (``_smoothing``, ``_contraction_blocks.{0-3}.
+{_downsampling_2x,_smoothing}``, ``_expansion_blocks.{0-3}.{_upsampling_2x,_smoothing}``,
+``_upsample_to_halfsize``, ``_upsample_to_fullsize``).  All arithmetic runs in libpds_hip.so: every
+layer stores LeakyReLU(conv) once plus partial InstanceNorm sums; the normalisation itself, the
+skip additions and the broadcast of the left-image shortcut are folded into the loads of the
+consuming layer, so no normalised tensor is ever written inside the hourglass.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from practicaldeepstereo_nips2018_amd import _lib
+from practicaldeepstereo_nips2018_amd import network_blocks
+
+
+def _block_params(block):
+    return _lib.conv_block_params(block.conv, block.norm)
+
+
+class ContractionBlock3d(nn.Module):
+    """2x "downsampling" convolution followed by a "smoothing" convolution (regularization.py:11-31)."""
+
+    def __init__(self, number_of_features):
+        super(ContractionBlock3d, self).__init__()
+        self._downsampling_2x = network_blocks.convolutional_block_3x3x3_stride_2(
+            number_of_features, 2 * number_of_features)
+        self._smoothing = network_blocks.convolutional_block_3x3x3(
+            2 * number_of_features, 2 * number_of_features)
+        self._workspace = _lib.Workspace()
+
+    def forward(self, block_input):
+        x = _lib.require_gpu_tensor(block_input, 'block_input', 5)
+        if x.size(1) != self._downsampling_2x.conv.in_channels:
+            raise ValueError('expected %d input features, got %d' %
+                             (self._downsampling_2x.conv.in_channels, x.size(1)))
+        return _ContractionFunction.apply(self, x, *self.parameters())
+
+
+class _ContractionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *unused_parameters):
+        lib = _lib.load()
+        batch, c, d, h, w = x.shape
+        shape = (batch, 2 * c, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2)
+        down = torch.empty(shape, dtype=torch.float32, device=x.device)
+        smooth = torch.empty(shape, dtype=torch.float32, device=x.device)
+        pd, ps = _block_params(module._downsampling_2x), _block_params(module._smoothing)
+        nbytes = lib.pds_contraction_block_workspace_bytes(batch, c, d, h, w)
+        ws = module._workspace.get(nbytes, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pds_contraction_block_fwd(
+                ctypes.byref(pd), ctypes.byref(ps), _lib.ptr(x), _lib.ptr(down), _lib.ptr(smooth),
+                batch, c, d, h, w, _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)),
+                'pds_contraction_block_fwd')
+        return down, smooth
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _lib.not_differentiable('ContractionBlock3d')
+
+
+class ExpansionBlock3d(nn.Module):
+    """2x "upsampling" transposed convolution, skip sum, "smoothing" convolution
+    (regularization.py:34-57)."""
+
+    def __init__(self, number_of_features):
+        super(ExpansionBlock3d, self).__init__()
+        self._upsampling_2x = network_blocks.transposed_convolutional_block_4x4x4_stride_2(
+            number_of_features, number_of_features // 2)
+        self._smoothing = network_blocks.convolutional_block_3x3x3(
+            number_of_features // 2, number_of_features // 2)
+        self._workspace = _lib.Workspace()
+
+    def forward(self, block_input, shortcut_from_contraction):
+        x = _lib.require_gpu_tensor(block_input, 'block_input', 5)
+        shortcut = _lib.require_gpu_tensor(shortcut_from_contraction, 'shortcut_from_contraction', 5)
+        batch, c, d, h, w = x.shape
+        if c != self._upsampling_2x.conv.in_channels:
+            raise ValueError('expected %d input features, got %d' % (self._upsampling_2x.conv.in_channels, c))
+        if tuple(shortcut.shape) != (batch, c // 2, 2 * d, 2 * h, 2 * w):
+            raise ValueError('shortcut of shape %s does not match upsampled input %s' %
+                             (tuple(shortcut.shape), (batch, c // 2, 2 * d, 2 * h, 2 * w)))
+        return _ExpansionFunction.apply(self, x, shortcut, *self.parameters())
+
+
+class _ExpansionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, shortcut, *unused_parameters):
+        lib = _lib.load()
+        batch, c, d, h, w = x.shape
+        out = torch.empty_like(shortcut)
+        pu, ps = _block_params(module._upsampling_2x), _block_params(module._smoothing)
+        nbytes = lib.pds_expansion_block_workspace_bytes(batch, c, d, h, w)
+        ws = module._workspace.get(nbytes, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pds_expansion_block_fwd(
+                ctypes.byref(pu), ctypes.byref(ps), _lib.ptr(x), _lib.ptr(shortcut), _lib.ptr(out),
+                batch, c, d, h, w, _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)),
+                'pds_expansion_block_fwd')
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _lib.not_differentiable('ExpansionBlock3d')
+
+
+class Regularization(nn.Module):
+    """Hourglass 3-D network: /16 contraction, expansion back, then x2 (D, H, W) and x2 (H, W)
+    up-sampling; returns matching cost for even disparities (regularization.py:60-126)."""
+
+    def __init__(self, number_of_features=8):
+        super(Regularization, self).__init__()
+        self._smoothing = network_blocks.convolutional_block_3x3x3(
+            number_of_features, number_of_features)
+        self._contraction_blocks = nn.ModuleList(
+            [ContractionBlock3d(number_of_features * scale) for scale in (1, 2, 4, 8)])
+        self._expansion_blocks = nn.ModuleList(
+            [ExpansionBlock3d(number_of_features * scale) for scale in (16, 8, 4, 2)])
+        self._upsample_to_halfsize = network_blocks.transposed_convolutional_block_4x4x4_stride_2(
+            number_of_features, number_of_features // 2)
+        self._upsample_to_fullsize = network_blocks.transposed_convolution_3x4x4_stride_122(
+            number_of_features // 2, 1)
+        self._workspace = _lib.Workspace()
+
+    @property
+    def number_of_features(self):
+        return self._smoothing.conv.in_channels
+
+    def native_params(self):
+        params = _lib.RegularizationParams()
+        params.features = self.number_of_features
+        params.smoothing = _block_params(self._smoothing)
+        for level in range(4):
+            contraction, expansion = self._contraction_blocks[level], self._expansion_blocks[level]
+            params.contraction[level][0] = _block_params(contraction._downsampling_2x)
+            params.contraction[level][1] = _block_params(contraction._smoothing)
+            params.expansion[level][0] = _block_params(expansion._upsampling_2x)
+            params.expansion[level][1] = _block_params(expansion._smoothing)
+        params.upsample_half = _block_params(self._upsample_to_halfsize)
+        params.upsample_full = _lib.conv_block_params(self._upsample_to_fullsize)
+        return params
+
+    def _check_inputs(self, matching_signatures, shortcut_from_left_image):
+        ms = _lib.require_gpu_tensor(matching_signatures, 'matching_signatures', 5)
+        shortcut = _lib.require_gpu_tensor(shortcut_from_left_image, 'shortcut_from_left_image', 4)
+        batch, c, d, h, w = ms.shape
+        if c != self.number_of_features:
+            raise ValueError('expected %d matching signature features, got %d' % (self.number_of_features, c))
+        if tuple(shortcut.shape) != (batch, c, h, w):
+            raise ValueError('shortcut of shape %s does not match signatures %s' %
+                             (tuple(shortcut.shape), tuple(ms.shape)))
+        return ms, shortcut
+
+    def forward(self, matching_signatures, shortcut_from_left_image):
+        """[batch, 8, D, h, w] + [batch, 8, h, w] -> matching cost [batch, 2D, 4h, 4w]."""
+        ms, shortcut = self._check_inputs(matching_signatures, shortcut_from_left_image)
+        return _RegularizationFunction.apply(self, ms, shortcut, None, *self.parameters())
+
+    def forward_with_estimator(self, matching_signatures, shortcut_from_left_image, estimator):
+        """Eval-mode fusion used by PdsNetwork: Regularization followed by SubpixelMap without
+        materialising the full-resolution cost volume (network.py:50-51).  -> [batch, 4h, 4w]."""
+        ms, shortcut = self._check_inputs(matching_signatures, shortcut_from_left_image)
+        window = (estimator._half_support_window, estimator._disparity_step)
+        return _RegularizationFunction.apply(self, ms, shortcut, window, *self.parameters())
+
+
+class _RegularizationFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, ms, shortcut, estimator_window, *unused_parameters):
+        lib = _lib.load()
+        batch, _, d, h, w = ms.shape
+        params = module.native_params()
+        nbytes = lib.pds_regularization_workspace_bytes(ctypes.byref(params), batch, d, h, w)
+        if nbytes == 0:
+            raise ValueError(lib.pds_last_error().decode())
+        ws = module._workspace.get(nbytes, ms.device)
+        with torch.cuda.device(ms.device):
+            if estimator_window is None:
+                out = torch.empty((batch, 2 * d, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
+                _lib.check(lib.pds_regularization_fwd(
+                    ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
+                    batch, d, h, w, _lib.ptr(ws), ws.numel(), _lib.stream_handle(ms.device)),
+                    'pds_regularization_fwd')
+            else:
+                out = torch.empty((batch, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
+                _lib.check(lib.pds_regularization_subpixel_map_fwd(
+                    ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
+                    batch, d, h, w, estimator_window[0], estimator_window[1],
+                    _lib.ptr(ws), ws.numel(), _lib.stream_handle(ms.device)),
+                    'pds_regularization_subpixel_map_fwd')
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _lib.not_differentiable('Regularization')

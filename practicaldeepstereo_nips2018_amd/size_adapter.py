@@ -1,0 +1,26 @@
+"""Pads network inputs to multiples of a minimum size and crops the output back.
+
+Off the hot path; same behaviour as reference
+practical_deep_stereo/size_adapter.py:11-52: zero rows are added on TOP and zero columns on the
+LEFT, and the amounts of the last ``pad`` call are remembered for ``unpad``.
+"""
+import torch.nn.functional as F
+
+
+class SizeAdapter(object):
+    def __init__(self, minimum_size=64):
+        self._minimum_size = minimum_size
+        self._pixels_pad_to_width = None
+        self._pixels_pad_to_height = None
+
+    def _padding_for(self, size):
+        return (-size) % self._minimum_size
+
+    def pad(self, network_input):
+        height, width = network_input.shape[-2:]
+        self._pixels_pad_to_height = self._padding_for(height)
+        self._pixels_pad_to_width = self._padding_for(width)
+        return F.pad(network_input, (self._pixels_pad_to_width, 0, self._pixels_pad_to_height, 0))
+
+    def unpad(self, network_output):
+        return network_output[..., self._pixels_pad_to_height:, self._pixels_pad_to_width:]

@@ -1,0 +1,264 @@
+"""Generates the committed golden fixtures and pins oracle/pds_oracle.py against the reference.
+
+Run ONLY in the build container, where the reference is importable:
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference (read-only), runs the reference modules on seeded inputs, asserts the
+oracle restatement reproduces them, and writes small ``.npz`` fixtures (inputs, expected outputs,
+weight checksums) next to this file plus ``pinning_report.json`` with the measured differences.
+Nothing of the reference travels: fixtures are data only.  Weights are never stored; they are
+re-created by ``torch.manual_seed`` + constructing this repo's own modules (identical construction
+order) and guarded by an fp64 checksum.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+from practical_deep_stereo import estimator as ref_estimator  # noqa: E402
+from practical_deep_stereo import matching as ref_matching  # noqa: E402
+from practical_deep_stereo import network as ref_network  # noqa: E402
+from practical_deep_stereo import regularization as ref_regularization  # noqa: E402
+
+from oracle import pds_oracle as oracle  # noqa: E402
+
+REPORT = {}
+
+
+def checksum(state_dict):
+    return float(sum(v.double().sum() for v in state_dict.values()))
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def prefixed(state_dict, prefix):
+    return {prefix + '.' + k: v for k, v in state_dict.items()}
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+
+
+def mock_operation(x):
+    return torch.max(x, dim=1, keepdim=True)[0]
+
+
+@torch.no_grad()
+def g1_matching_mock():
+    left = torch.tensor([0., 2., 1., 2.]).view(1, 1, 1, 4)
+    right = torch.tensor([3., 4., 2., 4.]).view(1, 1, 1, 4)
+    outs = {}
+    for n in (2, 1, 0):
+        ref = ref_matching.Matching(maximum_disparity=n, operation=mock_operation)(left, right)
+        mine = oracle.matching(left, right, n, mock_operation)
+        assert torch.equal(ref, mine)
+        outs['out_max%d' % n] = ref
+    # the reference's own expected values, test/test_matching.py:22-31
+    assert np.array_equal(outs['out_max2'].numpy().reshape(3, 4), [[3, 4, 2, 4], [0, 3, 4, 2], [0, 2, 3, 4]])
+    # a wider random case with several channels and rows
+    g = torch.Generator().manual_seed(11)
+    l2 = torch.randn(2, 3, 4, 9, generator=g)
+    r2 = torch.randn(2, 3, 4, 9, generator=g)
+    ref = ref_matching.Matching(maximum_disparity=5, operation=mock_operation)(l2, r2)
+    assert torch.equal(ref, oracle.matching(l2, r2, 5, mock_operation))
+    save('g1_matching_mock', left=left, right=right, left2=l2, right2=r2, out2_max5=ref, **outs)
+    REPORT['g1_matching_mock'] = 'bit-exact'
+
+
+@torch.no_grad()
+def g2_matching_operation():
+    torch.manual_seed(0)
+    op = ref_matching.MatchingOperation()
+    net = ref_matching.Matching(maximum_disparity=15, operation=op)
+    g = torch.Generator().manual_seed(2)
+    left = torch.randn(1, 64, 16, 32, generator=g)
+    right = torch.randn(1, 64, 16, 32, generator=g)
+    ref = net(left, right)
+    p = prefixed(op.state_dict(), '_m._operation')
+    mine = oracle.matching_with_operation(p, '_m', left, right, 15)
+    d = maxdiff(ref, mine)
+    assert d <= 1e-6, d
+    # standalone MatchingOperation on an explicit concatenation, batch 2, odd size
+    x = torch.rand(2, 128, 25, 25, generator=g)
+    ref_op = op(x)
+    mine_op = oracle.matching_operation(p, '_m._operation', x)
+    assert maxdiff(ref_op, mine_op) <= 1e-6
+    save('g2_matching', left=left, right=right, signatures=ref, weight_checksum=checksum(op.state_dict()),
+         concatenated=x, operation_out=ref_op)
+    REPORT['g2_matching'] = {'oracle_vs_reference_max': d,
+                             'operation_max': maxdiff(ref_op, mine_op)}
+
+
+@torch.no_grad()
+def g3_regularization():
+    torch.manual_seed(0)
+    reg = ref_regularization.Regularization()
+    g = torch.Generator().manual_seed(3)
+    ms = torch.randn(1, 8, 16, 16, 32, generator=g)
+    shortcut = torch.randn(1, 8, 16, 32, generator=g)
+    ref = reg(ms, shortcut)
+    p = prefixed(reg.state_dict(), '_r')
+    mine = oracle.regularization(p, '_r', ms, shortcut)
+    d = maxdiff(ref, mine)
+    assert d <= 1e-6, d
+    save('g3_regularization', signatures=ms, shortcut=shortcut, cost=ref,
+         weight_checksum=checksum(reg.state_dict()))
+    REPORT['g3_regularization'] = {'oracle_vs_reference_max': d}
+
+
+@torch.no_grad()
+def g4_blocks():
+    torch.manual_seed(0)
+    x = torch.rand(2, 6, 10, 14, 16)
+    con = ref_regularization.ContractionBlock3d(number_of_features=6)
+    down, smooth = con(x)
+    pc = prefixed(con.state_dict(), '_c')
+    d1, s1 = oracle.contraction_block_3d(pc, '_c', x)
+    assert maxdiff(down, d1) <= 1e-6 and maxdiff(smooth, s1) <= 1e-6
+    torch.manual_seed(0)
+    xi = torch.rand(2, 6, 10, 14, 16)
+    sc = torch.rand(2, 3, 20, 28, 32)
+    exp = ref_regularization.ExpansionBlock3d(number_of_features=6)
+    out = exp(xi, sc)
+    pe = prefixed(exp.state_dict(), '_e')
+    o1 = oracle.expansion_block_3d(pe, '_e', xi, sc)
+    assert maxdiff(out, o1) <= 1e-6
+    save('g4_blocks', contraction_in=x, contraction_down=down, contraction_smooth=smooth,
+         contraction_checksum=checksum(con.state_dict()),
+         expansion_in=xi, expansion_shortcut=sc, expansion_out=out,
+         expansion_checksum=checksum(exp.state_dict()))
+    REPORT['g4_blocks'] = {'contraction_max': max(maxdiff(down, d1), maxdiff(smooth, s1)),
+                           'expansion_max': maxdiff(out, o1)}
+
+
+@torch.no_grad()
+def g5_subpixel_map():
+    cases = {}
+    worst = 0.0
+    sim5 = torch.tensor([0.1, 0.4, 0.3, 0.2, 0.3]).view(1, 5, 1, 1)
+    for name, sim, hw, step in [
+            ('ref_test_21', sim5, 2, 1),                      # test/test_estimator.py:14-21 -> 1.52
+            ('ref_test_22', sim5, 2, 2),                      # test/test_estimator.py:23-27 -> 2.124
+            ('tie_first', torch.tensor([1., .5, 1., .2, 1., .1]).view(1, 6, 1, 1), 4, 2),
+            ('all_equal', torch.ones(1, 6, 1, 1), 4, 2),
+            ('edge_low', torch.tensor([2., .5, 1., .2, 1., .1]).view(1, 6, 1, 1), 4, 2),
+            ('edge_high', torch.tensor([0., .5, 1., .2, 1., 3.1]).view(1, 6, 1, 1), 4, 2),
+            ('random_42', torch.randn(2, 32, 8, 8, generator=torch.Generator().manual_seed(5)), 4, 2),
+            ('random_41', torch.randn(2, 9, 5, 7, generator=torch.Generator().manual_seed(6)), 4, 1),
+            ('random_84', torch.randn(1, 40, 6, 12, generator=torch.Generator().manual_seed(7)), 8, 4),
+            ('random_102', torch.randn(1, 24, 3, 5, generator=torch.Generator().manual_seed(8)), 10, 2),
+            ('single_plane', torch.randn(1, 1, 4, 4, generator=torch.Generator().manual_seed(9)), 4, 2)]:
+        ref = ref_estimator.SubpixelMap(half_support_window=hw, disparity_step=step)(sim)
+        mine = oracle.subpixel_map(sim, hw, step)
+        d = maxdiff(ref, mine)
+        assert d <= 1e-5, (name, d)
+        worst = max(worst, d)
+        cases[name + '_in'] = sim
+        cases[name + '_out'] = ref
+        cases[name + '_cfg'] = np.array([hw, step])
+    assert abs(float(cases['ref_test_21_out'].reshape(-1)[0]) - 1.52) < 1e-4
+    assert abs(float(cases['ref_test_22_out'].reshape(-1)[0]) - 2.124) < 1e-4
+    for bad in [(4, 0), (0, 2), (3, 2)]:
+        for cls in (ref_estimator.SubpixelMap,):
+            try:
+                cls(half_support_window=bad[0], disparity_step=bad[1])
+                raise AssertionError('expected ValueError')
+            except ValueError:
+                pass
+        try:
+            oracle.check_subpixel_map_arguments(*bad)
+            raise AssertionError('expected ValueError')
+        except ValueError:
+            pass
+    save('g5_subpixel_map', **cases)
+    REPORT['g5_subpixel_map'] = {'oracle_vs_reference_max': worst}
+
+
+def images(batch, height, width):
+    g = torch.Generator().manual_seed(1)
+    left = torch.rand(batch, 3, height, width, generator=g) * 255
+    right = torch.rand(batch, 3, height, width, generator=g) * 255
+    return left, right
+
+
+def stage_stats(t):
+    d = t.double()
+    return np.array([d.mean().item(), d.std().item(), d.min().item(), d.max().item(), d.sum().item(),
+                     d.abs().sum().item()])
+
+
+@torch.no_grad()
+def g6_config1_network():
+    """Config 1: full PdsNetwork.default(63) eval forward on a 128x256 pair."""
+    torch.manual_seed(0)
+    net = ref_network.PdsNetwork.default(63).eval()
+    left, right = images(1, 128, 256)
+    ld, shortcut = net._embedding(net._size_adapter.pad(left))
+    rd = net._embedding(net._size_adapter.pad(right))[0]
+    ms = net._matching(ld, rd)
+    cost = net._regularization(ms, shortcut)
+    disparity = net._estimator(cost)
+    full = net(left, right)
+    assert torch.equal(full, disparity)
+    p = net.state_dict()
+    ms_o, cost_o, disp_o = oracle.hot_path(p, ld, rd, shortcut, 63, return_stages=True)
+    rep = {'ms_max': maxdiff(ms, ms_o), 'cost_max': maxdiff(cost, cost_o), 'disparity_max': maxdiff(disparity, disp_o)}
+    assert rep['ms_max'] <= 1e-6 and rep['cost_max'] <= 1e-5 and rep['disparity_max'] <= 1e-3, rep
+    save('g6_config1', disparity=disparity, left_descriptor_stats=stage_stats(ld),
+         signatures_stats=stage_stats(ms), cost_stats=stage_stats(cost),
+         cost_sub=cost[:, ::4, ::8, ::8].contiguous(), signatures_sub=ms[:, :, ::2, ::4, ::4].contiguous(),
+         weight_checksum=checksum(p))
+    REPORT['g6_config1'] = rep
+
+
+@torch.no_grad()
+def g7_config2_statistics():
+    """Config 2 (960x540, D=192): per-stage statistics and a sub-sample, not the 212 MB tensors."""
+    torch.manual_seed(0)
+    net = ref_network.PdsNetwork.default(191).eval()
+    left, right = images(1, 540, 960)
+    ld, shortcut = net._embedding(net._size_adapter.pad(left))
+    rd = net._embedding(net._size_adapter.pad(right))[0]
+    ms = net._matching(ld, rd)
+    cost = net._regularization(ms, shortcut)
+    disparity = net._estimator(cost)
+    p = net.state_dict()
+    ms_o, cost_o, disp_o = oracle.hot_path(p, ld, rd, shortcut, 191, return_stages=True)
+    delta = (disparity - disp_o).abs()
+    rep = {'ms_max': maxdiff(ms, ms_o), 'cost_max': maxdiff(cost, cost_o),
+           'disparity_mae': float(delta.mean()), 'disparity_flips': float((delta > 0.5).double().mean())}
+    assert rep['ms_max'] <= 2e-5 and rep['cost_max'] <= 1e-4 and rep['disparity_mae'] <= 1e-3, rep
+    save('g7_config2_stats', signatures_stats=stage_stats(ms), cost_stats=stage_stats(cost),
+         disparity_stats=stage_stats(disparity), disparity_sub=disparity[:, ::16, ::16].contiguous(),
+         cost_sub=cost[:, ::8, ::32, ::32].contiguous(),
+         signatures_sub=ms[:, :, ::4, ::16, ::16].contiguous(), weight_checksum=checksum(p))
+    REPORT['g7_config2'] = rep
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    g1_matching_mock()
+    g2_matching_operation()
+    g3_regularization()
+    g4_blocks()
+    g5_subpixel_map()
+    g6_config1_network()
+    if '--skip-config2' not in sys.argv:
+        g7_config2_statistics()
+    REPORT['torch'] = torch.__version__
+    with open(os.path.join(HERE, 'pinning_report.json'), 'w') as f:
+        json.dump(REPORT, f, indent=2, sort_keys=True)
+    print(json.dumps(REPORT, indent=2, sort_keys=True))

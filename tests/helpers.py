@@ -1,0 +1,47 @@
+"""Shared helpers of the test-suite: seeded modules, golden fixtures, error metrics."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz')) as z:
+        return {k: torch.from_numpy(np.array(z[k])) for k in z.files}
+
+
+def checksum(state_dict):
+    return float(sum(v.double().sum() for v in state_dict.values()))
+
+
+def prefixed(state_dict, prefix):
+    return {prefix + '.' + k: v.detach().cpu() for k, v in state_dict.items()}
+
+
+def seeded(factory, seed=0):
+    torch.manual_seed(seed)
+    return factory()
+
+
+def images(batch, height, width):
+    """Input recipe of SURVEY.md 8c: left first, then right, uniform [0, 255)."""
+    g = torch.Generator().manual_seed(1)
+    left = torch.rand(batch, 3, height, width, generator=g) * 255
+    right = torch.rand(batch, 3, height, width, generator=g) * 255
+    return left, right
+
+
+def maxdiff(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def meandiff(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().mean())
+
+
+def disparity_report(gpu, cpu):
+    delta = (gpu.detach().double().cpu() - cpu.detach().double().cpu()).abs()
+    return {'mae': float(delta.mean()), 'max': float(delta.max()),
+            'flips': float((delta > 0.5).double().mean())}

@@ -1,0 +1,333 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Stated fp32 tolerances: Matching out max-abs <= 2e-5; cost volume max-abs <= 1e-4 and
+mean-abs <= 1e-5; estimator on identical cost max-abs <= 1e-3 px / MAE <= 1e-4; end-to-end disparity
+MAE <= 1e-3 with the flip fraction (|delta| > 0.5 px) reported.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pds_oracle as oracle
+from tests import helpers
+import practicaldeepstereo_nips2018_amd as pds
+
+pytestmark = pytest.mark.gpu
+
+TOL_SIGNATURES = 2e-5
+TOL_COST_MAX = 1e-4
+TOL_COST_MEAN = 1e-5
+TOL_EST_MAX = 1e-3
+TOL_EST_MAE = 1e-4
+TOL_DISPARITY_MAE = 1e-3
+
+
+@pytest.fixture(scope='module')
+def dev(hip_library):
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def mock_operation(x):
+    return torch.max(x, dim=1, keepdim=True)[0]
+
+
+# ------------------------------------------------------------------------------- estimator (a8)
+def test_subpixel_map_reference_known_answers(dev):
+    sim = torch.tensor([0.1, 0.4, 0.3, 0.2, 0.3], device=dev).view(1, 5, 1, 1)
+    assert abs(pds.SubpixelMap(2, 1)(sim).item() - 1.52) < 1e-4      # test_estimator.py:14-21
+    assert abs(pds.SubpixelMap(2, 2)(sim).item() - 2.124) < 1e-4     # test_estimator.py:23-27
+
+
+def test_subpixel_map_golden_cases(dev):
+    g = helpers.golden('g5_subpixel_map')
+    for name in sorted(k[:-3] for k in g if k.endswith('_in')):
+        hw, step = [int(v) for v in g[name + '_cfg']]
+        out = pds.SubpixelMap(hw, step)(g[name + '_in'].to(dev))
+        assert out.shape == g[name + '_out'].shape, name
+        assert helpers.maxdiff(out, g[name + '_out']) <= 1e-5, name
+
+
+@pytest.mark.parametrize('shape,hw,step', [((2, 32, 17, 23), 4, 2), ((1, 96, 64, 128), 4, 2),
+                                           ((3, 7, 5, 4), 2, 1), ((1, 64, 33, 31), 8, 2),
+                                           ((1, 48, 16, 20), 12, 2)])
+def test_subpixel_map_random_vs_oracle(dev, shape, hw, step):
+    sim = torch.randn(*shape, generator=torch.Generator().manual_seed(3))
+    out = pds.SubpixelMap(hw, step)(sim.to(dev))
+    ref = oracle.subpixel_map(sim, hw, step)
+    assert helpers.maxdiff(out, ref) <= TOL_EST_MAX
+    assert helpers.meandiff(out, ref) <= TOL_EST_MAE
+
+
+def test_subpixel_map_ties_take_first_plane(dev):
+    sim = torch.zeros(1, 12, 4, 8)
+    sim[:, 3] = 1.0
+    sim[:, 9] = 1.0
+    out = pds.SubpixelMap()(sim.to(dev))
+    assert helpers.maxdiff(out, oracle.subpixel_map(sim)) <= 1e-5
+
+
+def test_subpixel_map_full_size_properties(dev):
+    """Config 2 size [1, 96, 576, 960]: range, one-hot recovery, agreement with the oracle."""
+    g = torch.Generator().manual_seed(4)
+    sim = torch.randn(1, 96, 576, 960, generator=g) * 0.58
+    out = pds.SubpixelMap()(sim.to(dev))
+    assert out.shape == (1, 576, 960)
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 2 * 95 + 1e-4
+    ref = oracle.subpixel_map(sim)
+    assert helpers.maxdiff(out, ref) <= TOL_EST_MAX
+    assert helpers.meandiff(out, ref) <= TOL_EST_MAE
+    hot = torch.full((1, 96, 64, 64), -50.0)
+    idx = torch.randint(0, 96, (1, 1, 64, 64), generator=g)
+    hot.scatter_(1, idx, 50.0)
+    got = pds.SubpixelMap()(hot.to(dev)).cpu()
+    assert torch.allclose(got, 2.0 * idx[:, 0].float(), atol=1e-4)
+
+
+# ------------------------------------------------------------------------------- matching (a1-a3)
+def test_matching_generic_operation_known_answer(dev):
+    # reference test/test_matching.py:17-32
+    net = pds.Matching(maximum_disparity=2, operation=mock_operation)
+    left = torch.tensor([0., 2., 1., 2.], device=dev).view(1, 1, 1, 4)
+    right = torch.tensor([3., 4., 2., 4.], device=dev).view(1, 1, 1, 4)
+    out = net(left, right)
+    assert np.array_equal(out.cpu().numpy().reshape(3, 4), [[3, 4, 2, 4], [0, 3, 4, 2], [0, 2, 3, 4]])
+    net.set_maximum_disparity(maximum_disparity=1)
+    out = net(left, right)
+    assert np.array_equal(out.cpu().numpy().reshape(2, 4), [[3, 4, 2, 4], [0, 3, 4, 2]])
+    g = helpers.golden('g1_matching_mock')
+    out = pds.Matching(5, mock_operation)(g['left2'].to(dev), g['right2'].to(dev))
+    assert torch.equal(out.cpu(), g['out2_max5'])
+
+
+def test_matching_operation_output_size_and_values(dev):
+    # reference test/test_matching.py:35-40 (shape) + golden values
+    g = helpers.golden('g2_matching')
+    op = helpers.seeded(pds.MatchingOperation).to(dev)
+    with torch.no_grad():
+        out = op(g['concatenated'].to(dev))
+    assert out.size() == (2, 8, 25, 25)
+    assert helpers.maxdiff(out, g['operation_out']) <= TOL_SIGNATURES
+
+
+def test_fused_matching_golden(dev):
+    g = helpers.golden('g2_matching')
+    op = helpers.seeded(pds.MatchingOperation)
+    net = pds.Matching(15, op).to(dev)
+    with torch.no_grad():
+        out = net(g['left'].to(dev), g['right'].to(dev))
+    assert out.shape == (1, 8, 16, 16, 32)
+    assert helpers.maxdiff(out, g['signatures']) <= TOL_SIGNATURES
+    # the fused path and the generic per-plane path (same HIP MatchingOperation) agree
+    generic = pds.Matching(15, lambda x: op(x))
+    with torch.no_grad():
+        out2 = generic(g['left'].to(dev), g['right'].to(dev))
+    assert helpers.maxdiff(out, out2) <= TOL_SIGNATURES
+
+
+@pytest.mark.parametrize('batch,h,w,maxd', [(2, 9, 21, 6), (1, 32, 64, 15), (1, 8, 16, 20), (1, 5, 7, 0)])
+def test_fused_matching_shapes_vs_oracle(dev, batch, h, w, maxd):
+    """Ragged sizes, batch > 1, disparity range wider than the image, single plane."""
+    op = helpers.seeded(pds.MatchingOperation, seed=7)
+    p = helpers.prefixed(op.state_dict(), '_m._operation')
+    g = torch.Generator().manual_seed(8)
+    left = torch.randn(batch, 64, h, w, generator=g)
+    right = torch.randn(batch, 64, h, w, generator=g)
+    ref = oracle.matching_with_operation(p, '_m', left, right, maxd)
+    net = pds.Matching(maxd, op).to(dev)
+    with torch.no_grad():
+        out = net(left.to(dev), right.to(dev))
+    assert out.shape == ref.shape
+    assert helpers.maxdiff(out, ref) <= TOL_SIGNATURES
+
+
+def test_disparity_sharding_is_bit_identical(dev):
+    """planes are independent, so N sequential shards concatenated == unsharded."""
+    op = helpers.seeded(pds.MatchingOperation)
+    g = torch.Generator().manual_seed(9)
+    left = torch.randn(1, 64, 16, 32, generator=g).to(dev)
+    right = torch.randn(1, 64, 16, 32, generator=g).to(dev)
+    net = pds.Matching(15, op).to(dev)
+    with torch.no_grad():
+        whole = net(left, right)
+        for shards in (2, 4, 8):
+            per = 16 // shards
+            parts = []
+            for r in range(shards):
+                net.set_disparity_shard((r * per, per))
+                parts.append(net(left, right))
+            net.set_disparity_shard(None)
+            assert torch.equal(torch.cat(parts, dim=2), whole), shards
+
+
+# ------------------------------------------------------------------------------- regularization (a4-a7)
+def test_contraction_and_expansion_blocks_golden(dev):
+    # shapes of reference test/test_regularization.py:11-26, values from the golden vectors
+    g = helpers.golden('g4_blocks')
+    con = helpers.seeded(lambda: (torch.rand(2, 6, 10, 14, 16), pds.ContractionBlock3d(6))[1]).to(dev)
+    with torch.no_grad():
+        down, smooth = con(g['contraction_in'].to(dev))
+    assert down.size() == (2, 12, 5, 7, 8) and smooth.size() == (2, 12, 5, 7, 8)
+    assert helpers.maxdiff(down, g['contraction_down']) <= TOL_COST_MAX
+    assert helpers.maxdiff(smooth, g['contraction_smooth']) <= TOL_COST_MAX
+
+    def make_expansion():
+        torch.rand(2, 6, 10, 14, 16)
+        torch.rand(2, 3, 20, 28, 32)
+        return pds.ExpansionBlock3d(6)
+    exp = helpers.seeded(make_expansion).to(dev)
+    with torch.no_grad():
+        out = exp(g['expansion_in'].to(dev), g['expansion_shortcut'].to(dev))
+    assert out.size() == (2, 3, 20, 28, 32)
+    assert helpers.maxdiff(out, g['expansion_out']) <= TOL_COST_MAX
+
+
+def test_regularization_output_size(dev):
+    # reference test/test_regularization.py:29-36
+    reg = helpers.seeded(pds.Regularization).to(dev)
+    with torch.no_grad():
+        cost = reg(torch.rand(2, 8, 32, 32, 32, device=dev), torch.rand(2, 8, 32, 32, device=dev))
+    assert cost.size() == (2, 64, 128, 128)
+
+
+def test_regularization_golden(dev):
+    g = helpers.golden('g3_regularization')
+    reg = helpers.seeded(pds.Regularization).to(dev)
+    with torch.no_grad():
+        cost = reg(g['signatures'].to(dev), g['shortcut'].to(dev))
+    assert cost.shape == (1, 32, 64, 128)
+    assert helpers.maxdiff(cost, g['cost']) <= TOL_COST_MAX
+    assert helpers.meandiff(cost, g['cost']) <= TOL_COST_MEAN
+
+
+def test_regularization_batch2_vs_oracle(dev):
+    reg = helpers.seeded(pds.Regularization, seed=5)
+    p = helpers.prefixed(reg.state_dict(), '_r')
+    g = torch.Generator().manual_seed(6)
+    ms = torch.randn(2, 8, 16, 32, 48, generator=g)
+    shortcut = torch.randn(2, 8, 32, 48, generator=g)
+    ref = oracle.regularization(p, '_r', ms, shortcut)
+    reg = reg.to(dev)
+    with torch.no_grad():
+        cost = reg(ms.to(dev), shortcut.to(dev))
+    assert helpers.maxdiff(cost, ref) <= TOL_COST_MAX
+    assert helpers.meandiff(cost, ref) <= TOL_COST_MEAN
+
+
+def test_regularization_rejects_illegal_sizes(dev):
+    reg = pds.Regularization().to(dev)
+    with pytest.raises(ValueError):
+        reg(torch.rand(1, 8, 12, 16, 32, device=dev), torch.rand(1, 8, 16, 32, device=dev))
+    with pytest.raises(ValueError):  # a single voxel at 1/16 scale (torch >= 2 InstanceNorm guard)
+        reg(torch.rand(1, 8, 16, 16, 16, device=dev), torch.rand(1, 8, 16, 16, device=dev))
+
+
+def test_fused_regularization_estimator_matches_unfused(dev):
+    g = helpers.golden('g3_regularization')
+    reg = helpers.seeded(pds.Regularization).to(dev)
+    est = pds.SubpixelMap()
+    with torch.no_grad():
+        unfused = est(reg(g['signatures'].to(dev), g['shortcut'].to(dev)))
+        fused = reg.forward_with_estimator(g['signatures'].to(dev), g['shortcut'].to(dev), est)
+    ref = oracle.subpixel_map(g['cost'])
+    assert helpers.disparity_report(fused, ref)['mae'] <= TOL_DISPARITY_MAE
+    assert helpers.disparity_report(fused, unfused)['mae'] <= TOL_DISPARITY_MAE
+
+
+# ------------------------------------------------------------------------------- whole hot path
+def hot_path_inputs(maximum_disparity, batch, height, width):
+    """SURVEY.md 8c recipe: seed-0 default network, seed-1 images, descriptors computed once on CPU."""
+    net = helpers.seeded(lambda: pds.PdsNetwork.default(maximum_disparity)).eval()
+    left, right = helpers.images(batch, height, width)
+    with torch.no_grad():
+        ld, shortcut = net._embedding(net._size_adapter.pad(left))
+        rd = net._embedding(net._size_adapter.pad(right))[0]
+    return net, ld, rd, shortcut
+
+
+def run_hot_path(net, dev, ld, rd, shortcut, fuse):
+    net = net.to(dev)
+    with torch.no_grad():
+        ms = net._matching(ld.to(dev), rd.to(dev))
+        if fuse:
+            return ms, None, net._regularization.forward_with_estimator(ms, shortcut.to(dev), net._estimator)
+        cost = net._regularization(ms, shortcut.to(dev))
+        return ms, cost, net._estimator(cost)
+
+
+def test_config1_hot_path_vs_golden(dev):
+    """BASELINE configs[0] shape (128x256, D=64) through the HIP hot path."""
+    g = helpers.golden('g6_config1')
+    net, ld, rd, shortcut = hot_path_inputs(63, 1, 128, 256)
+    assert abs(helpers.checksum(net.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    ms, cost, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=False)
+    assert ms.shape == (1, 8, 16, 32, 64) and cost.shape == (1, 32, 128, 256)
+    assert helpers.maxdiff(ms[:, :, ::2, ::4, ::4], g['signatures_sub']) <= TOL_SIGNATURES
+    assert helpers.maxdiff(cost[:, ::4, ::8, ::8], g['cost_sub']) <= TOL_COST_MAX
+    rep = helpers.disparity_report(disparity, g['disparity'])
+    print('config1 disparity', rep)
+    assert rep['mae'] <= TOL_DISPARITY_MAE, rep
+    # estimator alone on the identical (GPU) cost volume
+    est = oracle.subpixel_map(cost.cpu())
+    assert helpers.maxdiff(disparity, est) <= TOL_EST_MAX
+
+
+def test_config1_full_network_on_gpu(dev):
+    """The drop-in: PdsNetwork.default with the embedding on PyTorch-ROCm and the HIP hot path."""
+    g = helpers.golden('g6_config1')
+    net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).eval().to(dev)
+    left, right = helpers.images(1, 128, 256)
+    with torch.no_grad():
+        out = net(left.to(dev), right.to(dev))
+    assert out.shape == (1, 128, 256)
+    rep = helpers.disparity_report(out, g['disparity'])
+    print('config1 full network (GPU embedding)', rep)
+    assert rep['mae'] <= 5e-3, rep   # the MIOpen embedding perturbs the descriptors by ~1e-6
+    net.train()
+    with torch.no_grad():
+        cost = net(left.to(dev), right.to(dev))
+    assert cost.shape == (1, 32, 128, 256)   # training mode returns the cost volume (network.py:50-52)
+
+
+def test_config2_full_size_vs_oracle_and_golden(dev):
+    """BASELINE configs[1]: 960x540, D=192.  Stage-wise parity against the oracle run on the host
+    and against the committed statistics of the reference."""
+    g = helpers.golden('g7_config2_stats')
+    net, ld, rd, shortcut = hot_path_inputs(191, 1, 540, 960)
+    assert abs(helpers.checksum(net.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    ms, cost, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=False)
+    assert ms.shape == (1, 8, 48, 144, 240) and cost.shape == (1, 96, 576, 960)
+    assert helpers.maxdiff(ms[:, :, ::4, ::16, ::16], g['signatures_sub']) <= TOL_SIGNATURES
+    assert helpers.maxdiff(cost[:, ::8, ::32, ::32], g['cost_sub']) <= TOL_COST_MAX
+    p = {k: v.cpu() for k, v in net.state_dict().items()}
+    ms_o, cost_o, disp_o = oracle.hot_path(p, ld, rd, shortcut, 191, return_stages=True)
+    assert helpers.maxdiff(ms, ms_o) <= TOL_SIGNATURES
+    assert helpers.maxdiff(cost, cost_o) <= TOL_COST_MAX
+    assert helpers.meandiff(cost, cost_o) <= TOL_COST_MEAN
+    rep = helpers.disparity_report(disparity, disp_o)
+    print('config2 disparity vs oracle', rep)
+    assert rep['mae'] <= TOL_DISPARITY_MAE, rep
+    assert rep['flips'] <= 1e-4, rep
+    sub = helpers.disparity_report(disparity[:, ::16, ::16], g['disparity_sub'])
+    assert sub['mae'] <= 5e-2, sub     # 2 160 samples: one ~100 px flip alone is 0.046
+    # fused eval path at full size
+    _, _, fused = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
+    rep_f = helpers.disparity_report(fused, disp_o)
+    print('config2 fused disparity vs oracle', rep_f)
+    assert rep_f['mae'] <= TOL_DISPARITY_MAE, rep_f
+
+
+def test_config4_kitti_shape_batch(dev):
+    """BASELINE configs[3]: 375x1242 (pads top 9 / left 38), D=256 -> run at batch 2 to bound the
+    oracle's host time; checks unpad offsets and batch handling."""
+    net, ld, rd, shortcut = hot_path_inputs(255, 2, 375, 1242)
+    assert ld.shape == (2, 64, 96, 320)
+    ms, cost, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
+    p = {k: v.cpu() for k, v in net.state_dict().items()}
+    ms_o, cost_o, disp_o = oracle.hot_path(p, ld, rd, shortcut, 255, return_stages=True)
+    assert helpers.maxdiff(ms, ms_o) <= TOL_SIGNATURES
+    rep = helpers.disparity_report(disparity, disp_o)
+    print('config4 disparity vs oracle', rep)
+    assert rep['mae'] <= 2e-3, rep
+    out = net._size_adapter.unpad(disparity)
+    assert out.shape == (2, 375, 1242)

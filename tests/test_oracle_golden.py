@@ -1,0 +1,115 @@
+"""CPU: the oracle restatement against the committed golden vectors (generated from the reference
+by tests/golden/make_golden.py) and against the reference's own known-answer tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pds_oracle as oracle
+from tests import helpers
+import practicaldeepstereo_nips2018_amd as pds
+
+
+def mock_operation(x):
+    return torch.max(x, dim=1, keepdim=True)[0]
+
+
+def test_matching_shift_semantics_known_answer():
+    # reference test/test_matching.py:17-32
+    left = torch.tensor([0., 2., 1., 2.]).view(1, 1, 1, 4)
+    right = torch.tensor([3., 4., 2., 4.]).view(1, 1, 1, 4)
+    out = oracle.matching(left, right, 2, mock_operation)
+    assert np.array_equal(out.numpy().reshape(3, 4), [[3, 4, 2, 4], [0, 3, 4, 2], [0, 2, 3, 4]])
+    out = oracle.matching(left, right, 1, mock_operation)
+    assert np.array_equal(out.numpy().reshape(2, 4), [[3, 4, 2, 4], [0, 3, 4, 2]])
+    g = helpers.golden('g1_matching_mock')
+    assert torch.equal(oracle.matching(g['left2'], g['right2'], 5, mock_operation), g['out2_max5'])
+
+
+def test_subpixel_map_known_answers():
+    # reference test/test_estimator.py:14-27
+    sim = torch.tensor([0.1, 0.4, 0.3, 0.2, 0.3]).view(1, 5, 1, 1)
+    assert abs(oracle.subpixel_map(sim, 2, 1).item() - 1.52) < 1e-4
+    assert abs(oracle.subpixel_map(sim, 2, 2).item() - 2.124) < 1e-4
+
+
+def test_subpixel_map_golden_cases():
+    g = helpers.golden('g5_subpixel_map')
+    names = sorted(k[:-3] for k in g if k.endswith('_in'))
+    assert len(names) >= 10
+    for name in names:
+        hw, step = [int(v) for v in g[name + '_cfg']]
+        out = oracle.subpixel_map(g[name + '_in'], hw, step)
+        assert helpers.maxdiff(out, g[name + '_out']) <= 1e-6, name
+    # probes of SURVEY.md 7.3
+    assert abs(g['tie_first_out'].item() - oracle.subpixel_map(g['tie_first_in']).item()) < 1e-6
+    assert abs(g['all_equal_out'].item() - 2.0) < 1e-6
+    assert abs(g['edge_low_out'].item() - 1.2053844) < 1e-5
+    assert abs(g['edge_high_out'].item() - 9.6050835) < 1e-5
+
+
+@pytest.mark.parametrize('bad', [(4, 0), (0, 2), (3, 2)])
+def test_subpixel_map_value_errors(bad):
+    with pytest.raises(ValueError):
+        oracle.check_subpixel_map_arguments(*bad)
+
+
+def test_matching_operation_golden():
+    g = helpers.golden('g2_matching')
+    op = helpers.seeded(pds.MatchingOperation)
+    assert abs(helpers.checksum(op.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    p = helpers.prefixed(op.state_dict(), '_m._operation')
+    out = oracle.matching_with_operation(p, '_m', g['left'], g['right'], 15)
+    assert out.shape == (1, 8, 16, 16, 32)
+    assert helpers.maxdiff(out, g['signatures']) <= 1e-6
+    assert helpers.maxdiff(oracle.matching_operation(p, '_m._operation', g['concatenated']),
+                           g['operation_out']) <= 1e-6
+
+
+def test_regularization_golden():
+    g = helpers.golden('g3_regularization')
+    reg = helpers.seeded(pds.Regularization)
+    assert abs(helpers.checksum(reg.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    p = helpers.prefixed(reg.state_dict(), '_r')
+    out = oracle.regularization(p, '_r', g['signatures'], g['shortcut'])
+    assert out.shape == (1, 32, 64, 128)
+    assert helpers.maxdiff(out, g['cost']) <= 1e-6
+
+
+def test_blocks_golden():
+    g = helpers.golden('g4_blocks')
+    con = helpers.seeded(lambda: (torch.rand(2, 6, 10, 14, 16), pds.ContractionBlock3d(6))[1])
+    assert abs(helpers.checksum(con.state_dict()) - g['contraction_checksum'].item()) < 1e-9
+    down, smooth = oracle.contraction_block_3d(helpers.prefixed(con.state_dict(), '_c'), '_c',
+                                               g['contraction_in'])
+    assert down.shape == (2, 12, 5, 7, 8) and smooth.shape == (2, 12, 5, 7, 8)
+    assert helpers.maxdiff(down, g['contraction_down']) <= 1e-6
+    assert helpers.maxdiff(smooth, g['contraction_smooth']) <= 1e-6
+
+    def make_expansion():
+        torch.rand(2, 6, 10, 14, 16)
+        torch.rand(2, 3, 20, 28, 32)
+        return pds.ExpansionBlock3d(6)
+    exp = helpers.seeded(make_expansion)
+    assert abs(helpers.checksum(exp.state_dict()) - g['expansion_checksum'].item()) < 1e-9
+    out = oracle.expansion_block_3d(helpers.prefixed(exp.state_dict(), '_e'), '_e',
+                                    g['expansion_in'], g['expansion_shortcut'])
+    assert out.shape == (2, 3, 20, 28, 32)
+    assert helpers.maxdiff(out, g['expansion_out']) <= 1e-6
+
+
+def test_config1_full_network_golden():
+    """Config 1 (BASELINE.json configs[0]): 128x256, D=64, the whole pipeline on CPU with this
+    repo's own embedding feeding the oracle hot path."""
+    g = helpers.golden('g6_config1')
+    net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).eval()
+    assert abs(helpers.checksum(net.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    left, right = helpers.images(1, 128, 256)
+    with torch.no_grad():
+        ld, shortcut = net._embedding(net._size_adapter.pad(left))
+        rd = net._embedding(net._size_adapter.pad(right))[0]
+        p = {k: v for k, v in net.state_dict().items()}
+        ms, cost, disparity = oracle.hot_path(p, ld, rd, shortcut, 63, return_stages=True)
+    assert helpers.maxdiff(ms[:, :, ::2, ::4, ::4], g['signatures_sub']) <= 2e-5
+    assert helpers.maxdiff(cost[:, ::4, ::8, ::8], g['cost_sub']) <= 1e-4
+    rep = helpers.disparity_report(disparity, g['disparity'])
+    assert rep['mae'] <= 1e-3, rep
