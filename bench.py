@@ -1,0 +1,227 @@
+"""Benchmark of the Practical Deep Stereo cost-volume hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one stereo pair through Matching -> Regularization -> SubpixelMap (eval mode) at
+BASELINE.json configs[1]: 960x540 (padded 576x960), D=192 (maximum_disparity 191), fp32, random-init
+weights (seed 0), descriptors of seeded uniform images (SURVEY.md 8c recipe) resident in HBM before
+the timed region.  N > 1 follows configs[2]: the disparity axis of Matching is sharded over the
+ranks, one all-gather (RCCL) reassembles the signatures, Regularization + estimator run replicated;
+the total work is one pair per step, so scaling is "strong".  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     - the dominant kernel (conv2d 3x3 64->64 over all disparity planes, fp32 MFMA): its
+                 launch is timed in isolation with HIP events through pds_conv_block_fwd;
+                 achieved = 122.31 GFLOP per launch / mean duration against the 157.3 TFLOP/s peak.
+  cpu_baseline - the oracle (oracle/pds_oracle.py, PyTorch-CPU restatement of the reference) on the
+                 same inputs on this host's cores (rank 0, N=1 only), and the parity of the GPU result
+                 against it.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import practicaldeepstereo_nips2018_amd as pds  # noqa: E402
+from practicaldeepstereo_nips2018_amd import _lib  # noqa: E402
+from practicaldeepstereo_nips2018_amd.distributed import ShardedMatching  # noqa: E402
+
+HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+# dense 2*MAC count of one 64->64 3x3 convolution over [1, 64, 48, 144, 240] (122.31 GF)
+CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--kernel-reps', type=int, default=10)
+    return ap.parse_args()
+
+
+def make_inputs():
+    """Seed-0 default network, seed-1 images; the (off-path) embedding runs once on the host so the
+    GPU path and the CPU baseline see bit-identical descriptors."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(MAX_DISPARITY).eval()
+    g = torch.Generator().manual_seed(1)
+    left = torch.rand(1, 3, HEIGHT, WIDTH, generator=g) * 255
+    right = torch.rand(1, 3, HEIGHT, WIDTH, generator=g) * 255
+    with torch.no_grad():
+        ld, shortcut = net._embedding(net._size_adapter.pad(left))
+        rd = net._embedding(net._size_adapter.pad(right))[0]
+    return net, ld, rd, shortcut
+
+
+def time_dominant_kernel(net, device, reps):
+    """Mean duration (ms) of one conv2d 64->64 block launch over all 48 planes, HIP events on the
+    stream the kernel is launched on (torch's current stream)."""
+    lib = _lib.load()
+    block = net._matching._operation._matching_operation_modules[1].convolutions[0]
+    params = _lib.conv_block_params(block.conv, block.norm)
+    n, c, d, h, w = 1, 64, (MAX_DISPARITY + 1) // 4, 144, 240
+    x = torch.randn(n, c, d, h, w, device=device)
+    raw = torch.empty_like(x)
+    scale = torch.empty(n * c * d, device=device)
+    shift = torch.empty(n * c * d, device=device)
+    nbytes = lib.pds_conv_block_workspace_bytes(n, c, c, d, h, w, 1, 1, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    stream = _lib.stream_handle(device)
+
+    def launch():
+        _lib.check(lib.pds_conv_block_fwd(ctypes.byref(params), _lib.ptr(x), _lib.ptr(raw), _lib.ptr(scale),
+                                          _lib.ptr(shift), n, c, c, d, h, w, 1, 1, 1, _lib.ptr(ws), ws.numel(),
+                                          stream), 'pds_conv_block_fwd')
+    for _ in range(2):
+        launch()
+    torch.cuda.synchronize(device)
+    total = 0.0
+    for _ in range(reps):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        launch()
+        stop.record()
+        stop.synchronize()
+        total += start.elapsed_time(stop)
+    return total / reps
+
+
+def cpu_baseline(net, ld, rd, shortcut, gpu_disparity):
+    from oracle import pds_oracle as oracle
+    # Threads: the cores this process may actually run on, capped at 32 -- oneDNN's small 3-D
+    # convolutions thrash with hundreds of threads (256 threads measured 282 s per pair on the
+    # 2 x 64-core host of the GPU box versus a few seconds with 32).
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(usable, 32)))
+    params = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    best = float('inf')
+    disparity = None
+    passes = 0
+    budget_start = time.perf_counter()
+    with torch.no_grad():
+        for i in range(3):  # 1 warm-up + best of 2, bounded to ~30 s of host time
+            t0 = time.perf_counter()
+            disparity = oracle.hot_path(params, ld, rd, shortcut, MAX_DISPARITY)
+            dt = time.perf_counter() - t0
+            passes += 1
+            if i > 0 or dt > 15.0:
+                best = min(best, dt)
+            if time.perf_counter() - budget_start > 30.0:
+                break
+    delta = (gpu_disparity.double().cpu() - disparity.double()).abs()
+    parity = {'disparity_mae': float(delta.mean()), 'disparity_max': float(delta.max()),
+              'flip_fraction': float((delta > 0.5).double().mean()), 'tolerance_mae': 1e-3}
+    cpu_name = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_name = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')][0]
+    except Exception:
+        pass
+    base = {'value': 1.0 / best, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'best of %d full passes (first one is warm-up) of the same 960x540 D=192 pair, '
+                      'PyTorch-CPU oracle, %s, %d usable cores' % (passes, cpu_name, usable),
+            'ms_per_pair': best * 1e3}
+    return base, parity
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    _lib.load()  # fail loudly when the HIP extension is missing
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    net, ld, rd, shortcut = make_inputs()
+    net = net.to(device)
+    ld_g, rd_g, sc_g = ld.to(device), rd.to(device), shortcut.to(device)
+    matching = ShardedMatching(net._matching) if world > 1 else net._matching
+    regularization, estimator = net._regularization, net._estimator
+
+    def step():
+        signatures = matching(ld_g, rd_g)
+        return regularization.forward_with_estimator(signatures, sc_g, estimator)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            disparity = step()
+        barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            disparity = step()
+        torch.cuda.synchronize(device)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            'metric': 'stereo pairs/sec, 960x540 D=192, Matching+Regularization+SubpixelMap hot path',
+            'value': args.steps / elapsed,
+            'unit': 'pairs/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'ms_per_frame': ms_per_step,
+            'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'configs[1]: 960x540 pair padded to 576x960, D=192 (48 matching planes, 96 cost '
+                                   'planes), batch 1, eval mode, random-init weights seed 0',
+                       'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL)' % world)
+                       if world > 1 else 'single GPU'},
+        }
+        with torch.no_grad():
+            kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)
+        achieved = CONV64_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
+        line['roofline'] = {'kernel': 'conv2d 3x3 64->64 (+bias, LeakyReLU, InstanceNorm partials) over 48 planes '
+                                      'of 144x240, one launch', 'bound': 'mfma', 'achieved': achieved,
+                            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+                            'traffic': None, 'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP}
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline(net, ld, rd, shortcut, disparity)
+            line['cpu_baseline'] = base
+            line['parity'] = parity
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -152,6 +152,20 @@ int pds_expansion_block_fwd(const PdsConvBlockParams* upsampling, const PdsConvB
                             int batch, int c, int d, int h, int w,
                             void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * One convolution block of network_blocks.py:47-72 on a plain input tensor x [n, cin, d, h, w]:
+ * raw = LeakyReLU(conv(x) + bias) [n, cout, d', h', w'] plus the folded InstanceNorm coefficients
+ * (normalised = scale * raw + shift, scale/shift [n*cout] or [n*cout*d'] when per_plane).
+ * kd = 1 is Conv2d applied to every d-plane (Matching), kd = 3 is Conv3d; stride 1 or 2.
+ * With params->gamma == NULL the block is a bare convolution (scale/shift untouched).
+ * This is the launch bench.py times for the roofline of the dominant kernel.
+ * ---------------------------------------------------------------------------------- */
+size_t pds_conv_block_workspace_bytes(int n, int cin, int cout, int d, int h, int w, int kd, int stride,
+                                      int per_plane);
+int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* raw, float* scale,
+                       float* shift, int n, int cin, int cout, int d, int h, int w, int kd, int stride,
+                       int per_plane, void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

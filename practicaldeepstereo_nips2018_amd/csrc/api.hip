@@ -71,7 +71,8 @@ static Geom conv_out_geom(const Geom& in, int cout, int kd, int stride) {
 
 // conv (+ LeakyReLU + deferred InstanceNorm when P.gamma) ; out_raw may be caller-provided
 static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvBlockParams& P, int cout,
-                     int kd, int stride, int per_plane, float* out_raw = nullptr, bool allow_mfma = true) {
+                     int kd, int stride, int per_plane, float* out_raw = nullptr, bool allow_mfma = true,
+                     float* scale_out = nullptr, float* shift_out = nullptr) {
     DT o;
     o.g = conv_out_geom(in, cout, kd, stride);
     o.per_plane = per_plane;
@@ -96,8 +97,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         const size_t records = (size_t)o.g.n * o.g.c * o.g.d * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
-        o.scale = c.get<float>(groups);
-        o.shift = c.get<float>(groups);
+        o.scale = scale_out ? scale_out : c.get<float>(groups);
+        o.shift = shift_out ? shift_out : c.get<float>(groups);
         if (!c.plan) {
             c.run(mfma ? launch_conv2d_mfma(L, c.s) : launch_conv_direct(L, c.s));
             const int per_group = tiles * (per_plane ? 1 : o.g.d);
@@ -380,6 +381,32 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
     if (c.err) return c.err;
     return pds_subpixel_map_fwd(cost, disparities, batch, 2 * d, 4 * h, 4 * w, half_support_window, disparity_step,
                                 stream);
+}
+
+size_t pds_conv_block_workspace_bytes(int n, int cin, int cout, int d, int h, int w, int kd, int stride,
+                                      int per_plane) {
+    Ctx c{nullptr, 0, true, nullptr};
+    PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
+    conv_block(c, plain_src(nullptr), no_src(), Geom{n, cin, d, h, w}, dummy, cout, kd, stride, per_plane,
+               (float*)1, true, (float*)1, (float*)1);
+    return c.off + 256;
+}
+
+int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* raw, float* scale, float* shift,
+                       int n, int cin, int cout, int d, int h, int w, int kd, int stride, int per_plane,
+                       void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(params && x && raw && workspace, "conv_block: null pointer");
+    PDS_REQUIRE(params->weight && params->bias, "conv_block: null weight/bias");
+    PDS_REQUIRE(n > 0 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, "conv_block: bad shape");
+    PDS_REQUIRE((kd == 1 || kd == 3) && (stride == 1 || stride == 2) && !(kd == 1 && stride == 2),
+                "conv_block: unsupported kd=%d stride=%d", kd, stride);
+    if (params->gamma) PDS_REQUIRE(params->beta && scale && shift, "conv_block: null InstanceNorm outputs");
+    const size_t need = pds_conv_block_workspace_bytes(n, cin, cout, d, h, w, kd, stride, per_plane);
+    PDS_REQUIRE(workspace_bytes >= need, "conv_block: workspace too small (%zu < %zu)", workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    conv_block(c, plain_src(x), no_src(), Geom{n, cin, d, h, w}, *params, cout, kd, stride, per_plane, raw, true,
+               scale, shift);
+    return c.err;
 }
 
 size_t pds_contraction_block_workspace_bytes(int batch, int c_, int d, int h, int w) {

@@ -1,0 +1,68 @@
+"""Disparity-axis sharding of Matching across the GPUs of one node.
+
+The reference has no multi-device code; this is new design.  Every disparity plane of Matching is
+an independent 2-D network evaluation with its own InstanceNorm statistics (reference
+practical_deep_stereo/matching.py:56-62), so rank r of N computes planes
+[r*D'/N, (r+1)*D'/N) with ``pds_matching_fwd(d_begin, d_count)`` and ONE all-gather (RCCL over xGMI
+when the process group's backend is "nccl") reassembles the compact signatures
+[batch, 8, D', h, w] on every rank.  Regularization and the estimator couple all planes (3-D
+convolutions, volume-wide InstanceNorm, arg-max) and run replicated after the gather.
+
+One process per GPU; ``torch.distributed`` must be initialised by the caller (torchrun env).
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+def shard_range(number_of_planes, rank, world_size):
+    """(first_plane, number_of_planes_on_this_rank); planes must divide evenly (D' is a multiple of
+    16 by network.py:28, so 2, 4 and 8 ranks always do)."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError('bad rank %d of %d' % (rank, world_size))
+    if number_of_planes % world_size != 0:
+        raise ValueError('%d disparity planes do not divide over %d ranks' %
+                         (number_of_planes, world_size))
+    per_rank = number_of_planes // world_size
+    return rank * per_rank, per_rank
+
+
+def gather_planes(local_planes, group=None):
+    """All-gathers [batch, C, D_local, h, w] shards along dim 2 in rank order.
+
+    One collective: all_gather_into_tensor into a rank-major staging buffer, then one strided
+    copy into the [batch, C, D, h, w] layout Regularization consumes."""
+    world_size = dist.get_world_size(group)
+    if world_size == 1:
+        return local_planes
+    local_planes = local_planes.contiguous()
+    batch, channels, d_local, h, w = local_planes.shape
+    staged = local_planes.new_empty((world_size,) + tuple(local_planes.shape))
+    dist.all_gather_into_tensor(staged, local_planes, group=group)
+    return staged.permute(1, 2, 0, 3, 4, 5).reshape(batch, channels, world_size * d_local, h, w)
+
+
+class ShardedMatching(nn.Module):
+    """Wraps a ``Matching`` module so that each rank evaluates its slice of the disparity range and
+    the full set of matching signatures is reassembled with one all-gather.  Same call signature
+    and result as the wrapped module (matching.py:34-63)."""
+
+    def __init__(self, matching_module, group=None):
+        super(ShardedMatching, self).__init__()
+        self._matching = matching_module
+        self._group = group
+
+    def set_maximum_disparity(self, maximum_disparity):
+        self._matching.set_maximum_disparity(maximum_disparity)
+
+    def forward(self, left_embedding, right_embedding):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self._group) == 1:
+            return self._matching(left_embedding, right_embedding)
+        planes = self._matching._maximum_disparity + 1
+        shard = shard_range(planes, dist.get_rank(self._group), dist.get_world_size(self._group))
+        self._matching.set_disparity_shard(shard)
+        try:
+            local = self._matching(left_embedding, right_embedding)
+        finally:
+            self._matching.set_disparity_shard(None)
+        return gather_planes(local, self._group)
