@@ -27,6 +27,7 @@ int check_launch(const char* what) {
 int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s);        // conv2d_mfma.hip
 bool conv2d_mfma_supported(const ConvLayer& L);
 int conv2d_mfma_tiles(const Geom& out_g);
+size_t conv2d_mfma_packed_floats(int cin, int cout);
 
 // ---- workspace arena: plan mode only measures ---------------------------------------------------
 struct Ctx {
@@ -91,7 +92,9 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     L.lrelu = norm ? 1 : 0;
     L.stat_per_plane = per_plane;
     L.partials = nullptr;
+    L.packed = nullptr;
     const bool mfma = allow_mfma && conv2d_mfma_supported(L);
+    if (mfma) L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout));
     const int tiles = mfma ? conv2d_mfma_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
     if (norm) {
         const size_t records = (size_t)o.g.n * o.g.c * o.g.d * tiles;

@@ -59,6 +59,7 @@ struct ConvLayer {
     int lrelu;
     int stat_per_plane;  // statistics grouping of THIS layer's InstanceNorm
     double* partials;    // nullptr: no statistics wanted
+    float* packed;       // scratch for MFMA-ordered weights (conv2d_mfma only)
 };
 
 // direct VALU convolution, any channel count

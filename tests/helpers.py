@@ -43,5 +43,7 @@ def meandiff(a, b):
 
 def disparity_report(gpu, cpu):
     delta = (gpu.detach().double().cpu() - cpu.detach().double().cpu()).abs()
+    smooth = delta[delta <= 0.5]
     return {'mae': float(delta.mean()), 'max': float(delta.max()),
-            'flips': float((delta > 0.5).double().mean())}
+            'flips': float((delta > 0.5).double().mean()),
+            'mae_noflip': float(smooth.mean()) if smooth.numel() else 0.0}
