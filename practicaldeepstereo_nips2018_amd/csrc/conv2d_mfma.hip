@@ -16,7 +16,8 @@
 //                  fragment reads are lane-linear).  Two buffers: chunk c+1 is fetched to registers
 //                  before the MFMAs of chunk c and written after them -> one barrier per chunk.
 //   prologue       the InstanceNorm of the producing layer (scale * raw + shift), an optional second
-//                  source (residual sum) and literal zero padding are applied while staging.
+//                  source (residual sum) and literal zero padding are applied while staging; every thread
+//                  owns <= 2 fixed halo positions for all 8 channels, loads are unconditional (clamped).
 //   epilogue       + bias, LeakyReLU(0.1), store, and per-(plane, channel) sum / sum-of-squares partials in
 //                  fp64 for the deferred InstanceNorm of THIS layer (deterministic: one record per tile).
 #include "common.hpp"
@@ -25,7 +26,7 @@ namespace pds {
 
 namespace {
 
-constexpr int TH = 4, TW = 80, NB = TW / 16, KC = 8;
+constexpr int TH = 4, TW = 80, NB = TW / 16, KC = 4;
 constexpr int RS = 84;                               // LDS row stride (>= TW + 2)
 constexpr int CS = ((TH + 2) * RS + 31) / 32 * 32 + 16;  // channel stride, == 16 (mod 32)
 constexpr int IN_CHUNK = KC * CS;                    // floats
@@ -77,12 +78,19 @@ __global__ __launch_bounds__(256) void pack_conv2d_weights_kernel(const float* _
     }
 }
 
+// sum over the 16 lanes of a DPP row; the total lands in lane 15 of each row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+}
+
 template <int MB, bool HAS_B>
-__global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs A) {
+__global__ __launch_bounds__(THREADS, 3) void conv2d_mfma_kernel(const MfmaArgs A) {
     using C = Cfg<MB>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // [2 buffers][input chunk | weight chunk] then coefficient table [2 src][2][Cin]
-    float* coef = lds + 2 * C::BUF;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][input chunk | weight chunk]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,82 +103,70 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs 
     const size_t cstride = (size_t)A.D * plane;  // channel stride of NCDHW
     const int nchunks = A.Cin / KC;
 
-    // ---- per-channel affine coefficients of the two sources into LDS ------------------------
-    for (int c = tid; c < A.Cin; c += THREADS) {
-        float sa = 1.f, ha = 0.f, sb = 1.f, hb = 0.f;
-        if (A.a.scale) {
-            const int g = A.a.per_plane ? ((n * A.Cin + c) * A.D + d) : (n * A.Cin + c);
-            sa = A.a.scale[g];
-            ha = A.a.shift[g];
-        }
-        if (HAS_B && A.b.scale) {
-            const int g = A.b.per_plane ? ((n * A.Cin + c) * A.D + d) : (n * A.Cin + c);
-            sb = A.b.scale[g];
-            hb = A.b.shift[g];
-        }
-        coef[c] = sa;
-        coef[A.Cin + c] = ha;
-        coef[2 * A.Cin + c] = sb;
-        coef[3 * A.Cin + c] = hb;
+    // ---- staging map: thread -> up to POS positions (row r, column xx) of the (TH+2) x (TW+2) halo tile,
+    // the same positions for each of the 8 channels of a chunk.  Loads are unconditional from clamped
+    // coordinates; padding is applied as a select when the value is written to LDS.
+    constexpr int NPOS = (TH + 2) * (TW + 2);
+    constexpr int POS = (NPOS + THREADS - 1) / THREADS;
+    int g_off[POS], l_off[POS];
+    bool inside[POS];
+#pragma unroll
+    for (int k = 0; k < POS; ++k) {
+        const int p = min(tid + k * THREADS, NPOS - 1);  // surplus threads duplicate the last position
+        const int r = p / (TW + 2), xx = p % (TW + 2);
+        const int y = y0 - 1 + r, x = x0 - 1 + xx;
+        inside[k] = y >= 0 && y < A.H && x >= 0 && x < A.W;
+        const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
+        g_off[k] = yc * A.W + xc;
+        l_off[k] = r * RS + xx;
     }
-
-    // ---- staging bookkeeping: element e of the input chunk -> (channel, row, column) ------------
     const float* pa = A.a.p + ((size_t)n * A.Cin * A.D + d) * plane;
     const float* pb = HAS_B ? A.b.p + ((size_t)n * A.Cin * A.D + d) * plane : nullptr;
-    int g_off[IN_ITERS];   // offset inside a chunk of 8 channels, or -1 when padding / unused
-    int l_off[IN_ITERS];   // LDS offset (floats), -1 when the slot does not exist
-    int e_ch[IN_ITERS];
-#pragma unroll
-    for (int it = 0; it < IN_ITERS; ++it) {
-        const int e = it * THREADS + tid;
-        const int c = e / ((TH + 2) * (TW + 2));
-        const int rem = e % ((TH + 2) * (TW + 2));
-        const int r = rem / (TW + 2), xx = rem % (TW + 2);
-        const int y = y0 - 1 + r, x = x0 - 1 + xx;
-        const bool exists = e < IN_ELEMS;
-        const bool inside = exists && y >= 0 && y < A.H && x >= 0 && x < A.W;
-        l_off[it] = exists ? c * CS + r * RS + xx : -1;
-        g_off[it] = inside ? (int)(c * cstride + (size_t)y * A.W + x) : -1;
-        e_ch[it] = c;
+    const int wlast = C::W_CHUNK / 4 - 1;
+
+    float va[KC][POS], vb[HAS_B ? KC : 1][POS];
+    f32x4 vw[C::W_ITERS];  // ext-vector type: HIP's float4 struct keeps the array in scratch
+
+#define PDS_FETCH(chunk_)                                                                          \
+    {                                                                                              \
+        const float* ca = pa + (size_t)(chunk_) * KC * cstride;                                    \
+        const float* cb = HAS_B ? pb + (size_t)(chunk_) * KC * cstride : nullptr;                  \
+        _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                           \
+            _Pragma("unroll") for (int k = 0; k < POS; ++k) {                                      \
+                va[c][k] = ca[c * cstride + g_off[k]];                                             \
+                if (HAS_B) vb[c][k] = cb[c * cstride + g_off[k]];                                  \
+            }                                                                                      \
+        }                                                                                          \
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(A.wpk + (size_t)(chunk_) * C::W_CHUNK); \
+        _Pragma("unroll") for (int it = 0; it < C::W_ITERS; ++it)                                  \
+            vw[it] = wsrc[min(it * THREADS + tid, wlast)];                                         \
     }
 
-    float va[IN_ITERS], vb[IN_ITERS];
-    float4 vw[C::W_ITERS];
-
-    auto fetch = [&](int chunk) {
-        const size_t cbase = (size_t)chunk * KC * cstride;
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) {
-            va[it] = g_off[it] >= 0 ? pa[cbase + g_off[it]] : 0.f;
-            if (HAS_B) vb[it] = g_off[it] >= 0 ? pb[cbase + g_off[it]] : 0.f;
-        }
-        const float4* wsrc = reinterpret_cast<const float4*>(A.wpk + (size_t)chunk * C::W_CHUNK);
-#pragma unroll
-        for (int it = 0; it < C::W_ITERS; ++it) {
-            const int e = it * THREADS + tid;
-            if (e < C::W_CHUNK / 4) vw[it] = wsrc[e];
-        }
-    };
-    auto stash = [&](int chunk, float* buf) {
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) {
-            if (l_off[it] >= 0) {
-                const int c = chunk * KC + e_ch[it];
-                float v = 0.f;
-                if (g_off[it] >= 0) {
-                    v = fmaf(coef[c], va[it], coef[A.Cin + c]);
-                    if (HAS_B) v += fmaf(coef[2 * A.Cin + c], vb[it], coef[3 * A.Cin + c]);
-                }
-                buf[l_off[it]] = v;
-            }
-        }
-        float4* wdst = reinterpret_cast<float4*>(buf + IN_CHUNK);
-#pragma unroll
-        for (int it = 0; it < C::W_ITERS; ++it) {
-            const int e = it * THREADS + tid;
-            if (e < C::W_CHUNK / 4) wdst[e] = vw[it];
-        }
-    };
+#define PDS_STASH(chunk_, buf_)                                                                    \
+    {                                                                                              \
+        _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                           \
+            const int ch = (chunk_) * KC + c;                                                      \
+            float sa = 1.f, ha = 0.f, sb = 1.f, hb = 0.f;                                          \
+            if (A.a.scale) {                                                                       \
+                const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);      \
+                sa = A.a.scale[g];                                                                 \
+                ha = A.a.shift[g];                                                                 \
+            }                                                                                      \
+            if (HAS_B && A.b.scale) {                                                              \
+                const int g = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);      \
+                sb = A.b.scale[g];                                                                 \
+                hb = A.b.shift[g];                                                                 \
+            }                                                                                      \
+            _Pragma("unroll") for (int k = 0; k < POS; ++k) {                                      \
+                float v = fmaf(sa, va[c][k], ha);                                                  \
+                if (HAS_B) v += fmaf(sb, vb[c][k], hb);                                            \
+                (buf_)[c * CS + l_off[k]] = inside[k] ? v : 0.f;                                   \
+            }                                                                                      \
+        }                                                                                          \
+        f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + IN_CHUNK);                                 \
+        _Pragma("unroll") for (int it = 0; it < C::W_ITERS; ++it)                                  \
+            wdst[min(it * THREADS + tid, wlast)] = vw[it];                                         \
+    }
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -178,9 +174,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs 
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    __syncthreads();  // coefficient table visible
-    stash(0, lds);
+    PDS_FETCH(0)
+    PDS_STASH(0, lds)
     __syncthreads();
 
     // lane-constant part of the fragment addresses
@@ -188,7 +183,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs 
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         float* buf = lds + (chunk & 1) * C::BUF;
-        if (chunk + 1 < nchunks) fetch(chunk + 1);
+        float* nxt = lds + ((chunk + 1) & 1) * C::BUF;
+        const bool more = chunk + 1 < nchunks;
+        if (more) PDS_FETCH(chunk + 1)
         const float* xin = buf + b_lane;
         const float* win = buf + IN_CHUNK + lane;
 #pragma unroll
@@ -208,15 +205,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs 
                         acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[m][j], 0, 0, 0);
             }
         }
-        if (chunk + 1 < nchunks) stash(chunk + 1, lds + ((chunk + 1) & 1) * C::BUF);
+        if (more) PDS_STASH(chunk + 1, nxt)
         __syncthreads();
     }
+#undef PDS_FETCH
+#undef PDS_STASH
 
     // ---- epilogue ----------------------------------------------------------------------------
     const int y = y0 + wave;
     const bool rowok = y < A.H;
     const int jx = lane & 15, q = lane >> 4;
-    double* red = reinterpret_cast<double*>(lds);  // [4 waves][MB*16 channels][2]; staging LDS is free now
+    float* red = lds;  // [4 waves][MB*16 channels][2]; the staging buffers are free after the last barrier
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -238,15 +237,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs 
                 }
             }
             if (A.partials) {
-                double ds = (double)s, dq = (double)sq;
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
-                    ds += __shfl_xor(ds, off, 64);
-                    dq += __shfl_xor(dq, off, 64);
-                }
-                if (jx == 0) {
-                    red[((wave * MB * 16) + oc) * 2 + 0] = ds;
-                    red[((wave * MB * 16) + oc) * 2 + 1] = dq;
+                s = row16_sum(s);
+                sq = row16_sum(sq);
+                if (jx == 15) {
+                    red[((wave * MB * 16) + oc) * 2 + 0] = s;
+                    red[((wave * MB * 16) + oc) * 2 + 1] = sq;
                 }
             }
         }
@@ -258,7 +253,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma_kernel(const MfmaArgs 
             if (oc < A.Cout) {
                 double v = 0.0;
 #pragma unroll
-                for (int wv = 0; wv < 4; ++wv) v += red[((wv * MB * 16) + oc) * 2 + k];
+                for (int wv = 0; wv < 4; ++wv) v += (double)red[((wv * MB * 16) + oc) * 2 + k];
                 A.partials[((((size_t)n * A.Cout + oc) * A.D + d) * A.tiles + tile) * 2 + k] = v;
             }
         }
@@ -288,7 +283,7 @@ size_t conv2d_mfma_packed_floats(int cin, int cout) {
 template <int MB, bool HAS_B>
 static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
     using C = Cfg<MB>;
-    const size_t lds_bytes = (size_t)(2 * C::BUF + 4 * A.Cin) * sizeof(float);
+    const size_t lds_bytes = (size_t)(2 * C::BUF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, HAS_B>),

@@ -1,0 +1,33 @@
+"""Micro-benchmark of the dominant kernel: pds_conv_block_fwd, conv2d 3x3 64->64 over [1,64,48,144,240].
+Usage: python tools/bench_conv64.py [reps]"""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import practicaldeepstereo_nips2018_amd as pds
+from practicaldeepstereo_nips2018_amd import _lib
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+lib = _lib.load()
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+op = pds.MatchingOperation().to(dev)
+block = op._matching_operation_modules[1].convolutions[0]
+params = _lib.conv_block_params(block.conv, block.norm)
+n, c, d, h, w = 1, 64, 48, 144, 240
+x = torch.randn(n, c, d, h, w, device=dev)
+raw = torch.empty_like(x)
+scale = torch.empty(n * c * d, device=dev); shift = torch.empty(n * c * d, device=dev)
+ws = torch.empty(lib.pds_conv_block_workspace_bytes(n, c, c, d, h, w, 1, 1, 1), dtype=torch.uint8, device=dev)
+st = _lib.stream_handle(dev)
+def launch():
+    _lib.check(lib.pds_conv_block_fwd(ctypes.byref(params), _lib.ptr(x), _lib.ptr(raw), _lib.ptr(scale), _lib.ptr(shift),
+                                      n, c, c, d, h, w, 1, 1, 1, _lib.ptr(ws), ws.numel(), st), 'conv_block')
+for _ in range(2): launch()
+torch.cuda.synchronize()
+ts = []
+for _ in range(reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); launch(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b))
+gf = 2.0 * d * h * w * 64 * 64 * 9 / 1e9
+ts.sort()
+print('conv64 launch: min %.3f ms  median %.3f ms  -> %.1f TF (median)' % (ts[0], ts[len(ts)//2], gf / ts[len(ts)//2]))
