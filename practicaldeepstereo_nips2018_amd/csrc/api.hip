@@ -28,6 +28,10 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s);        // conv2d_mfma
 bool conv2d_mfma_supported(const ConvLayer& L);
 int conv2d_mfma_tiles(const Geom& out_g);
 size_t conv2d_mfma_packed_floats(int cin, int cout);
+int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma.hip
+bool conv3d_mfma_supported(const ConvLayer& L);
+int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
+size_t conv3d_mfma_packed_floats(const Geom& out_g, int cin, int stride);
 
 // ---- workspace arena: plan mode only measures ---------------------------------------------------
 struct Ctx {
@@ -93,24 +97,33 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     L.stat_per_plane = per_plane;
     L.partials = nullptr;
     L.packed = nullptr;
-    const bool mfma = allow_mfma && conv2d_mfma_supported(L);
-    if (mfma) L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout));
-    const int tiles = mfma ? conv2d_mfma_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
+    // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3)
+    int kind = 0;
+    if (allow_mfma && conv2d_mfma_supported(L)) kind = 2;
+    else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
+    if (kind == 2) L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout));
+    if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
+    auto launch = [&]() {
+        return kind == 2 ? launch_conv2d_mfma(L, c.s) : kind == 3 ? launch_conv3d_mfma(L, c.s) : launch_conv_direct(L, c.s);
+    };
     if (norm) {
-        const size_t records = (size_t)o.g.n * o.g.c * o.g.d * tiles;
+        // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
+        const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
+                                    : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride) : conv_direct_tiles_for(o.g, stride);
+        const size_t records = (size_t)o.g.n * o.g.c * (kind == 3 ? 1 : o.g.d) * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
         o.scale = scale_out ? scale_out : c.get<float>(groups);
         o.shift = shift_out ? shift_out : c.get<float>(groups);
         if (!c.plan) {
-            c.run(mfma ? launch_conv2d_mfma(L, c.s) : launch_conv_direct(L, c.s));
-            const int per_group = tiles * (per_plane ? 1 : o.g.d);
+            c.run(launch());
+            const int per_group = kind == 3 ? tiles : tiles * (per_plane ? 1 : o.g.d);
             const double count = (double)o.g.h * o.g.w * (per_plane ? 1 : o.g.d);
             c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
                                      per_plane ? o.g.d : 1, o.scale, o.shift, c.s));
         }
     } else if (!c.plan) {
-        c.run(mfma ? launch_conv2d_mfma(L, c.s) : launch_conv_direct(L, c.s));
+        c.run(launch());
     }
     return o;
 }
