@@ -32,6 +32,10 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma
 bool conv3d_mfma_supported(const ConvLayer& L);
 int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
 size_t conv3d_mfma_packed_floats(const Geom& out_g, int cin, int stride);
+int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s);
+bool deconv3d_mfma_supported(const DeconvLayer& L);
+int deconv3d_mfma_tiles(const Geom& in_g);
+size_t deconv3d_mfma_packed_floats(const Geom& in_g, int cout, int kd);
 
 // ---- workspace arena: plan mode only measures ---------------------------------------------------
 struct Ctx {
@@ -150,20 +154,24 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
     L.kd = kd;
     L.lrelu = norm ? 1 : 0;
     L.partials = nullptr;
-    const int tiles = deconv_direct_tiles(o.g);
+    L.packed = nullptr;
+    const bool mfma = deconv3d_mfma_supported(L);
+    if (mfma) L.packed = c.get<float>(deconv3d_mfma_packed_floats(in, cout, kd));
+    // partial records per (n, c): direct kernel [d][tile]; MFMA kernel [tile][parity class]
+    const int per_group = mfma ? deconv3d_mfma_tiles(in) * (kd == 4 ? 8 : 4) : deconv_direct_tiles(o.g) * o.g.d;
     if (norm) {
-        const size_t records = (size_t)o.g.n * o.g.c * o.g.d * tiles;
+        const size_t records = (size_t)o.g.n * o.g.c * per_group;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c;
         o.scale = c.get<float>(groups);
         o.shift = c.get<float>(groups);
         if (!c.plan) {
-            c.run(launch_deconv_direct(L, c.s));
-            c.run(launch_in_finalize(L.partials, groups, tiles * o.g.d, (double)o.g.volume(), P.gamma, P.beta,
+            c.run(mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s));
+            c.run(launch_in_finalize(L.partials, groups, per_group, (double)o.g.volume(), P.gamma, P.beta,
                                      o.g.c, 1, o.scale, o.shift, c.s));
         }
     } else if (!c.plan) {
-        c.run(launch_deconv_direct(L, c.s));
+        c.run(mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s));
     }
     return o;
 }

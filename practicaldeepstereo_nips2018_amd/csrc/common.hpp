@@ -76,6 +76,7 @@ struct DeconvLayer {
     int kd;       // 4 (stride 2 in D) or 3 (stride 1 in D)
     int lrelu;
     double* partials;
+    float* packed;  // scratch for the MFMA path (virtual weights + tap masks)
 };
 int launch_deconv_direct(const DeconvLayer& L, hipStream_t s);
 int deconv_direct_tiles(const Geom& out_g);

@@ -13,6 +13,14 @@
 //               along D: regularization.py:115,119) and zero padding folded into the staging.
 //   epilogue    bias, LeakyReLU(0.1), store, per-(n, channel) partial sums for InstanceNorm3d, one
 //               deterministic record per tile.
+// Transposed convolutions (network_blocks.py:37-44, 75-85, 124-131: kernel 4 / stride 2 / pad 1, and the
+// final (3,4,4) / (1,2,2) layer) run on the same kernel (MODE 1 / 2): a stride-2 transposed convolution is a
+// stride-1 3x3x3 convolution on the INPUT grid with one group of "virtual" output channels per output
+// parity class (8 resp. 4 groups), v = class * Cout + oc, whose weights are the transposed-conv taps that
+// parity uses (out = 2*i - 1 + k: even outputs use (i, k=1), (i-1, k=3); odd outputs (i, k=2), (i+1, k=0))
+// and zero elsewhere; taps that are structurally zero for a whole 16-channel block are skipped through a
+// per-block tap mask, so the MFMA count equals the class-wise optimum.  The epilogue scatters virtual
+// channel (class, oc) at input position (z, y, x) to output (2z+pd, 2y+ph, 2x+pw).
 // The small deep layers of the hourglass are latency-bound, so their configurations use 16-channel
 // chunks (fewer global round trips) and a single channel block per workgroup (more workgroups).
 #include "common.hpp"
@@ -34,7 +42,9 @@ struct Args3 {
     int Cout, Do, Ho, Wo;
     int lrelu;
     int tiles_x, tiles_y, tiles;  // tiles per batch element = tiles_x * tiles_y * tiles_z
-    int mblocks;                  // ceil(Cout / 16)
+    int mblocks;                  // ceil(virtual Cout / 16)
+    int Creal;                    // real output channels (== Cout for a convolution)
+    const unsigned* __restrict__ tapmask;  // [mblocks] 27-bit masks of the taps a channel block uses
 };
 
 template <int S, int MB, int TZ, int TY, int NB, int KC>
@@ -90,8 +100,10 @@ __global__ __launch_bounds__(256) void pack_conv3d_weights_kernel(const float* _
     }
 }
 
-template <int S, int MB, int TZ, int TY, int NB, int KC>
+// MODE 0: convolution; 1: transposed k4 s2 p1 (8 classes); 2: transposed k(3,4,4) s(1,2,2) p1 (4 classes)
+template <int MODE, int S, int MB, int TZ, int TY, int NB, int KC>
 __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
+    static_assert(MODE == 0 || (S == 1 && MB == 1), "transposed convolutions use stride-1 tiles, one block");
     using C = Cfg3<S, MB, TZ, TY, NB, KC>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -110,6 +122,7 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
     const bool hasb = A.b.p != nullptr;
     const size_t cstride_b = A.b.bcast_d ? plane_i : cstride_a;
     const int nchunks = (A.Cin + KC - 1) / KC;
+    const unsigned tapmask = MODE != 0 ? A.tapmask[mb0] : 0x7ffffffu;
 
     int ga[C::POS], gb[C::POS], lo[C::POS];
     bool inside[C::POS];
@@ -205,6 +218,7 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            if (MODE != 0 && !((tapmask >> tap) & 1u)) continue;  // wave-uniform: structurally zero weights
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 float af[MB];
@@ -232,29 +246,42 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
     // ---- epilogue ---------------------------------------------------------------------------------
     const int jx = lane & 15, q = lane >> 4;
     const size_t plane_o = (size_t)A.Ho * A.Wo;
+    constexpr int NCLS = MODE == 1 ? 8 : (MODE == 2 ? 4 : 1);
     float* red = lds;  // [4 waves][MB*16][2]
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int oc = (mb0 + m) * 16 + q * 4 + rr;
-            const bool chok = oc < A.Cout;
+            const int v = (mb0 + m) * 16 + q * 4 + rr;       // (virtual) output channel
+            const bool chok = v < A.Cout;
+            const int cls = MODE == 0 ? 0 : v / A.Creal;
+            const int oc = MODE == 0 ? v : v - cls * A.Creal;
+            const int pd = MODE == 1 ? (cls >> 2) & 1 : 0, ph = (cls >> 1) & 1, pw = cls & 1;
             const float bv = (chok && A.bias) ? A.bias[oc] : 0.f;
             float s = 0.f, sq = 0.f;
 #pragma unroll
             for (int r = 0; r < C::RW; ++r) {
                 const int rho = wave * C::RW + r;
-                const int z = z0 + rho / TY, y = y0 + rho % TY;
-                const bool rowok = chok && z < A.Do && y < A.Ho;
-                float* po = A.out + (((size_t)n * A.Cout + (chok ? oc : 0)) * A.Do + min(z, A.Do - 1)) * plane_o +
-                            (size_t)min(y, A.Ho - 1) * A.Wo;
+                const int z = z0 + rho / TY, y = y0 + rho % TY;   // tile coordinates (input grid when MODE != 0)
+                int oz = z, oy = y;
+                bool rowok;
+                if (MODE == 0) {
+                    rowok = chok && z < A.Do && y < A.Ho;
+                } else {
+                    rowok = chok && z < A.Di && y < A.Hi;
+                    oz = MODE == 1 ? 2 * z + pd : z;
+                    oy = 2 * y + ph;
+                }
+                float* po = A.out + (((size_t)n * A.Creal + (chok ? oc : 0)) * A.Do + min(oz, A.Do - 1)) * plane_o +
+                            (size_t)min(oy, A.Ho - 1) * A.Wo;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int x = x0 + j * 16 + jx;
                     float t = acc[m][r][j][rr] + bv;
                     if (A.lrelu) t = t > 0.f ? t : t * kLeakySlope;
-                    if (rowok && x < A.Wo) {
-                        po[x] = t;
+                    const bool ok = rowok && (MODE == 0 ? x < A.Wo : x < A.Wi);
+                    if (ok) {
+                        po[MODE == 0 ? x : 2 * x + pw] = t;
                         s += t;
                         sq = fmaf(t, t, sq);
                     }
@@ -274,12 +301,15 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
         __syncthreads();
         if (tid < MB * 16 * 2) {
             const int ocl = tid >> 1, k = tid & 1;
-            const int oc = mb0 * 16 + ocl;
-            if (oc < A.Cout) {
-                double v = 0.0;
+            const int v = mb0 * 16 + ocl;
+            if (v < A.Cout) {
+                double sum = 0.0;
 #pragma unroll
-                for (int wv = 0; wv < 4; ++wv) v += (double)red[((wv * MB * 16) + ocl) * 2 + k];
-                A.partials[(((size_t)n * A.Cout + oc) * A.tiles + tile) * 2 + k] = v;
+                for (int wv = 0; wv < 4; ++wv) sum += (double)red[((wv * MB * 16) + ocl) * 2 + k];
+                const int cls = MODE == 0 ? 0 : v / A.Creal;
+                const int oc = MODE == 0 ? v : v - cls * A.Creal;
+                // records of one real channel: [tile][class]
+                A.partials[((((size_t)n * A.Creal + oc) * A.tiles + tile) * NCLS + cls) * 2 + k] = sum;
             }
         }
     }
@@ -311,18 +341,18 @@ Plan3 choose_plan(const Geom& o, int cin, int stride) {
     return Plan3{8, 1, 2, 2, 1, 8};
 }
 
-template <int S, int MB, int TZ, int TY, int NB, int KC>
+template <int MODE, int S, int MB, int TZ, int TY, int NB, int KC>
 int launch3(const Args3& A0, hipStream_t s) {
     using C = Cfg3<S, MB, TZ, TY, NB, KC>;
     Args3 A = A0;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<S, MB, TZ, TY, NB, KC>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }
     dim3 grid(A.tiles, (A.mblocks + MB - 1) / MB, A.N);
-    hipLaunchKernelGGL((conv3d_mfma_kernel<S, MB, TZ, TY, NB, KC>), grid, dim3(THREADS), C::LDS_BYTES, s, A);
+    hipLaunchKernelGGL((conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>), grid, dim3(THREADS), C::LDS_BYTES, s, A);
     return check_launch("conv3d_mfma");
 }
 
@@ -378,6 +408,8 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s) {
     A.tiles_y = (A.Ho + p.ty - 1) / p.ty;
     A.tiles = conv3d_mfma_tiles(L.out_g, L.in.c, L.stride);
     A.mblocks = (A.Cout + 15) / 16;
+    A.Creal = A.Cout;
+    A.tapmask = nullptr;
     {
         const int total = (int)conv3d_mfma_packed_floats(L.out_g, L.in.c, L.stride);
         hipLaunchKernelGGL(pack_conv3d_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, L.weight,
@@ -385,17 +417,176 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s) {
         if (int rc = check_launch("pack_conv3d_weights")) return rc;
     }
     switch (p.id) {
-        case 0: return launch3<1, 1, 2, 4, 5, 4>(A, s);
-        case 1: return launch3<1, 1, 2, 4, 4, 4>(A, s);
-        case 2: return launch3<1, 2, 2, 2, 4, 4>(A, s);
-        case 3: return launch3<1, 1, 2, 2, 4, 4>(A, s);
-        case 4: return launch3<1, 1, 2, 2, 2, 16>(A, s);
-        case 5: return launch3<1, 1, 2, 2, 1, 16>(A, s);
-        case 6: return launch3<2, 1, 2, 2, 4, 4>(A, s);
-        case 7: return launch3<2, 1, 2, 2, 2, 8>(A, s);
-        case 8: return launch3<2, 1, 2, 2, 1, 8>(A, s);
+        case 0: return launch3<0, 1, 1, 2, 4, 5, 4>(A, s);
+        case 1: return launch3<0, 1, 1, 2, 4, 4, 4>(A, s);
+        case 2: return launch3<0, 1, 2, 2, 2, 4, 4>(A, s);
+        case 3: return launch3<0, 1, 1, 2, 2, 4, 4>(A, s);
+        case 4: return launch3<0, 1, 1, 2, 2, 2, 16>(A, s);
+        case 5: return launch3<0, 1, 1, 2, 2, 1, 16>(A, s);
+        case 6: return launch3<0, 2, 1, 2, 2, 4, 4>(A, s);
+        case 7: return launch3<0, 2, 1, 2, 2, 2, 8>(A, s);
+        case 8: return launch3<0, 2, 1, 2, 2, 1, 8>(A, s);
     }
     return set_error(-1, "conv3d_mfma: no configuration");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transposed convolutions
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// transposed-conv tap index used by output parity `par` at input offset index `o` (0,1,2 <-> -1,0,+1); -1: none
+__host__ __device__ inline int tconv_tap(int par, int o) {
+    if (o == 1) return par == 0 ? 1 : 2;
+    if (par == 0) return o == 0 ? 3 : -1;
+    return o == 2 ? 0 : -1;
+}
+
+Plan3 choose_plan_deconv(const Geom& in) {
+    if ((size_t)in.d * in.h * in.w >= 100000) {
+        if (in.w % 80 == 0) return Plan3{0, 1, 2, 4, 5, 4};
+        return Plan3{1, 1, 2, 4, 4, 4};
+    }
+    if (in.w > 32) return Plan3{3, 1, 2, 2, 4, 4};
+    if (in.w > 16) return Plan3{4, 1, 2, 2, 2, 16};
+    return Plan3{5, 1, 2, 2, 1, 16};
+}
+
+}  // namespace
+
+// wpk[chunk][tap][ks][mb][k][i]: virtual channel v = mb*16 + i = class * Cout + oc, c = chunk*kc + ks*4 + k
+__global__ __launch_bounds__(256) void pack_deconv3d_weights_kernel(const float* __restrict__ w,
+                                                                    float* __restrict__ wpk, int Cout, int Cin,
+                                                                    int mblocks, int kc, int mode) {
+    const int ks_n = kc / 4;
+    const int chunks = (Cin + kc - 1) / kc;
+    const int total = chunks * 27 * ks_n * mblocks * 64;
+    const int ncls = mode == 1 ? 8 : 4;
+    const int kdn = mode == 1 ? 4 : 3;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        int r = e;
+        const int i = r % 16;
+        r /= 16;
+        const int k = r % 4;
+        r /= 4;
+        const int mb = r % mblocks;
+        r /= mblocks;
+        const int ks = r % ks_n;
+        r /= ks_n;
+        const int tap = r % 27;
+        const int chunk = r / 27;
+        const int v = mb * 16 + i, c = chunk * kc + ks * 4 + k;
+        float val = 0.f;
+        if (v < ncls * Cout && c < Cin) {
+            const int cls = v / Cout, oc = v % Cout;
+            const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            const int kd = mode == 1 ? tconv_tap(pd, dz) : 2 - dz;  // (3,.,.) stride 1: id = od + 1 - kd
+            const int kh = tconv_tap(ph, dy), kw = tconv_tap(pw, dx);
+            if (kd >= 0 && kh >= 0 && kw >= 0) val = w[(((size_t)c * Cout + oc) * kdn + kd) * 16 + kh * 4 + kw];
+        }
+        wpk[e] = val;
+    }
+}
+
+// one 27-bit mask per 16-channel block: taps with a non-zero weight for at least one of its channels
+__global__ void deconv_tapmask_kernel(unsigned* __restrict__ mask, int Cout, int mblocks, int mode) {
+    const int mb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mb >= mblocks) return;
+    const int ncls = mode == 1 ? 8 : 4;
+    unsigned m = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int v = mb * 16 + i;
+        if (v >= ncls * Cout) break;
+        const int cls = v / Cout;
+        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            const int kd = mode == 1 ? tconv_tap(pd, dz) : 2 - dz;
+            if (kd >= 0 && tconv_tap(ph, dy) >= 0 && tconv_tap(pw, dx) >= 0) m |= 1u << tap;
+        }
+    }
+    mask[mb] = m;
+}
+
+bool deconv3d_mfma_supported(const DeconvLayer& L) {
+    if (L.kd != 4 && L.kd != 3) return false;
+    if (L.in.c % 4 != 0) return false;
+    if ((L.a.scale && L.a.per_plane) || (L.b.scale && L.b.per_plane)) return false;
+    if ((size_t)L.out_g.d * L.out_g.h * L.out_g.w >= ((size_t)1 << 31)) return false;
+    if (L.in.n > 65535) return false;
+    return true;
+}
+
+static int deconv_classes(int kd) { return kd == 4 ? 8 : 4; }
+
+int deconv3d_mfma_tiles(const Geom& in) {
+    const Plan3 p = choose_plan_deconv(in);
+    return ((in.w + 16 * p.nb - 1) / (16 * p.nb)) * ((in.h + p.ty - 1) / p.ty) * ((in.d + p.tz - 1) / p.tz);
+}
+
+// floats of scratch: packed virtual weights followed by the tap masks
+size_t deconv3d_mfma_packed_floats(const Geom& in, int cout, int kd) {
+    const Plan3 p = choose_plan_deconv(in);
+    const int chunks = (in.c + p.kc - 1) / p.kc;
+    const int mblocks = (deconv_classes(kd) * cout + 15) / 16;
+    return (size_t)chunks * 27 * (p.kc / 4) * mblocks * 64 + mblocks + 64;
+}
+
+int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s) {
+    if (!L.packed) return set_error(-1, "deconv3d_mfma: packed weights missing");
+    const Plan3 p = choose_plan_deconv(L.in);
+    const int mode = L.kd == 4 ? 1 : 2;
+    const int ncls = deconv_classes(L.kd);
+    Args3 A;
+    A.a = L.a;
+    A.b = L.b;
+    A.wpk = L.packed;
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.N = L.in.n;
+    A.Cin = L.in.c;
+    A.Di = L.in.d;
+    A.Hi = L.in.h;
+    A.Wi = L.in.w;
+    A.Creal = L.out_g.c;
+    A.Cout = ncls * L.out_g.c;  // virtual channels
+    A.Do = L.out_g.d;
+    A.Ho = L.out_g.h;
+    A.Wo = L.out_g.w;
+    A.lrelu = L.lrelu;
+    A.tiles_x = (A.Wi + 16 * p.nb - 1) / (16 * p.nb);
+    A.tiles_y = (A.Hi + p.ty - 1) / p.ty;
+    A.tiles = deconv3d_mfma_tiles(L.in);
+    A.mblocks = (A.Cout + 15) / 16;
+    const int chunks = (A.Cin + p.kc - 1) / p.kc;
+    const size_t wfloats = (size_t)chunks * 27 * (p.kc / 4) * A.mblocks * 64;
+    unsigned* mask = reinterpret_cast<unsigned*>(L.packed + wfloats);
+    A.tapmask = mask;
+    hipLaunchKernelGGL(pack_deconv3d_weights_kernel, dim3((unsigned)((wfloats + 255) / 256)), dim3(256), 0, s,
+                       L.weight, L.packed, A.Creal, A.Cin, A.mblocks, p.kc, mode);
+    hipLaunchKernelGGL(deconv_tapmask_kernel, dim3((A.mblocks + 63) / 64), dim3(64), 0, s, mask, A.Creal, A.mblocks,
+                       mode);
+    if (int rc = check_launch("pack_deconv3d_weights")) return rc;
+    if (mode == 1) {
+        switch (p.id) {
+            case 0: return launch3<1, 1, 1, 2, 4, 5, 4>(A, s);
+            case 1: return launch3<1, 1, 1, 2, 4, 4, 4>(A, s);
+            case 3: return launch3<1, 1, 1, 2, 2, 4, 4>(A, s);
+            case 4: return launch3<1, 1, 1, 2, 2, 2, 16>(A, s);
+            case 5: return launch3<1, 1, 1, 2, 2, 1, 16>(A, s);
+        }
+    } else {
+        switch (p.id) {
+            case 0: return launch3<2, 1, 1, 2, 4, 5, 4>(A, s);
+            case 1: return launch3<2, 1, 1, 2, 4, 4, 4>(A, s);
+            case 3: return launch3<2, 1, 1, 2, 2, 4, 4>(A, s);
+            case 4: return launch3<2, 1, 1, 2, 2, 2, 16>(A, s);
+            case 5: return launch3<2, 1, 1, 2, 2, 1, 16>(A, s);
+        }
+    }
+    return set_error(-1, "deconv3d_mfma: no configuration");
 }
 
 }  // namespace pds
