@@ -36,6 +36,10 @@ int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s);
 bool deconv3d_mfma_supported(const DeconvLayer& L);
 int deconv3d_mfma_tiles(const Geom& in_g);
 size_t deconv3d_mfma_packed_floats(const Geom& in_g, int cout, int kd);
+bool upsample_estimator_supported(int cin, int lo, int hi);       // upsample_estimator.hip
+int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w,
+                              const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
+                              int hi, int step, hipStream_t s);
 
 // ---- workspace arena: plan mode only measures ---------------------------------------------------
 struct Ctx {
@@ -400,6 +404,16 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
     PDS_REQUIRE(workspace_bytes >= need, "regularization_subpixel_map: workspace too small (%zu < %zu)",
                 workspace_bytes, need);
     Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    const int hi = half_support_window / disparity_step;
+    const int lo = -((half_support_window + disparity_step - 1) / disparity_step);
+    if (upsample_estimator_supported(params->features / 2, lo, hi)) {
+        // fused: the full-resolution cost volume is never materialised
+        DT half = regularization_trunk(c, *params, signatures, left_shortcut, batch, d, h, w);
+        if (c.err) return c.err;
+        return launch_upsample_estimator(half.raw, half.scale, half.shift, params->upsample_full.weight,
+                                         params->upsample_full.bias, disparities, batch, half.g.c, half.g.d, half.g.h,
+                                         half.g.w, lo, hi, disparity_step, c.s);
+    }
     float* cost = c.get<float>((size_t)batch * 2 * d * 4 * h * 4 * w);
     regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
     if (c.err) return c.err;

@@ -1,0 +1,253 @@
+// Eval-mode fusion of Regularization's last layer with SubpixelMap:
+//   cost = ConvTranspose3d(k=(3,4,4), s=(1,2,2), p=1)(InstanceNorm(half))   reference regularization.py:90-92,125-126
+//   disparity = SubpixelMap(cost)                                           reference estimator.py:45-91, network.py:50-51
+// The [B, 2D, 4h, 4w] cost volume (212 MB at 960x540, D=192) is never written or re-read: every lane
+// sweeps the planes once for its 2 x 4 output pixels, accumulating the transposed convolution on the VALU
+// (48 MACs per output voxel, weights as scalar operands) and feeding each finished plane to the
+// streaming arg-max / soft-arg-max state of estimator.hip.
+//
+//   workgroup   ONE wave = input tile of 4 rows x 32 columns of the half-resolution tensor (output 8 x 64);
+//               lane (r, cp) owns input positions (i0 + r, j0 + 2cp .. 2cp+1) -> output rows 2i, 2i+1 and four
+//               consecutive output columns (16-byte disparity stores, 256 B contiguous per 16 lanes).
+//   planes      input plane p contributes to output planes p-1, p, p+1 (od = id - 1 + kd), so three running
+//               accumulators rotate; plane p-1 is complete after plane p.
+//   LDS         double-buffered halo tile [C][6][34] of the normalised plane (InstanceNorm of the previous
+//               layer and zero padding applied while staging); plane p+1 is fetched while p is consumed.
+//   taps        out = 2*i - 1 + k:  even output: (i, k=1), (i-1, k=3);  odd output: (i, k=2), (i+1, k=0).
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int TR = 4, TC = 32;            // input tile
+constexpr int HR = TR + 2, HC = TC + 2;   // halo tile
+constexpr int NPOS = HR * HC;             // 204
+constexpr int POS = (NPOS + 63) / 64;     // 4
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FusedArgs {
+    const float* __restrict__ in;     // raw upsample_half output [B, C, D, Hi, Wi]
+    const float* __restrict__ scale;  // [B*C] folded InstanceNorm
+    const float* __restrict__ shift;
+    const float* __restrict__ w;      // [C, 1, 3, 4, 4]
+    const float* __restrict__ bias;   // [1]
+    float* __restrict__ disp;         // [B, 2Hi, 2Wi]
+    int D, Hi, Wi;
+    int lo, hi;                       // tap range of the estimator
+    float step;
+};
+
+}  // namespace
+
+template <int CIN, int T>
+__global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedArgs A) {
+    __shared__ __attribute__((aligned(16))) float tile[2][CIN][NPOS + 4];
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, cp = lane & 15;
+    const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)A.Hi * A.Wi;
+    const size_t cstride = (size_t)A.D * plane;
+    const float* src = A.in + (size_t)b * CIN * cstride;
+
+    int goff[POS], loff[POS];
+    bool inside[POS];
+#pragma unroll
+    for (int k = 0; k < POS; ++k) {
+        const int p = min(lane + k * 64, NPOS - 1);
+        const int rr = p / HC, cc = p % HC;
+        const int y = i0 - 1 + rr, x = j0 - 1 + cc;
+        inside[k] = y >= 0 && y < A.Hi && x >= 0 && x < A.Wi;
+        goff[k] = min(max(y, 0), A.Hi - 1) * A.Wi + min(max(x, 0), A.Wi - 1);
+        loff[k] = p;
+    }
+    float sc[CIN], sh[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+        sc[c] = A.scale ? A.scale[b * CIN + c] : 1.f;
+        sh[c] = A.scale ? A.shift[b * CIN + c] : 0.f;
+    }
+    const float bias = A.bias ? A.bias[0] : 0.f;
+
+    float st[CIN][POS];
+#define PDS_FETCHP(p_)                                                             \
+    _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < POS; ++k) \
+        st[c][k] = src[c * cstride + (size_t)(p_) * plane + goff[k]];
+#define PDS_STASHP(buf_)                                                           \
+    _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < POS; ++k) \
+        tile[buf_][c][loff[k]] = inside[k] ? fmaf(sc[c], st[c][k], sh[c]) : 0.f;
+
+    // estimator state for the 2 x 4 pixels of this lane: a delayed window win[0..2T] of the last finished
+    // planes (win[2T] newest).  When the centre win[T] (plane k - T) beats the running maximum, its T
+    // neighbours on either side are captured from the window -- static register indices only.
+    float best[8], win[8][2 * T + 1], bprev[8][T], bnext[8][T];
+    int bi[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        best[o] = -INFINITY;
+        bi[o] = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) bprev[o][t] = bnext[o][t] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * T + 1; ++t) win[o][t] = -INFINITY;
+    }
+    // accumulators: [0] -> output plane p-1, [1] -> p, [2] -> p+1 ; pixel index o = py * 4 + q
+    float acc[3][8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[0][o] = acc[1][o] = acc[2][o] = bias;
+
+    PDS_FETCHP(0)
+    PDS_STASHP(0)
+    __syncthreads();
+
+    const int lbase = r * HC + 2 * cp;  // halo row r, halo column 2cp  (input column j0 + 2cp - 1)
+    for (int p = 0; p <= A.D + T; ++p) {  // + T flush steps that only drain the window
+        if (p < A.D) {
+            const int cur = p & 1;
+            if (p + 1 < A.D) PDS_FETCHP(p + 1)
+#pragma nounroll
+            for (int c = 0; c < CIN; ++c) {  // not unrolled: keeps only 3 x 16 weight SGPRs live
+                float v[3][4];
+#pragma unroll
+                for (int vr = 0; vr < 3; ++vr) {
+                    const float2 lo2 = *reinterpret_cast<const float2*>(&tile[cur][c][lbase + vr * HC]);
+                    const float2 hi2 = *reinterpret_cast<const float2*>(&tile[cur][c][lbase + vr * HC + 2]);
+                    v[vr][0] = lo2.x;
+                    v[vr][1] = lo2.y;
+                    v[vr][2] = hi2.x;
+                    v[vr][3] = hi2.y;
+                }
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    // 16 taps of (c, kd) as SGPR operands: an explicit s_load_dwordx16 (hipcc turns plain reads of
+                    // the weight pointer into vector loads parked in VGPRs, which spills this kernel)
+                    f32x16 wp;
+                    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=s"(wp)
+                                 : "s"(A.w), "s"((c * 3 + kd) * 64)
+                                 : "memory");
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const int vr = (a == 0) ? 1 : (py == 0 ? 0 : 2);
+                            const int kh = (py == 0) ? (a == 0 ? 1 : 3) : (a == 0 ? 2 : 0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int px = q & 1, jc = 1 + (q >> 1);
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const int vc = (e == 0) ? jc : (px == 0 ? jc - 1 : jc + 1);
+                                    const int kw = (px == 0) ? (e == 0 ? 1 : 3) : (e == 0 ? 2 : 0);
+                                    acc[kd][py * 4 + q] = fmaf(wp[kh * 4 + kw], v[vr][vc], acc[kd][py * 4 + q]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (p + 1 < A.D) PDS_STASHP(cur ^ 1)
+            __syncthreads();
+        }
+        if (p >= 1) {
+            const int k = p - 1;          // plane entering the window (a real plane while k < D)
+            const int centre = k - T;     // plane now at the centre of the window
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+#pragma unroll
+                for (int t = 0; t < 2 * T; ++t) win[o][t] = win[o][t + 1];
+                win[o][2 * T] = k < A.D ? acc[0][o] : -INFINITY;
+                const bool up = centre >= 0 && win[o][T] > best[o];  // strict: first occurrence wins
+                best[o] = up ? win[o][T] : best[o];
+                bi[o] = up ? centre : bi[o];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    bprev[o][t] = up ? win[o][T - 1 - t] : bprev[o][t];
+                    bnext[o][t] = up ? win[o][T + 1 + t] : bnext[o][t];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            acc[0][o] = acc[1][o];
+            acc[1][o] = acc[2][o];
+            acc[2][o] = bias;
+        }
+    }
+#undef PDS_FETCHP
+#undef PDS_STASHP
+
+    // soft-arg-max around the best plane (estimator.py:84-91)
+    const int planes = A.D;
+    const int i = i0 + r, j = j0 + 2 * cp;
+    float res[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float den = 1.f;
+        float num = A.step * (float)bi[o];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int kb = bi[o] - (t + 1);
+            const bool okb = -(t + 1) >= A.lo && kb >= 0;
+            const float eb = okb ? expf(bprev[o][t] - best[o]) : 0.f;
+            den += eb;
+            num = fmaf(eb, A.step * (float)kb, num);
+            const int ka = bi[o] + (t + 1);
+            const bool oka = (t + 1) <= A.hi && ka < planes;
+            const float ea = oka ? expf(bnext[o][t] - best[o]) : 0.f;
+            den += ea;
+            num = fmaf(ea, A.step * (float)ka, num);
+        }
+        res[o] = num / den;
+    }
+    if (i < A.Hi && j < A.Wi) {
+        const int Wo = 2 * A.Wi;
+        float* dst0 = A.disp + ((size_t)b * 2 * A.Hi + 2 * i) * Wo + 2 * j;
+        float* dst1 = dst0 + Wo;
+        if (j + 1 < A.Wi) {
+            *reinterpret_cast<float4*>(dst0) = make_float4(res[0], res[1], res[2], res[3]);
+            *reinterpret_cast<float4*>(dst1) = make_float4(res[4], res[5], res[6], res[7]);
+        } else {
+            dst0[0] = res[0];
+            dst0[1] = res[1];
+            dst1[0] = res[4];
+            dst1[1] = res[5];
+        }
+    }
+}
+
+bool upsample_estimator_supported(int cin, int lo, int hi) {
+    const int t = (-lo > hi) ? -lo : hi;
+    return cin == 4 && t >= 1 && t <= 4;
+}
+
+int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w,
+                              const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
+                              int hi, int step, hipStream_t s) {
+    FusedArgs A;
+    A.in = in;
+    A.scale = scale;
+    A.shift = shift;
+    A.w = w;
+    A.bias = bias;
+    A.disp = disp;
+    A.D = d;
+    A.Hi = hi_;
+    A.Wi = wi;
+    A.lo = lo;
+    A.hi = hi;
+    A.step = (float)step;
+    dim3 grid((wi + TC - 1) / TC, (hi_ + TR - 1) / TR, batch);
+    const int t = (-lo > hi) ? -lo : hi;
+    if (cin != 4) return set_error(-1, "upsample_estimator: unsupported channel count %d", cin);
+    if (t <= 1)
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1>), grid, dim3(64), 0, s, A);
+    else if (t <= 2)
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2>), grid, dim3(64), 0, s, A);
+    else
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4>), grid, dim3(64), 0, s, A);
+    return check_launch("upsample_full_subpixel");
+}
+
+}  // namespace pds
