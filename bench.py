@@ -41,6 +41,9 @@ HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 # dense 2*MAC count of one 64->64 3x3 convolution over [1, 64, 48, 144, 240] (122.31 GF)
 CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
+# HBM bytes per launch of that kernel from the PMC counters (profiles/r01_conv64_pmc.txt); a recorded
+# measurement, not re-collected by this script (counters need rocprofv3 around the process)
+CONV64_HBM_BYTES = 884.3e6
 
 
 def parse():
@@ -212,7 +215,10 @@ def main():
         line['roofline'] = {'kernel': 'conv2d 3x3 64->64 (+bias, LeakyReLU, InstanceNorm partials) over 48 planes '
                                       'of 144x240, one launch', 'bound': 'mfma', 'achieved': achieved,
                             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                            'traffic': None, 'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP}
+                            'traffic': CONV64_HBM_BYTES, 'traffic_unit': 'bytes per launch',
+                            'traffic_source': 'rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes, see '
+                                              'profiles/r01_conv64_pmc.txt (algorithmic 849e6)',
+                            'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP}
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(net, ld, rd, shortcut, disparity)
             line['cpu_baseline'] = base

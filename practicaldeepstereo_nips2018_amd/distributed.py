@@ -37,8 +37,10 @@ def gather_planes(local_planes, group=None):
         return local_planes
     local_planes = local_planes.contiguous()
     batch, channels, d_local, h, w = local_planes.shape
-    staged = local_planes.new_empty((world_size,) + tuple(local_planes.shape))
-    dist.all_gather_into_tensor(staged, local_planes, group=group)
+    # flat buffers: every backend (RCCL and gloo) accepts "output = world_size x input" along dim 0
+    staged = local_planes.new_empty(world_size * local_planes.numel())
+    dist.all_gather_into_tensor(staged, local_planes.view(-1), group=group)
+    staged = staged.view((world_size,) + tuple(local_planes.shape))
     return staged.permute(1, 2, 0, 3, 4, 5).reshape(batch, channels, world_size * d_local, h, w)
 
 
