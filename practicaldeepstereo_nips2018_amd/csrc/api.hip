@@ -1,6 +1,7 @@
 // C ABI of libpds_hip.so (include/pds_hip.h): argument checks, workspace carving and the
 // per-module launch sequences.  No allocation, no synchronisation: everything is enqueued on the
 // caller's stream into caller-owned memory.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -82,10 +83,19 @@ static Geom conv_out_geom(const Geom& in, int cout, int kd, int stride) {
     return o;
 }
 
+// Extras of the fused Matching path (conv2d_mfma only): layer-0 terms formed in the loader, side output.
+struct ConvExtra {
+    const float* l0A = nullptr;
+    const float* l0G = nullptr;
+    const float* l0G2 = nullptr;
+    int d_begin = 0;
+    float* side_out = nullptr;
+};
+
 // conv (+ LeakyReLU + deferred InstanceNorm when P.gamma) ; out_raw may be caller-provided
 static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvBlockParams& P, int cout,
                      int kd, int stride, int per_plane, float* out_raw = nullptr, bool allow_mfma = true,
-                     float* scale_out = nullptr, float* shift_out = nullptr) {
+                     float* scale_out = nullptr, float* shift_out = nullptr, const ConvExtra* extra = nullptr) {
     DT o;
     o.g = conv_out_geom(in, cout, kd, stride);
     o.per_plane = per_plane;
@@ -105,12 +115,23 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     L.stat_per_plane = per_plane;
     L.partials = nullptr;
     L.packed = nullptr;
+    if (extra) {
+        L.l0A = extra->l0A;
+        L.l0G = extra->l0G;
+        L.l0G2 = extra->l0G2;
+        L.d_begin = extra->d_begin;
+        L.side_out = extra->side_out;
+    }
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3)
     int kind = 0;
     if (allow_mfma && conv2d_mfma_supported(L)) kind = 2;
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
     if (kind == 2) L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
+    if (extra && kind != 2) {
+        c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
+        return o;
+    }
     auto launch = [&]() {
         return kind == 2 ? launch_conv2d_mfma(L, c.s) : kind == 3 ? launch_conv3d_mfma(L, c.s) : launch_conv_direct(L, c.s);
     };
@@ -201,6 +222,20 @@ static void operation_tail(Ctx& c, const PdsMatchingParams& P, float* x0, const 
         conv_block(c, plain_src(cur), no_src(), g, P.last, P.signature_features, 1, 1, 1, signature);
 }
 
+// Can the fused Matching path (layer-0 terms in the loader, residual sums as side outputs) be used?
+static bool fused_matching_supported(const PdsMatchingParams& P, int batch, int h, int w, int d_count) {
+    ConvLayer L{};
+    L.a = plain_src(nullptr);
+    L.b = no_src();
+    L.in = Geom{batch, P.features, d_count, h, w};
+    L.out_g = L.in;
+    L.kd = 1;
+    L.stride = 1;
+    ConvLayer T = L;
+    T.out_g.c = P.signature_features;
+    return conv2d_mfma_supported(L) && conv2d_mfma_supported(T);
+}
+
 static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* left, const float* right,
                               float* signatures, int batch, int h, int w, int d_begin, int d_count) {
     const int F = P.features;
@@ -222,9 +257,49 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     DT G = conv_block(c, plain_src(rp), no_src(), g2p, pr, F, 1, 1, 1);
     DT G2 = conv_block(c, plain_src(rp), no_src(), g2p, pr2, F, 1, 1, 1);
     const Geom g{batch, F, d_count, h, w};
-    float* x0 = c.get<float>(g.numel());
-    if (!c.plan) c.run(launch_l0_combine(A.raw, G.raw, G2.raw, x0, batch, F, h, w, d_begin, d_count, c.s));
-    operation_tail(c, P, x0, g, signatures);
+    // PDS_MATCHING_FUSED=0 selects the unfused reference sequence (A/B measurements, debugging)
+    static const bool fused_enabled = []() {
+        const char* e = getenv("PDS_MATCHING_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (!fused_enabled || !fused_matching_supported(P, batch, h, w, d_count)) {
+        float* x0 = c.get<float>(g.numel());
+        if (!c.plan) c.run(launch_l0_combine(A.raw, G.raw, G2.raw, x0, batch, F, h, w, d_begin, d_count, c.s));
+        operation_tail(c, P, x0, g, signatures);
+        return;
+    }
+    // Fused: x0 = A + shift_d(G) is never stored.  The first conv forms it inside its loader; the first
+    // residual sum x1 = norm(t2) + x0 is produced by one streaming kernel that re-forms x0 from the
+    // cache-resident A / G (one 425 MB stream in, one out, instead of two in).
+    ConvExtra l0;
+    l0.l0A = A.raw;
+    l0.l0G = G.raw;
+    l0.l0G2 = G2.raw;
+    l0.d_begin = d_begin;
+    const Src none = no_src();
+    if (P.residual_blocks == 0) {
+        conv_block(c, none, none, g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr, &l0);
+        return;
+    }
+    DT t1 = conv_block(c, none, none, g, P.blocks[0], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &l0);
+    DT t2 = conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1);
+    if (P.residual_blocks == 1) {
+        conv_block(c, t2.src(), none, g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr,
+                   &l0);
+        return;
+    }
+    float* cur = c.get<float>(g.numel());
+    if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, A.raw, G.raw, G2.raw, d_begin, cur, c.s));
+    for (int r = 1; r < P.residual_blocks; ++r) {
+        t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1);
+        t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1);
+        if (r + 1 < P.residual_blocks) {
+            float* nxt = c.get<float>(g.numel());
+            if (!c.plan) c.run(launch_materialize(t2.src(), plain_src(cur), g, nxt, c.s));
+            cur = nxt;
+        }
+    }
+    conv_block(c, t2.src(), plain_src(cur), g, P.last, P.signature_features, 1, 1, 1, signatures);
 }
 
 static void operation_pipeline(Ctx& c, const PdsMatchingParams& P, const float* concatenated, float* signature,

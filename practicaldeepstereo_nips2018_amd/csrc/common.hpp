@@ -59,7 +59,14 @@ struct ConvLayer {
     int lrelu;
     int stat_per_plane;  // statistics grouping of THIS layer's InstanceNorm
     double* partials;    // nullptr: no statistics wanted
-    float* packed;       // scratch for MFMA-ordered weights (conv2d_mfma only)
+    float* packed;       // scratch for MFMA-ordered weights (MFMA kernels only)
+    // conv2d_mfma only: layer-0 terms added on the fly (x0 = l0A + shift_d(l0G)) and an
+    // optional copy of the staged input (the residual sum the NEXT block needs)
+    const float* l0A = nullptr;
+    const float* l0G = nullptr;
+    const float* l0G2 = nullptr;
+    int d_begin = 0;
+    float* side_out = nullptr;
 };
 
 // direct VALU convolution, any channel count
@@ -89,6 +96,9 @@ int launch_in_finalize(const double* partials, int groups, int per_group, double
 
 // out = a (+ b), both deferred-normalised
 int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s);
+// out = norm(a) + (A + shift_d(G)): the first residual sum of the fused Matching path
+int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2, int d_begin,
+                          float* out, hipStream_t s);
 
 int launch_subpixel_map(const float* sim, float* disp, int batch, int planes, int height, int width,
                         int taps_lo, int taps_hi, int step, hipStream_t s);

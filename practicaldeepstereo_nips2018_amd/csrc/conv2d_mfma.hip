@@ -45,6 +45,12 @@ struct MfmaArgs {
     int N, Cin, D, H, W, Cout;
     int lrelu;
     int tiles_x, tiles;              // tiles per row of tiles, tiles per plane
+    // layer-0 terms formed on the fly (SRC 2, 3): x0[c,d,y,x] = A[c,y,x] + G[c,y,x-d] (+ right-edge fix)
+    const float* __restrict__ l0A;   // [N, Cin, H, W]      conv_L(left) + bias
+    const float* __restrict__ l0G;   // [N, Cin, H, W + 1]  conv_R(right), column u + 1 for u = x - d
+    const float* __restrict__ l0G2;  // same without the dx = +1 taps (used at x = W-1, d >= 1)
+    int d_begin;                     // disparity of plane 0
+    float* __restrict__ side_out;    // optional: the staged (summed, normalised) input is also written here
 };
 
 template <int MB>
@@ -87,8 +93,12 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int MB, bool HAS_B>
-__global__ __launch_bounds__(THREADS, 3) void conv2d_mfma_kernel(const MfmaArgs A) {
+// SRC: 0 = source a;  1 = a + b;  2 = layer-0 terms (A + shifted G);  3 = a + layer-0 terms
+template <int MB, int SRC>
+__global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? 3 : 2) void conv2d_mfma_kernel(const MfmaArgs A) {
+    constexpr bool HAS_A = SRC != 2;
+    constexpr bool HAS_B = SRC == 1;
+    constexpr bool HAS_L0 = SRC >= 2;
     using C = Cfg<MB>;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][input chunk | weight chunk]
 
@@ -108,33 +118,49 @@ __global__ __launch_bounds__(THREADS, 3) void conv2d_mfma_kernel(const MfmaArgs 
     // coordinates; padding is applied as a select when the value is written to LDS.
     constexpr int NPOS = (TH + 2) * (TW + 2);
     constexpr int POS = (NPOS + THREADS - 1) / THREADS;
-    int g_off[POS], l_off[POS];
-    bool inside[POS];
+    int g_off[POS], l_off[POS], gg_off[HAS_L0 ? POS : 1];
+    bool inside[POS], gvalid[HAS_L0 ? POS : 1], interior[POS];
+    const float* gsel[HAS_L0 ? POS : 1];
+    const int disp = A.d_begin + d;
 #pragma unroll
     for (int k = 0; k < POS; ++k) {
         const int p = min(tid + k * THREADS, NPOS - 1);  // surplus threads duplicate the last position
         const int r = p / (TW + 2), xx = p % (TW + 2);
         const int y = y0 - 1 + r, x = x0 - 1 + xx;
         inside[k] = y >= 0 && y < A.H && x >= 0 && x < A.W;
+        interior[k] = inside[k] && r >= 1 && r <= TH && xx >= 1 && xx <= TW && (tid + k * THREADS) < NPOS;
         const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
         g_off[k] = yc * A.W + xc;
         l_off[k] = r * RS + xx;
+        if (HAS_L0) {
+            const int u = xc - disp;  // column of the un-shifted right descriptor
+            gvalid[k] = u >= -1;
+            gg_off[k] = yc * (A.W + 1) + max(u, -1) + 1;
+            gsel[k] = ((xc == A.W - 1 && disp >= 1) ? A.l0G2 : A.l0G) + (size_t)n * A.Cin * (size_t)A.H * (A.W + 1);
+        }
     }
-    const float* pa = A.a.p + ((size_t)n * A.Cin * A.D + d) * plane;
+    const float* pa = HAS_A ? A.a.p + ((size_t)n * A.Cin * A.D + d) * plane : nullptr;
     const float* pb = HAS_B ? A.b.p + ((size_t)n * A.Cin * A.D + d) * plane : nullptr;
+    const float* pl = HAS_L0 ? A.l0A + (size_t)n * A.Cin * plane : nullptr;
+    const size_t gplane = (size_t)A.H * (A.W + 1);
     const int wlast = C::W_CHUNK / 4 - 1;
 
-    float va[KC][POS], vb[HAS_B ? KC : 1][POS];
+    float va[HAS_A ? KC : 1][POS], vb[(HAS_B || HAS_L0) ? KC : 1][POS], vg[HAS_L0 ? KC : 1][POS];
     f32x4 vw[C::W_ITERS];  // ext-vector type: HIP's float4 struct keeps the array in scratch
 
 #define PDS_FETCH(chunk_)                                                                          \
     {                                                                                              \
-        const float* ca = pa + (size_t)(chunk_) * KC * cstride;                                    \
+        const float* ca = HAS_A ? pa + (size_t)(chunk_) * KC * cstride : nullptr;                  \
         const float* cb = HAS_B ? pb + (size_t)(chunk_) * KC * cstride : nullptr;                  \
         _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                           \
             _Pragma("unroll") for (int k = 0; k < POS; ++k) {                                      \
-                va[c][k] = ca[c * cstride + g_off[k]];                                             \
+                if (HAS_A) va[c][k] = ca[c * cstride + g_off[k]];                                  \
                 if (HAS_B) vb[c][k] = cb[c * cstride + g_off[k]];                                  \
+                if (HAS_L0) {                                                                      \
+                    const int ch = (chunk_) * KC + c;                                              \
+                    vb[c][k] = pl[(size_t)ch * plane + g_off[k]];                                  \
+                    vg[c][k] = gsel[k][(size_t)ch * gplane + gg_off[k]];                           \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(A.wpk + (size_t)(chunk_) * C::W_CHUNK); \
@@ -147,7 +173,7 @@ __global__ __launch_bounds__(THREADS, 3) void conv2d_mfma_kernel(const MfmaArgs 
         _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                           \
             const int ch = (chunk_) * KC + c;                                                      \
             float sa = 1.f, ha = 0.f, sb = 1.f, hb = 0.f;                                          \
-            if (A.a.scale) {                                                                       \
+            if (HAS_A && A.a.scale) {                                                              \
                 const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);      \
                 sa = A.a.scale[g];                                                                 \
                 ha = A.a.shift[g];                                                                 \
@@ -158,9 +184,17 @@ __global__ __launch_bounds__(THREADS, 3) void conv2d_mfma_kernel(const MfmaArgs 
                 hb = A.b.shift[g];                                                                 \
             }                                                                                      \
             _Pragma("unroll") for (int k = 0; k < POS; ++k) {                                      \
-                float v = fmaf(sa, va[c][k], ha);                                                  \
+                float v = 0.f;                                                                     \
+                if (HAS_A) v = fmaf(sa, va[c][k], ha);                                             \
                 if (HAS_B) v += fmaf(sb, vb[c][k], hb);                                            \
-                (buf_)[c * CS + l_off[k]] = inside[k] ? v : 0.f;                                   \
+                if (HAS_L0) {                                                                      \
+                    const float x0v = vb[c][k] + (gvalid[k] ? vg[c][k] : 0.f);                     \
+                    v = HAS_A ? v + x0v : x0v;                                                     \
+                }                                                                                  \
+                v = inside[k] ? v : 0.f;                                                           \
+                (buf_)[c * CS + l_off[k]] = v;                                                     \
+                if (A.side_out && interior[k])                                                     \
+                    A.side_out[(((size_t)n * A.Cin + ch) * A.D + d) * plane + g_off[k]] = v;       \
             }                                                                                      \
         }                                                                                          \
         f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + IN_CHUNK);                                 \
@@ -268,6 +302,7 @@ bool conv2d_mfma_supported(const ConvLayer& L) {
     if (L.in.c % KC != 0 || L.in.c > 256) return false;
     if (mfma_blocks(L.out_g.c) == 0) return false;
     if (L.b.p && L.b.bcast_d) return false;
+    if (L.l0A && L.in.h * (L.in.w + 1) * (size_t)L.in.c >= ((size_t)1 << 31)) return false;
     // offsets inside an 8-channel chunk are kept in 32-bit registers
     if ((size_t)KC * L.in.d * L.in.h * L.in.w >= ((size_t)1 << 31)) return false;
     if (L.in.d > 65535 || L.in.n > 65535) return false;
@@ -280,18 +315,18 @@ size_t conv2d_mfma_packed_floats(int cin, int cout) {
     return (size_t)(cin / KC) * 9 * (KC / 4) * mfma_blocks(cout) * 64;
 }
 
-template <int MB, bool HAS_B>
+template <int MB, int SRC>
 static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
     using C = Cfg<MB>;
     const size_t lds_bytes = (size_t)(2 * C::BUF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, HAS_B>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }
     dim3 grid(A.tiles, A.D, A.N);
-    hipLaunchKernelGGL((conv2d_mfma_kernel<MB, HAS_B>), grid, dim3(THREADS), lds_bytes, s, A);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<MB, SRC>), grid, dim3(THREADS), lds_bytes, s, A);
     return check_launch("conv2d_mfma");
 }
 
@@ -320,9 +355,28 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     A.lrelu = L.lrelu;
     A.tiles_x = (A.W + TW - 1) / TW;
     A.tiles = conv2d_mfma_tiles(L.out_g);
-    const bool has_b = L.b.p != nullptr;
-    if (mb == 4) return has_b ? launch_cfg<4, true>(A, s) : launch_cfg<4, false>(A, s);
-    return has_b ? launch_cfg<1, true>(A, s) : launch_cfg<1, false>(A, s);
+    A.l0A = L.l0A;
+    A.l0G = L.l0G;
+    A.l0G2 = L.l0G2;
+    A.d_begin = L.d_begin;
+    A.side_out = L.side_out;
+    const bool has_b = L.b.p != nullptr, has_l0 = L.l0A != nullptr, has_a = L.a.p != nullptr;
+    if (has_l0 && has_b) return set_error(-1, "conv2d_mfma: layer-0 terms and a second source together");
+    const int src = has_l0 ? (has_a ? 3 : 2) : (has_b ? 1 : 0);
+    if (mb == 4) {
+        switch (src) {
+            case 0: return launch_cfg<4, 0>(A, s);
+            case 1: return launch_cfg<4, 1>(A, s);
+            case 2: return launch_cfg<4, 2>(A, s);
+            default: return launch_cfg<4, 3>(A, s);
+        }
+    }
+    switch (src) {
+        case 0: return launch_cfg<1, 0>(A, s);
+        case 1: return launch_cfg<1, 1>(A, s);
+        case 2: return launch_cfg<1, 2>(A, s);
+        default: return launch_cfg<1, 3>(A, s);
+    }
 }
 
 }  // namespace pds
