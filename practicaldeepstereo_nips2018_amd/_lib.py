@@ -13,7 +13,8 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, 'csrc')
-LIB_PATH = os.path.join(_PKG_DIR, 'libpds_hip.so')
+# PDS_HIP_LIB overrides the library path (A/B experiments with alternative builds)
+LIB_PATH = os.environ.get('PDS_HIP_LIB') or os.path.join(_PKG_DIR, 'libpds_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'pds_hip.h')
 
 _lock = threading.Lock()

@@ -88,8 +88,10 @@ struct ConvExtra {
     const float* l0A = nullptr;
     const float* l0G = nullptr;
     const float* l0G2 = nullptr;
+    size_t l0_cstride = 0;
     int d_begin = 0;
     float* side_out = nullptr;
+    int plane_weight_sets = 0;
 };
 
 // conv (+ LeakyReLU + deferred InstanceNorm when P.gamma) ; out_raw may be caller-provided
@@ -119,14 +121,17 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.l0A = extra->l0A;
         L.l0G = extra->l0G;
         L.l0G2 = extra->l0G2;
+        L.l0_cstride = extra->l0_cstride;
         L.d_begin = extra->d_begin;
         L.side_out = extra->side_out;
+        L.plane_weight_sets = extra->plane_weight_sets;
     }
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3)
     int kind = 0;
     if (allow_mfma && conv2d_mfma_supported(L)) kind = 2;
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
-    if (kind == 2) L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout));
+    if (kind == 2)
+        L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (extra && kind != 2) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
@@ -239,32 +244,55 @@ static bool fused_matching_supported(const PdsMatchingParams& P, int batch, int 
 static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* left, const float* right,
                               float* signatures, int batch, int h, int w, int d_begin, int d_count) {
     const int F = P.features;
-    const Geom g2{batch, F, 1, h, w};
-    const Geom g2p{batch, F, 1, h, w + 1};
     const size_t wn = (size_t)F * F * 9;
-    float* wl = c.get<float>(wn);
-    float* wr = c.get<float>(wn);
-    float* wr2 = c.get<float>(wn);
-    float* rp = c.get<float>(g2p.numel());
+    float* w3 = c.get<float>(3 * wn);       // [3 sets][F][F][3][3]: left half, right half, right half without dx=+1
+    float* bias3 = c.get<float>(3 * F);
+    const Geom g3{batch, F, 3, h, w + 1};   // plane 0: left, planes 1-2: right, each padded by one zero column
+    float* x3 = c.get<float>(g3.numel());
     if (!c.plan) {
-        c.run(launch_split_first_weights(P.first.weight, wl, wr, wr2, F, F, c.s));
-        c.run(launch_pad_left1(right, rp, (size_t)batch * F * h, w, c.s));
+        c.run(launch_split_first_weights(P.first.weight, P.first.bias, w3, w3 + wn, w3 + 2 * wn, bias3, F, F, c.s));
+        c.run(launch_l0_stack_inputs(left, right, x3, (size_t)batch * F, h, w, c.s));
     }
-    PdsConvBlockParams pl{wl, P.first.bias, nullptr, nullptr};
-    PdsConvBlockParams pr{wr, nullptr, nullptr, nullptr};
-    PdsConvBlockParams pr2{wr2, nullptr, nullptr, nullptr};
-    DT A = conv_block(c, plain_src(left), no_src(), g2, pl, F, 1, 1, 1);
-    DT G = conv_block(c, plain_src(rp), no_src(), g2p, pr, F, 1, 1, 1);
-    DT G2 = conv_block(c, plain_src(rp), no_src(), g2p, pr2, F, 1, 1, 1);
+    // A = conv_L(left) + bias, G = conv_R(right), G2 = G without its dx = +1 taps: three planes of y3
     const Geom g{batch, F, d_count, h, w};
-    // PDS_MATCHING_FUSED=0 selects the unfused reference sequence (A/B measurements, debugging)
-    static const bool fused_enabled = []() {
-        const char* e = getenv("PDS_MATCHING_FUSED");
-        return !(e && e[0] == '0');
+    const bool fused = [&]() {
+        static const bool enabled = []() {  // PDS_MATCHING_FUSED=0 selects the unfused sequence (A/B, debugging)
+            const char* e = getenv("PDS_MATCHING_FUSED");
+            return !(e && e[0] == '0');
+        }();
+        return enabled && fused_matching_supported(P, batch, h, w, d_count);
     }();
-    if (!fused_enabled || !fused_matching_supported(P, batch, h, w, d_count)) {
+    float* y3;
+    if (fused) {
+        // one launch, per-plane weight sets
+        PdsConvBlockParams p3{w3, bias3, nullptr, nullptr};
+        ConvExtra e3;
+        e3.plane_weight_sets = 3;
+        y3 = conv_block(c, plain_src(x3), no_src(), g3, p3, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e3).raw;
+    } else {
+        // generic kernels share one weight set per launch: three launches into the planes of y3
+        y3 = c.get<float>(g3.numel());
+        float* tmp_in = c.get<float>((size_t)batch * F * h * (w + 1));
+        float* tmp_out = c.get<float>((size_t)batch * F * h * (w + 1));
+        const Geom g1{batch, F, 1, h, w + 1};
+        for (int p = 0; p < 3; ++p) {
+            if (!c.plan) c.run(launch_pad_left1(p == 0 ? left : right, tmp_in, (size_t)batch * F * h, w, c.s));
+            PdsConvBlockParams pp{w3 + p * wn, bias3 + p * F, nullptr, nullptr};
+            conv_block(c, plain_src(tmp_in), no_src(), g1, pp, F, 1, 1, 1, tmp_out);
+            // scatter [B*F][h][w+1] into plane p of y3
+            if (!c.plan)
+                c.run((int)hipMemcpy2DAsync(y3 + (size_t)p * h * (w + 1), (size_t)3 * h * (w + 1) * sizeof(float), tmp_out,
+                                        (size_t)h * (w + 1) * sizeof(float), (size_t)h * (w + 1) * sizeof(float),
+                                        (size_t)batch * F, hipMemcpyDeviceToDevice, c.s));
+        }
+    }
+    const size_t l0_cstride = (size_t)3 * h * (w + 1);
+    const float* l0A = y3 + 1;                               // column 1 of plane 0
+    const float* l0G = y3 + (size_t)h * (w + 1);             // plane 1
+    const float* l0G2 = y3 + (size_t)2 * h * (w + 1);        // plane 2
+    if (!fused) {
         float* x0 = c.get<float>(g.numel());
-        if (!c.plan) c.run(launch_l0_combine(A.raw, G.raw, G2.raw, x0, batch, F, h, w, d_begin, d_count, c.s));
+        if (!c.plan) c.run(launch_l0_combine(l0A, l0G, l0G2, l0_cstride, x0, batch, F, h, w, d_begin, d_count, c.s));
         operation_tail(c, P, x0, g, signatures);
         return;
     }
@@ -272,9 +300,10 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     // residual sum x1 = norm(t2) + x0 is produced by one streaming kernel that re-forms x0 from the
     // cache-resident A / G (one 425 MB stream in, one out, instead of two in).
     ConvExtra l0;
-    l0.l0A = A.raw;
-    l0.l0G = G.raw;
-    l0.l0G2 = G2.raw;
+    l0.l0A = l0A;
+    l0.l0G = l0G;
+    l0.l0G2 = l0G2;
+    l0.l0_cstride = l0_cstride;
     l0.d_begin = d_begin;
     const Src none = no_src();
     if (P.residual_blocks == 0) {
@@ -289,7 +318,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         return;
     }
     float* cur = c.get<float>(g.numel());
-    if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, A.raw, G.raw, G2.raw, d_begin, cur, c.s));
+    if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, d_begin, cur, c.s));
     for (int r = 1; r < P.residual_blocks; ++r) {
         t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1);
         t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1);

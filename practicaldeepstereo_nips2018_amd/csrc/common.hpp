@@ -62,11 +62,15 @@ struct ConvLayer {
     float* packed;       // scratch for MFMA-ordered weights (MFMA kernels only)
     // conv2d_mfma only: layer-0 terms added on the fly (x0 = l0A + shift_d(l0G)) and an
     // optional copy of the staged input (the residual sum the NEXT block needs)
+    // all three have row stride w + 1 and channel stride l0_cstride; l0A points at column 1 of its rows
     const float* l0A = nullptr;
     const float* l0G = nullptr;
     const float* l0G2 = nullptr;
+    size_t l0_cstride = 0;
     int d_begin = 0;
     float* side_out = nullptr;
+    // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)
+    int plane_weight_sets = 0;
 };
 
 // direct VALU convolution, any channel count
@@ -97,8 +101,8 @@ int launch_in_finalize(const double* partials, int groups, int per_group, double
 // out = a (+ b), both deferred-normalised
 int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s);
 // out = norm(a) + (A + shift_d(G)): the first residual sum of the fused Matching path
-int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2, int d_begin,
-                          float* out, hipStream_t s);
+int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
+                          size_t l0_cstride, int d_begin, float* out, hipStream_t s);
 
 int launch_subpixel_map(const float* sim, float* disp, int batch, int planes, int height, int width,
                         int taps_lo, int taps_hi, int step, hipStream_t s);
@@ -108,13 +112,16 @@ int launch_shift_concat(const float* left, const float* right, float* out, int b
 
 // Matching layer 0, factorised: x0[b,c,d,y,x] = A[b,c,y,x] + G[b,c,y,x-d] with the
 // right-edge fix.  A = conv_L(L)+bias [B,C,h,w]; G, G2 [B,C,h,w+1] indexed by u+1, u = x-d.
-int launch_l0_combine(const float* A, const float* G, const float* G2, float* x0, int batch,
+// A, G, G2: row stride w + 1, channel stride `cstride`; A already points at column 1.
+int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cstride, float* x0, int batch,
                       int channels, int h, int w, int d_begin, int d_count, hipStream_t s);
+int launch_l0_stack_inputs(const float* left, const float* right, float* out, size_t bc_count, int h, int w,
+                           hipStream_t s);
 
 // small utility: zero-pad one column on the left ([.., w] -> [.., w+1]); split conv0 weights
 int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_t s);
-int launch_split_first_weights(const float* w0, float* wl, float* wr, float* wr2, int cout, int cin_half,
-                               hipStream_t s);
+int launch_split_first_weights(const float* w0, const float* b0, float* wl, float* wr, float* wr2, float* bias3,
+                               int cout, int cin_half, hipStream_t s);
 
 // ---- wave helpers ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {

@@ -26,8 +26,14 @@ namespace pds {
 
 namespace {
 
-constexpr int TH = 4, TW = 80, NB = TW / 16, KC = 4;
-constexpr int RS = 84;                               // LDS row stride (>= TW + 2)
+#ifndef PDS_TW
+#define PDS_TW 80
+#endif
+#ifndef PDS_WAVES
+#define PDS_WAVES 3
+#endif
+constexpr int TH = 4, TW = PDS_TW, NB = TW / 16, KC = 4;
+constexpr int RS = TW + 4;                           // LDS row stride (>= TW + 2)
 constexpr int CS = ((TH + 2) * RS + 31) / 32 * 32 + 16;  // channel stride, == 16 (mod 32)
 constexpr int IN_CHUNK = KC * CS;                    // floats
 constexpr int THREADS = 256;
@@ -46,10 +52,14 @@ struct MfmaArgs {
     int lrelu;
     int tiles_x, tiles;              // tiles per row of tiles, tiles per plane
     // layer-0 terms formed on the fly (SRC 2, 3): x0[c,d,y,x] = A[c,y,x] + G[c,y,x-d] (+ right-edge fix)
-    const float* __restrict__ l0A;   // [N, Cin, H, W]      conv_L(left) + bias
-    const float* __restrict__ l0G;   // [N, Cin, H, W + 1]  conv_R(right), column u + 1 for u = x - d
+    // all three: row stride W + 1, channel stride l0_cstride
+    const float* __restrict__ l0A;   // conv_L(left) + bias, pointing at column 1 of its rows
+    const float* __restrict__ l0G;   // conv_R(right), column u + 1 for u = x - d
     const float* __restrict__ l0G2;  // same without the dx = +1 taps (used at x = W-1, d >= 1)
+    size_t l0_cstride;
     int d_begin;                     // disparity of plane 0
+    size_t w_set_stride;             // floats between the packed weight sets of consecutive planes (0: shared)
+    int bias_set_stride;             // ditto for the bias
     float* __restrict__ side_out;    // optional: the staged (summed, normalised) input is also written here
 };
 
@@ -95,7 +105,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // SRC: 0 = source a;  1 = a + b;  2 = layer-0 terms (A + shifted G);  3 = a + layer-0 terms
 template <int MB, int SRC>
-__global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? 3 : 2) void conv2d_mfma_kernel(const MfmaArgs A) {
+__global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WAVES : 2) void conv2d_mfma_kernel(const MfmaArgs A) {
     constexpr bool HAS_A = SRC != 2;
     constexpr bool HAS_B = SRC == 1;
     constexpr bool HAS_L0 = SRC >= 2;
@@ -136,13 +146,20 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? 3 : 2)
             const int u = xc - disp;  // column of the un-shifted right descriptor
             gvalid[k] = u >= -1;
             gg_off[k] = yc * (A.W + 1) + max(u, -1) + 1;
-            gsel[k] = ((xc == A.W - 1 && disp >= 1) ? A.l0G2 : A.l0G) + (size_t)n * A.Cin * (size_t)A.H * (A.W + 1);
+            gsel[k] = ((xc == A.W - 1 && disp >= 1) ? A.l0G2 : A.l0G) + (size_t)n * A.Cin * A.l0_cstride;
         }
     }
     const float* pa = HAS_A ? A.a.p + ((size_t)n * A.Cin * A.D + d) * plane : nullptr;
     const float* pb = HAS_B ? A.b.p + ((size_t)n * A.Cin * A.D + d) * plane : nullptr;
-    const float* pl = HAS_L0 ? A.l0A + (size_t)n * A.Cin * plane : nullptr;
-    const size_t gplane = (size_t)A.H * (A.W + 1);
+    const float* pl = HAS_L0 ? A.l0A + (size_t)n * A.Cin * A.l0_cstride : nullptr;
+    const size_t gplane = A.l0_cstride;
+    int la_off[HAS_L0 ? POS : 1];
+    if (HAS_L0) {
+#pragma unroll
+        for (int k = 0; k < POS; ++k) la_off[k] = (g_off[k] / A.W) * (A.W + 1) + g_off[k] % A.W;
+    }
+    const float* wbase = A.wpk + (size_t)d * A.w_set_stride;
+    const float* bias = A.bias ? A.bias + d * A.bias_set_stride : nullptr;
     const int wlast = C::W_CHUNK / 4 - 1;
 
     float va[HAS_A ? KC : 1][POS], vb[(HAS_B || HAS_L0) ? KC : 1][POS], vg[HAS_L0 ? KC : 1][POS];
@@ -158,12 +175,12 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? 3 : 2)
                 if (HAS_B) vb[c][k] = cb[c * cstride + g_off[k]];                                  \
                 if (HAS_L0) {                                                                      \
                     const int ch = (chunk_) * KC + c;                                              \
-                    vb[c][k] = pl[(size_t)ch * plane + g_off[k]];                                  \
+                    vb[c][k] = pl[(size_t)ch * gplane + la_off[k]];                                \
                     vg[c][k] = gsel[k][(size_t)ch * gplane + gg_off[k]];                           \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(A.wpk + (size_t)(chunk_) * C::W_CHUNK); \
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wbase + (size_t)(chunk_) * C::W_CHUNK);  \
         _Pragma("unroll") for (int it = 0; it < C::W_ITERS; ++it)                                  \
             vw[it] = wsrc[min(it * THREADS + tid, wlast)];                                         \
     }
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? 3 : 2)
         for (int r = 0; r < 4; ++r) {
             const int oc = m * 16 + q * 4 + r;
             const bool chok = oc < A.Cout;
-            const float bv = (chok && A.bias) ? A.bias[oc] : 0.f;
+            const float bv = (chok && bias) ? bias[oc] : 0.f;
             float* po = A.out + (((size_t)n * A.Cout + (chok ? oc : 0)) * A.D + d) * plane + (size_t)y * A.W;
             float s = 0.f, sq = 0.f;
 #pragma unroll
@@ -333,10 +350,14 @@ static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
 int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     if (!L.packed) return set_error(-1, "conv2d_mfma: packed weights missing");
     const int mb = mfma_blocks(L.out_g.c);
-    {
-        const int total = (int)conv2d_mfma_packed_floats(L.in.c, L.out_g.c);
-        hipLaunchKernelGGL(pack_conv2d_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, L.weight,
-                           L.packed, L.out_g.c, L.in.c, mb);
+    const int sets = L.plane_weight_sets > 0 ? L.plane_weight_sets : 1;
+    if (L.plane_weight_sets > 0 && L.plane_weight_sets != L.in.d)
+        return set_error(-1, "conv2d_mfma: %d weight sets for %d planes", L.plane_weight_sets, L.in.d);
+    const int total = (int)conv2d_mfma_packed_floats(L.in.c, L.out_g.c);
+    for (int i = 0; i < sets; ++i) {
+        hipLaunchKernelGGL(pack_conv2d_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                           L.weight + (size_t)i * L.out_g.c * L.in.c * 9, L.packed + (size_t)i * total, L.out_g.c,
+                           L.in.c, mb);
         if (int rc = check_launch("pack_conv2d_weights")) return rc;
     }
     MfmaArgs A;
@@ -358,6 +379,9 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     A.l0A = L.l0A;
     A.l0G = L.l0G;
     A.l0G2 = L.l0G2;
+    A.l0_cstride = L.l0_cstride;
+    A.w_set_stride = L.plane_weight_sets > 0 ? (size_t)total : 0;
+    A.bias_set_stride = L.plane_weight_sets > 0 ? L.out_g.c : 0;
     A.d_begin = L.d_begin;
     A.side_out = L.side_out;
     const bool has_b = L.b.p != nullptr, has_l0 = L.l0A != nullptr, has_a = L.a.p != nullptr;

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void materialize_kernel(const Src a, const Src
 // One thread per 4 consecutive x: 16-byte loads of a and A, 16-byte stores; G is read unaligned from cache.
 __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const Geom g, const float* __restrict__ A,
                                                              const float* __restrict__ G,
-                                                             const float* __restrict__ G2, int d_begin,
-                                                             float* __restrict__ out) {
+                                                             const float* __restrict__ G2, size_t l0_cstride,
+                                                             int d_begin, float* __restrict__ out) {
     // grid: x = tile over (y, x/4), y = d, z = n*C + c
     const int nc = blockIdx.z, d = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
@@ -462,28 +462,25 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
     float sa, ha;
     src_coeffs(a, n, g.c, c, g.d, d, sa, ha);
     const float* pa = a.p + ((size_t)nc * g.d + d) * px;
-    const float* pA = A + (size_t)nc * px;
-    const float* pG = G + (size_t)nc * g.h * (g.w + 1);
-    const float* pG2 = G2 + (size_t)nc * g.h * (g.w + 1);
+    const float* pA = A + (size_t)nc * l0_cstride;   // row stride w + 1, already at column 1
+    const float* pG = G + (size_t)nc * l0_cstride;
+    const float* pG2 = G2 + (size_t)nc * l0_cstride;
     float* po = out + ((size_t)nc * g.d + d) * px;
     const bool vec = (g.w & 3) == 0;
     for (int q = blockIdx.x * 256 + threadIdx.x; q < g.h * xq; q += gridDim.x * 256) {
         const int y = q / xq, x0 = (q - y * xq) * 4;
         const size_t i = (size_t)y * g.w + x0;
         float av[4], lv[4], r[4];
+        const size_t ia = (size_t)y * (g.w + 1) + x0;
         if (vec) {
             const float4 t = *reinterpret_cast<const float4*>(pa + i);
-            const float4 l = *reinterpret_cast<const float4*>(pA + i);
             av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-            lv[0] = l.x; lv[1] = l.y; lv[2] = l.z; lv[3] = l.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool ok = x0 + k < g.w;
-                av[k] = ok ? pa[i + k] : 0.f;
-                lv[k] = ok ? pA[i + k] : 0.f;
-            }
+            for (int k = 0; k < 4; ++k) av[k] = (x0 + k < g.w) ? pa[i + k] : 0.f;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lv[k] = (x0 + k < g.w) ? pA[ia + k] : 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int x = x0 + k;
@@ -505,13 +502,13 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
     }
 }
 
-int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2, int d_begin,
-                          float* out, hipStream_t s) {
+int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
+                          size_t l0_cstride, int d_begin, float* out, hipStream_t s) {
     const int quads = g.h * ((g.w + 3) / 4);
     unsigned bx = (unsigned)((quads + 255) / 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(materialize_l0_kernel, dim3(bx, g.d, g.n * g.c), dim3(256), 0, s, a, g, A, G, G2, d_begin,
-                       out);
+    hipLaunchKernelGGL(materialize_l0_kernel, dim3(bx, g.d, g.n * g.c), dim3(256), 0, s, a, g, A, G, G2, l0_cstride,
+                       d_begin, out);
     return check_launch("materialize_l0");
 }
 
