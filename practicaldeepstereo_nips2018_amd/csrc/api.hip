@@ -46,21 +46,50 @@ int launch_upsample_estimator(const float* in, const float* scale, const float* 
 struct Ctx {
     char* base;
     size_t off = 0;
-    bool plan;
+    bool plan;          // true: measure only (null pointers) or collect pack jobs (real pointers): NO launches
     hipStream_t s;
     int err = 0;
+    PackSink* sink = nullptr;
 
     template <class T>
     T* get(size_t count) {
         const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-        T* p = plan ? nullptr : reinterpret_cast<T*>(base + off);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
         off += bytes;
         return p;
     }
     void run(int rc) {
         if (!err && rc) err = rc;
     }
+    // Kernels whose output feeds the batched weight packing must be enqueued in the collect walk (before
+    // the pack launch), or right away when packing is inline.
+    bool before_packing() const {
+        if (sink) return base != nullptr && sink->phase == kPackCollect;
+        return !plan;
+    }
 };
+
+// Runs a module pipeline in two walks over the same (deterministic) arena: the first only collects the
+// weight-packing jobs of every MFMA layer, which are then executed by ONE launch; the second enqueues the
+// layers with their weights already packed.
+template <class Pipeline>
+static int run_with_batched_packing(void* workspace, hipStream_t stream, Pipeline&& pipeline) {
+    PackJob table[64];
+    PackSink sink;
+    sink.jobs = table;
+    sink.capacity = 64;
+    sink.phase = kPackCollect;
+    Ctx collect{(char*)workspace, 0, true, stream};
+    collect.sink = &sink;
+    pipeline(collect);
+    if (collect.err) return collect.err;
+    if (int rc = launch_multi_pack(table, sink.count, stream)) return rc;
+    sink.phase = kPackDone;
+    Ctx run{(char*)workspace, 0, false, stream};
+    run.sink = &sink;
+    pipeline(run);
+    return run.err;
+}
 
 // A tensor whose InstanceNorm is deferred to its consumers.
 struct DT {
@@ -117,6 +146,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     L.stat_per_plane = per_plane;
     L.partials = nullptr;
     L.packed = nullptr;
+    L.sink = c.sink;
     if (extra) {
         L.l0A = extra->l0A;
         L.l0G = extra->l0G;
@@ -140,6 +170,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     auto launch = [&]() {
         return kind == 2 ? launch_conv2d_mfma(L, c.s) : kind == 3 ? launch_conv3d_mfma(L, c.s) : launch_conv_direct(L, c.s);
     };
+    const bool collecting = c.sink && c.sink->phase == kPackCollect && c.base != nullptr;
+    if (collecting && kind != 0) c.run(launch());  // registers the pack job(s) only
     if (norm) {
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
@@ -185,8 +217,10 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
     L.lrelu = norm ? 1 : 0;
     L.partials = nullptr;
     L.packed = nullptr;
+    L.sink = c.sink;
     const bool mfma = deconv3d_mfma_supported(L);
     if (mfma) L.packed = c.get<float>(deconv3d_mfma_packed_floats(in, cout, kd));
+    if (mfma && c.sink && c.sink->phase == kPackCollect && c.base != nullptr) c.run(launch_deconv3d_mfma(L, c.s));
     // partial records per (n, c): direct kernel [d][tile]; MFMA kernel [tile][parity class]
     const int per_group = mfma ? deconv3d_mfma_tiles(in) * (kd == 4 ? 8 : 4) : deconv_direct_tiles(o.g) * o.g.d;
     if (norm) {
@@ -249,10 +283,9 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     float* bias3 = c.get<float>(3 * F);
     const Geom g3{batch, F, 3, h, w + 1};   // plane 0: left, planes 1-2: right, each padded by one zero column
     float* x3 = c.get<float>(g3.numel());
-    if (!c.plan) {
+    if (c.before_packing())
         c.run(launch_split_first_weights(P.first.weight, P.first.bias, w3, w3 + wn, w3 + 2 * wn, bias3, F, F, c.s));
-        c.run(launch_l0_stack_inputs(left, right, x3, (size_t)batch * F, h, w, c.s));
-    }
+    if (!c.plan) c.run(launch_l0_stack_inputs(left, right, x3, (size_t)batch * F, h, w, c.s));
     // A = conv_L(left) + bias, G = conv_R(right), G2 = G without its dx = +1 taps: three planes of y3
     const Geom g{batch, F, d_count, h, w};
     const bool fused = [&]() {
@@ -426,9 +459,9 @@ int pds_matching_fwd(const PdsMatchingParams* params, const float* left, const f
     PDS_REQUIRE(batch > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0, "matching: bad shape");
     const size_t need = pds_matching_workspace_bytes(params, batch, h, w, d_count);
     PDS_REQUIRE(workspace_bytes >= need, "matching: workspace too small (%zu < %zu)", workspace_bytes, need);
-    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
-    matching_pipeline(c, *params, left, right, signatures, batch, h, w, d_begin, d_count);
-    return c.err;
+    return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
+        matching_pipeline(c, *params, left, right, signatures, batch, h, w, d_begin, d_count);
+    });
 }
 
 size_t pds_matching_operation_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w) {
@@ -446,9 +479,9 @@ int pds_matching_operation_fwd(const PdsMatchingParams* params, const float* con
     const size_t need = pds_matching_operation_workspace_bytes(params, n, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "matching_operation: workspace too small (%zu < %zu)", workspace_bytes,
                 need);
-    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
-    operation_pipeline(c, *params, concatenated, signature, n, h, w);
-    return c.err;
+    return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
+        operation_pipeline(c, *params, concatenated, signature, n, h, w);
+    });
 }
 
 static int check_block(const PdsConvBlockParams& b, bool norm, const char* name) {
@@ -491,9 +524,9 @@ int pds_regularization_fwd(const PdsRegularizationParams* params, const float* s
     PDS_REQUIRE(signatures && left_shortcut && cost && workspace, "regularization: null pointer");
     const size_t need = pds_regularization_workspace_bytes(params, batch, d, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "regularization: workspace too small (%zu < %zu)", workspace_bytes, need);
-    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
-    regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
-    return c.err;
+    return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
+        regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
+    });
 }
 
 int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, const float* signatures,
@@ -512,15 +545,20 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
     const int lo = -((half_support_window + disparity_step - 1) / disparity_step);
     if (upsample_estimator_supported(params->features / 2, lo, hi)) {
         // fused: the full-resolution cost volume is never materialised
-        DT half = regularization_trunk(c, *params, signatures, left_shortcut, batch, d, h, w);
-        if (c.err) return c.err;
+        DT half;
+        if (int rc = run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& cc) {
+                half = regularization_trunk(cc, *params, signatures, left_shortcut, batch, d, h, w);
+            }))
+            return rc;
         return launch_upsample_estimator(half.raw, half.scale, half.shift, params->upsample_full.weight,
                                          params->upsample_full.bias, disparities, batch, half.g.c, half.g.d, half.g.h,
-                                         half.g.w, lo, hi, disparity_step, c.s);
+                                         half.g.w, lo, hi, disparity_step, (hipStream_t)stream);
     }
     float* cost = c.get<float>((size_t)batch * 2 * d * 4 * h * 4 * w);
-    regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
-    if (c.err) return c.err;
+    if (int rc = run_with_batched_packing((char*)workspace + c.off, (hipStream_t)stream, [&](Ctx& cc) {
+            regularization_pipeline(cc, *params, signatures, left_shortcut, cost, batch, d, h, w);
+        }))
+        return rc;
     return pds_subpixel_map_fwd(cost, disparities, batch, 2 * d, 4 * h, 4 * w, half_support_window, disparity_step,
                                 stream);
 }

@@ -46,6 +46,33 @@ struct Geom {
     __host__ __device__ size_t numel() const { return (size_t)n * c * d * h * w; }
 };
 
+// ---- weight packing jobs (pack.hip) -------------------------------------------------------------
+struct PackJob {
+    const float* src = nullptr;  // PyTorch-layout weights
+    float* dst = nullptr;        // fragment-ordered weights
+    unsigned* mask = nullptr;    // transposed convolutions: per-block tap masks
+    int cout = 0, cin = 0, mblocks = 0, kc = 4, taps = 9;
+    int mode = 0;                // 0 conv, 1 transposed k4 s2, 2 transposed k(3,4,4) s(1,2,2)
+    int total = 0;               // floats in dst
+};
+int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s);
+
+// How an MFMA launcher treats its weight packing:
+//   kPackInline  pack (own launch) then run            -- stand-alone layer entry points
+//   kPackCollect append the job(s) to `jobs`, launch NOTHING -- first walk of a module pipeline
+//   kPackDone    weights already packed, just run      -- second walk
+enum PackPhase { kPackInline = 0, kPackCollect = 1, kPackDone = 2 };
+struct PackSink {
+    PackPhase phase = kPackInline;
+    PackJob* jobs = nullptr;
+    int count = 0, capacity = 0;
+    bool push(const PackJob& j) {
+        if (count >= capacity) return false;
+        jobs[count++] = j;
+        return true;
+    }
+};
+
 // ---- launchers (defined in the .hip files) -------------------------------------------------
 struct ConvLayer {
     Src a, b;            // input = a (+ b)
@@ -71,6 +98,7 @@ struct ConvLayer {
     float* side_out = nullptr;
     // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)
     int plane_weight_sets = 0;
+    PackSink* sink = nullptr;  // nullptr: pack inline
 };
 
 // direct VALU convolution, any channel count
@@ -88,6 +116,7 @@ struct DeconvLayer {
     int lrelu;
     double* partials;
     float* packed;  // scratch for the MFMA path (virtual weights + tap masks)
+    PackSink* sink = nullptr;
 };
 int launch_deconv_direct(const DeconvLayer& L, hipStream_t s);
 int deconv_direct_tiles(const Geom& out_g);

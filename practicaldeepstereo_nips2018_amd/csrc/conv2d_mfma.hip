@@ -72,28 +72,6 @@ struct Cfg {
 
 }  // namespace
 
-// wpk[chunk][tap][ks][mb][k][i] = W[oc = mb*16 + i][c = chunk*8 + ks*4 + k][tap]   (0 when oc >= Cout)
-__global__ __launch_bounds__(256) void pack_conv2d_weights_kernel(const float* __restrict__ w,
-                                                                  float* __restrict__ wpk, int Cout, int Cin,
-                                                                  int MBn) {
-    const int total = (Cin / KC) * 9 * (KC / 4) * MBn * 64;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        int r = e;
-        const int i = r % 16;
-        r /= 16;
-        const int k = r % 4;
-        r /= 4;
-        const int mb = r % MBn;
-        r /= MBn;
-        const int ks = r % (KC / 4);
-        r /= (KC / 4);
-        const int tap = r % 9;
-        const int chunk = r / 9;
-        const int oc = mb * 16 + i, c = chunk * KC + ks * 4 + k;
-        wpk[e] = oc < Cout ? w[((size_t)oc * Cin + c) * 9 + tap] : 0.f;
-    }
-}
-
 // sum over the 16 lanes of a DPP row; the total lands in lane 15 of each row
 __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
@@ -354,11 +332,25 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     if (L.plane_weight_sets > 0 && L.plane_weight_sets != L.in.d)
         return set_error(-1, "conv2d_mfma: %d weight sets for %d planes", L.plane_weight_sets, L.in.d);
     const int total = (int)conv2d_mfma_packed_floats(L.in.c, L.out_g.c);
-    for (int i = 0; i < sets; ++i) {
-        hipLaunchKernelGGL(pack_conv2d_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
-                           L.weight + (size_t)i * L.out_g.c * L.in.c * 9, L.packed + (size_t)i * total, L.out_g.c,
-                           L.in.c, mb);
-        if (int rc = check_launch("pack_conv2d_weights")) return rc;
+    const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+    if (phase != kPackDone) {
+        PackJob jobs[8];
+        if (sets > 8) return set_error(-1, "conv2d_mfma: too many weight sets");
+        for (int i = 0; i < sets; ++i) {
+            PackJob& j = jobs[i];
+            j.src = L.weight + (size_t)i * L.out_g.c * L.in.c * 9;
+            j.dst = L.packed + (size_t)i * total;
+            j.cout = L.out_g.c;
+            j.cin = L.in.c;
+            j.mblocks = mb;
+            j.kc = KC;
+            j.taps = 9;
+            j.mode = 0;
+            j.total = total;
+            if (phase == kPackCollect && !L.sink->push(j)) return set_error(-1, "pack job table full");
+        }
+        if (phase == kPackCollect) return 0;
+        if (int rc = launch_multi_pack(jobs, sets, s)) return rc;
     }
     MfmaArgs A;
     A.a = L.a;

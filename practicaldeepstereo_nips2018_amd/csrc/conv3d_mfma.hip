@@ -76,30 +76,6 @@ __device__ __forceinline__ float row16_sum3(float v) {
 
 }  // namespace
 
-// wpk[chunk][tap][ks][mb][k][i] = W[oc = mb*16 + i][c = chunk*KC + ks*4 + k][tap]   (0 beyond Cout / Cin)
-__global__ __launch_bounds__(256) void pack_conv3d_weights_kernel(const float* __restrict__ w,
-                                                                  float* __restrict__ wpk, int Cout, int Cin,
-                                                                  int mblocks, int kc) {
-    const int ks_n = kc / 4;
-    const int chunks = (Cin + kc - 1) / kc;
-    const int total = chunks * 27 * ks_n * mblocks * 64;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        int r = e;
-        const int i = r % 16;
-        r /= 16;
-        const int k = r % 4;
-        r /= 4;
-        const int mb = r % mblocks;
-        r /= mblocks;
-        const int ks = r % ks_n;
-        r /= ks_n;
-        const int tap = r % 27;
-        const int chunk = r / 27;
-        const int oc = mb * 16 + i, c = chunk * kc + ks * 4 + k;
-        wpk[e] = (oc < Cout && c < Cin) ? w[((size_t)oc * Cin + c) * 27 + tap] : 0.f;
-    }
-}
-
 // MODE 0: convolution; 1: transposed k4 s2 p1 (8 classes); 2: transposed k(3,4,4) s(1,2,2) p1 (4 classes)
 template <int MODE, int S, int MB, int TZ, int TY, int NB, int KC>
 __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
@@ -411,10 +387,21 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s) {
     A.Creal = A.Cout;
     A.tapmask = nullptr;
     {
-        const int total = (int)conv3d_mfma_packed_floats(L.out_g, L.in.c, L.stride);
-        hipLaunchKernelGGL(pack_conv3d_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, L.weight,
-                           L.packed, A.Cout, A.Cin, A.mblocks, p.kc);
-        if (int rc = check_launch("pack_conv3d_weights")) return rc;
+        const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+        if (phase != kPackDone) {
+            PackJob j;
+            j.src = L.weight;
+            j.dst = L.packed;
+            j.cout = A.Cout;
+            j.cin = A.Cin;
+            j.mblocks = A.mblocks;
+            j.kc = p.kc;
+            j.taps = 27;
+            j.mode = 0;
+            j.total = (int)conv3d_mfma_packed_floats(L.out_g, L.in.c, L.stride);
+            if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
+            if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+        }
     }
     switch (p.id) {
         case 0: return launch3<0, 1, 1, 2, 4, 5, 4>(A, s);
@@ -435,13 +422,6 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// transposed-conv tap index used by output parity `par` at input offset index `o` (0,1,2 <-> -1,0,+1); -1: none
-__host__ __device__ inline int tconv_tap(int par, int o) {
-    if (o == 1) return par == 0 ? 1 : 2;
-    if (par == 0) return o == 0 ? 3 : -1;
-    return o == 2 ? 0 : -1;
-}
-
 Plan3 choose_plan_deconv(const Geom& in) {
     if ((size_t)in.d * in.h * in.w >= 100000) {
         if (in.w % 80 == 0) return Plan3{0, 1, 2, 4, 5, 4};
@@ -453,61 +433,6 @@ Plan3 choose_plan_deconv(const Geom& in) {
 }
 
 }  // namespace
-
-// wpk[chunk][tap][ks][mb][k][i]: virtual channel v = mb*16 + i = class * Cout + oc, c = chunk*kc + ks*4 + k
-__global__ __launch_bounds__(256) void pack_deconv3d_weights_kernel(const float* __restrict__ w,
-                                                                    float* __restrict__ wpk, int Cout, int Cin,
-                                                                    int mblocks, int kc, int mode) {
-    const int ks_n = kc / 4;
-    const int chunks = (Cin + kc - 1) / kc;
-    const int total = chunks * 27 * ks_n * mblocks * 64;
-    const int ncls = mode == 1 ? 8 : 4;
-    const int kdn = mode == 1 ? 4 : 3;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        int r = e;
-        const int i = r % 16;
-        r /= 16;
-        const int k = r % 4;
-        r /= 4;
-        const int mb = r % mblocks;
-        r /= mblocks;
-        const int ks = r % ks_n;
-        r /= ks_n;
-        const int tap = r % 27;
-        const int chunk = r / 27;
-        const int v = mb * 16 + i, c = chunk * kc + ks * 4 + k;
-        float val = 0.f;
-        if (v < ncls * Cout && c < Cin) {
-            const int cls = v / Cout, oc = v % Cout;
-            const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const int kd = mode == 1 ? tconv_tap(pd, dz) : 2 - dz;  // (3,.,.) stride 1: id = od + 1 - kd
-            const int kh = tconv_tap(ph, dy), kw = tconv_tap(pw, dx);
-            if (kd >= 0 && kh >= 0 && kw >= 0) val = w[(((size_t)c * Cout + oc) * kdn + kd) * 16 + kh * 4 + kw];
-        }
-        wpk[e] = val;
-    }
-}
-
-// one 27-bit mask per 16-channel block: taps with a non-zero weight for at least one of its channels
-__global__ void deconv_tapmask_kernel(unsigned* __restrict__ mask, int Cout, int mblocks, int mode) {
-    const int mb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mb >= mblocks) return;
-    const int ncls = mode == 1 ? 8 : 4;
-    unsigned m = 0;
-    for (int i = 0; i < 16; ++i) {
-        const int v = mb * 16 + i;
-        if (v >= ncls * Cout) break;
-        const int cls = v / Cout;
-        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-        for (int tap = 0; tap < 27; ++tap) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const int kd = mode == 1 ? tconv_tap(pd, dz) : 2 - dz;
-            if (kd >= 0 && tconv_tap(ph, dy) >= 0 && tconv_tap(pw, dx) >= 0) m |= 1u << tap;
-        }
-    }
-    mask[mb] = m;
-}
 
 bool deconv3d_mfma_supported(const DeconvLayer& L) {
     if (L.kd != 4 && L.kd != 3) return false;
@@ -564,11 +489,24 @@ int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s) {
     const size_t wfloats = (size_t)chunks * 27 * (p.kc / 4) * A.mblocks * 64;
     unsigned* mask = reinterpret_cast<unsigned*>(L.packed + wfloats);
     A.tapmask = mask;
-    hipLaunchKernelGGL(pack_deconv3d_weights_kernel, dim3((unsigned)((wfloats + 255) / 256)), dim3(256), 0, s,
-                       L.weight, L.packed, A.Creal, A.Cin, A.mblocks, p.kc, mode);
-    hipLaunchKernelGGL(deconv_tapmask_kernel, dim3((A.mblocks + 63) / 64), dim3(64), 0, s, mask, A.Creal, A.mblocks,
-                       mode);
-    if (int rc = check_launch("pack_deconv3d_weights")) return rc;
+    {
+        const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+        if (phase != kPackDone) {
+            PackJob j;
+            j.src = L.weight;
+            j.dst = L.packed;
+            j.mask = mask;
+            j.cout = A.Creal;
+            j.cin = A.Cin;
+            j.mblocks = A.mblocks;
+            j.kc = p.kc;
+            j.taps = 27;
+            j.mode = mode;
+            j.total = (int)wfloats;
+            if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
+            if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+        }
+    }
     if (mode == 1) {
         switch (p.id) {
             case 0: return launch3<1, 1, 1, 2, 4, 5, 4>(A, s);

@@ -1,0 +1,101 @@
+// Weight re-layout into MFMA fragment order for every MFMA kernel, batched: all layers of a module are
+// packed by ONE launch (grid.y = job) instead of one tiny launch per layer.
+//
+//   wpk[chunk][tap][ks][mb][k][i]   (i = lane & 15, k = lane >> 4: exactly the A-fragment of
+//                                    v_mfma_f32_16x16x4_f32, so the kernels read weights lane-linearly)
+//   conv   (taps 9 or 27): W[oc = mb*16 + i][c = chunk*kc + ks*4 + k][tap]          PyTorch [Cout, Cin, k...]
+//   deconv (taps 27 on the input grid): virtual channel v = class*Cout + oc, class = output parity;
+//           value = Wt[c][oc][kd][kh][kw] for the transposed-conv tap that parity uses at that input
+//           offset, else 0; plus one 27-bit tap mask per 16-channel block (see conv3d_mfma.hip).
+#include "common.hpp"
+
+namespace pds {
+
+// transposed-conv tap used by output parity `par` at input offset index `o` (0,1,2 <-> -1,0,+1); -1: none
+// out = 2*i - 1 + k: even outputs use (i, k=1), (i-1, k=3); odd outputs (i, k=2), (i+1, k=0)
+__host__ __device__ inline int tconv_tap(int par, int o) {
+    if (o == 1) return par == 0 ? 1 : 2;
+    if (par == 0) return o == 0 ? 3 : -1;
+    return o == 2 ? 0 : -1;
+}
+
+constexpr int kMaxJobs = 24;
+struct PackTable {
+    PackJob j[kMaxJobs];
+};
+
+__device__ __forceinline__ bool deconv_tap_valid(int mode, int cls, int tap, int& kd, int& kh, int& kw) {
+    const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    kd = mode == 1 ? tconv_tap(pd, dz) : 2 - dz;  // (3,.,.) stride 1: id = od + 1 - kd
+    kh = tconv_tap(ph, dy);
+    kw = tconv_tap(pw, dx);
+    return kd >= 0 && kh >= 0 && kw >= 0;
+}
+
+__global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
+    const PackJob J = T.j[blockIdx.y];
+    const int ks_n = J.kc / 4;
+    const int ncls = J.mode == 1 ? 8 : (J.mode == 2 ? 4 : 1);
+    const int kdn = J.mode == 1 ? 4 : 3;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
+        int r = e;
+        const int i = r % 16;
+        r /= 16;
+        const int k = r % 4;
+        r /= 4;
+        const int mb = r % J.mblocks;
+        r /= J.mblocks;
+        const int ks = r % ks_n;
+        r /= ks_n;
+        const int tap = r % J.taps;
+        const int chunk = r / J.taps;
+        const int v = mb * 16 + i, c = chunk * J.kc + ks * 4 + k;
+        float val = 0.f;
+        if (J.mode == 0) {
+            if (v < J.cout && c < J.cin) val = J.src[((size_t)v * J.cin + c) * J.taps + tap];
+        } else if (v < ncls * J.cout && c < J.cin) {
+            const int cls = v / J.cout, oc = v % J.cout;
+            int kd, kh, kw;
+            if (deconv_tap_valid(J.mode, cls, tap, kd, kh, kw))
+                val = J.src[(((size_t)c * J.cout + oc) * kdn + kd) * 16 + kh * 4 + kw];
+        }
+        J.dst[e] = val;
+    }
+    // tap masks of the transposed convolutions: one 27-bit word per 16-channel block
+    if (J.mode != 0 && blockIdx.x == 0) {
+        for (int mb = threadIdx.x; mb < J.mblocks; mb += 256) {
+            unsigned m = 0;
+            for (int i = 0; i < 16; ++i) {
+                const int v = mb * 16 + i;
+                if (v >= ncls * J.cout) break;
+                for (int tap = 0; tap < 27; ++tap) {
+                    int kd, kh, kw;
+                    if (deconv_tap_valid(J.mode, v / J.cout, tap, kd, kh, kw)) m |= 1u << tap;
+                }
+            }
+            J.mask[mb] = m;
+        }
+    }
+}
+
+int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s) {
+    for (int first = 0; first < count; first += kMaxJobs) {
+        PackTable T;
+        const int n = count - first < kMaxJobs ? count - first : kMaxJobs;
+        int biggest = 0;
+        for (int i = 0; i < n; ++i) {
+            T.j[i] = jobs[first + i];
+            if (T.j[i].total > biggest) biggest = T.j[i].total;
+        }
+        for (int i = n; i < kMaxJobs; ++i) T.j[i] = PackJob{};
+        int bx = (biggest + 255) / 256;
+        if (bx > 128) bx = 128;
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(multi_pack_kernel, dim3(bx, n), dim3(256), 0, s, T);
+        if (int rc = check_launch("multi_pack")) return rc;
+    }
+    return 0;
+}
+
+}  // namespace pds
