@@ -53,6 +53,12 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-reps', type=int, default=10)
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the hot path as one captured HIP graph (N = 1); measured equal to eager launches '
+                         'because the GPU is saturated, so eager is the default')
+    ap.add_argument('--backend', default='nccl', help='process-group backend for N > 1 ("nccl" is RCCL)')
+    ap.add_argument('--share-device', action='store_true',
+                    help='functional test only: every rank uses cuda:0 (needs --backend gloo)')
     return ap.parse_args()
 
 
@@ -153,10 +159,15 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
     _lib.load()  # fail loudly when the HIP extension is missing
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     net, ld, rd, shortcut = make_inputs()
     net = net.to(device)
@@ -171,6 +182,26 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    # --graph: the ~70 launches of a step are captured once into a HIP graph and replayed (the C ABI never
+    # allocates or synchronises, so the whole hot path is capturable).
+    use_graph = world == 1 and args.graph
+    if use_graph:
+        with torch.no_grad():
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                step()
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    graph_out = step()
+            torch.cuda.current_stream(device).wait_stream(side)
+        eager_step = step
+
+        def step():  # noqa: F811
+            graph.replay()
+            return graph_out
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -207,7 +238,8 @@ def main():
             'config': {'workload': 'configs[1]: 960x540 pair padded to 576x960, D=192 (48 matching planes, 96 cost '
                                    'planes), batch 1, eval mode, random-init weights seed 0',
                        'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL)' % world)
-                       if world > 1 else 'single GPU'},
+                       if world > 1 else 'single GPU',
+                       'launch': 'hip graph replay' if use_graph else 'eager'},
         }
         with torch.no_grad():
             kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)

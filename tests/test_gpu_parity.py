@@ -358,3 +358,47 @@ def test_config4_kitti_shape_batch(dev):
     assert rep['mae'] <= 2e-3, rep
     out = net._size_adapter.unpad(disparity)
     assert out.shape == (2, 375, 1242)
+
+
+# ------------------------------------------------------------------------------- ABI properties
+def test_hot_path_is_graph_capturable(dev):
+    """include/pds_hip.h promises no allocation / synchronisation inside the library: the whole hot path
+    must record into a HIP graph and replay bit-identically."""
+    net, ld, rd, shortcut = hot_path_inputs(63, 1, 128, 256)
+    net = net.to(dev)
+    ld, rd, sc = ld.to(dev), rd.to(dev), shortcut.to(dev)
+    with torch.no_grad():
+        def run():
+            ms = net._matching(ld, rd)
+            return net._regularization.forward_with_estimator(ms, sc, net._estimator)
+        eager = run().clone()          # also warms up workspaces and kernel attributes
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            run()                      # warm-up on the capture stream
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                captured = run()
+        for _ in range(3):
+            captured.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(captured, eager)
+
+
+def test_config4_full_batch_runs(dev):
+    """BASELINE configs[3] at its full batch of 4 (shape and finiteness only; values are checked at
+    batch 2 against the oracle above)."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(255).eval().to(dev)
+    g = torch.Generator().manual_seed(12)
+    ld = torch.randn(4, 64, 96, 320, generator=g).to(dev)
+    rd = torch.randn(4, 64, 96, 320, generator=g).to(dev)
+    sc = torch.randn(4, 8, 96, 320, generator=g).to(dev)
+    with torch.no_grad():
+        ms = net._matching(ld, rd)
+        disparity = net._regularization.forward_with_estimator(ms, sc, net._estimator)
+    assert ms.shape == (4, 8, 64, 96, 320) and disparity.shape == (4, 384, 1280)
+    assert bool(torch.isfinite(disparity).all())
+    assert float(disparity.min()) >= 0.0 and float(disparity.max()) <= 254.0 + 1e-3
