@@ -397,9 +397,20 @@ static DT regularization_trunk(Ctx& c, const PdsRegularizationParams& P, const f
     return deconv_block(c, out.src(), no_src(), out.g, P.upsample_half, F / 2, 4);
 }
 
+bool upsample_full_valu_supported(int cin);
+int launch_upsample_full(const float* in, const float* scale, const float* shift, const float* w, const float* bias,
+                         float* cost, int batch, int cin, int d, int hi_, int wi, hipStream_t s);
+
 static void regularization_pipeline(Ctx& c, const PdsRegularizationParams& P, const float* ms, const float* left,
                                     float* cost, int batch, int d, int h, int w) {
     DT half = regularization_trunk(c, P, ms, left, batch, d, h, w);
+    if (upsample_full_valu_supported(half.g.c)) {
+        // 4 -> 1 channels: the plane-sweeping VALU kernel beats the MFMA path (which wastes 12 of 16 rows)
+        if (!c.plan)
+            c.run(launch_upsample_full(half.raw, half.scale, half.shift, P.upsample_full.weight, P.upsample_full.bias,
+                                       cost, batch, half.g.c, half.g.d, half.g.h, half.g.w, c.s));
+        return;
+    }
     deconv_block(c, half.src(), no_src(), half.g, P.upsample_full, 1, 3, cost);
 }
 

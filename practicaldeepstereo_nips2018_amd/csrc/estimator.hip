@@ -6,8 +6,9 @@
 //
 // HBM-bound: the volume is read exactly once (the reference reads it >= 6 times: max + 5 gathers).
 // Each lane owns VEC consecutive pixels (16-byte loads when VEC == 4) and keeps, in registers, a
-// ring of the last T values plus the T values that follow the running maximum, so the taps around
-// the arg-max are known when the sweep ends -- no second gather pass.
+// delayed window of the last 2T+1 values; when the window's centre becomes the running maximum its
+// neighbours are captured, so the taps around the arg-max are known when the sweep ends -- no second
+// gather pass.
 #include "common.hpp"
 
 namespace pds {
@@ -22,48 +23,53 @@ __global__ __launch_bounds__(256) void subpixel_map_kernel(const float* __restri
     if (p0 >= plane_px) return;
     const float* src = sim + b * planes * plane_px + p0;
 
-    float best[VEC], prev[VEC][T], bprev[VEC][T], bnext[VEC][T];
+    // delayed window win[0..2T] of the last planes (win[2T] newest): when its centre (plane k - T) beats the
+    // running maximum the T neighbours on either side are captured -- static register indices only (a
+    // formulation with conditionally indexed arrays ends up in scratch memory).
+    float best[VEC], win[VEC][2 * T + 1], bprev[VEC][T], bnext[VEC][T];
     int bi[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         best[v] = -INFINITY;
         bi[v] = 0;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            prev[v][t] = -INFINITY;
-            bprev[v][t] = -INFINITY;
-            bnext[v][t] = -INFINITY;
-        }
+        for (int t = 0; t < T; ++t) bprev[v][t] = bnext[v][t] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * T + 1; ++t) win[v][t] = -INFINITY;
     }
 
 #pragma unroll 4
-    for (int k = 0; k < planes; ++k) {
+    for (int k = 0; k < planes + T; ++k) {  // + T flush steps
         float x[VEC];
-        if constexpr (VEC == 4) {
-            const float4 q = *reinterpret_cast<const float4*>(src + (size_t)k * plane_px);
-            x[0] = q.x;
-            x[1] = q.y;
-            x[2] = q.z;
-            x[3] = q.w;
+        if (k < planes) {
+            if constexpr (VEC == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(src + (size_t)k * plane_px);
+                x[0] = q.x;
+                x[1] = q.y;
+                x[2] = q.z;
+                x[3] = q.w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) x[v] = src[(size_t)k * plane_px + v];
+            }
         } else {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) x[v] = src[(size_t)k * plane_px + v];
+            for (int v = 0; v < VEC; ++v) x[v] = -INFINITY;
         }
+        const int centre = k - T;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const bool up = x[v] > best[v];  // strict: first occurrence wins (CPU th.max tie-break)
-            const int dk = k - bi[v];
+#pragma unroll
+            for (int t = 0; t < 2 * T; ++t) win[v][t] = win[v][t + 1];
+            win[v][2 * T] = x[v];
+            const bool up = centre >= 0 && win[v][T] > best[v];  // strict: first occurrence wins
+            best[v] = up ? win[v][T] : best[v];
+            bi[v] = up ? centre : bi[v];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                // value t+1 planes after the current best
-                bnext[v][t] = up ? -INFINITY : ((dk == t + 1) ? x[v] : bnext[v][t]);
-                bprev[v][t] = up ? prev[v][t] : bprev[v][t];
+                bprev[v][t] = up ? win[v][T - 1 - t] : bprev[v][t];
+                bnext[v][t] = up ? win[v][T + 1 + t] : bnext[v][t];
             }
-            best[v] = up ? x[v] : best[v];
-            bi[v] = up ? k : bi[v];
-#pragma unroll
-            for (int t = T - 1; t > 0; --t) prev[v][t] = prev[v][t - 1];
-            prev[v][0] = x[v];
         }
     }
 

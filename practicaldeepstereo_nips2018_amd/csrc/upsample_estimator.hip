@@ -33,6 +33,7 @@ struct FusedArgs {
     const float* __restrict__ w;      // [C, 1, 3, 4, 4]
     const float* __restrict__ bias;   // [1]
     float* __restrict__ disp;         // [B, 2Hi, 2Wi]
+    float* __restrict__ cost;         // WRITE_COST variant: [B, D, 2Hi, 2Wi] instead of the disparity
     int D, Hi, Wi;
     int lo, hi;                       // tap range of the estimator
     float step;
@@ -40,7 +41,9 @@ struct FusedArgs {
 
 }  // namespace
 
-template <int CIN, int T>
+// WRITE_COST = true: training-mode forward, every finished plane is stored to the cost volume and no
+// estimator state is kept (T is ignored).
+template <int CIN, int T, bool WRITE_COST>
 __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedArgs A) {
     __shared__ __attribute__((aligned(16))) float tile[2][CIN][NPOS + 4];
     const int lane = threadIdx.x;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
     __syncthreads();
 
     const int lbase = r * HC + 2 * cp;  // halo row r, halo column 2cp  (input column j0 + 2cp - 1)
-    for (int p = 0; p <= A.D + T; ++p) {  // + T flush steps that only drain the window
+    for (int p = 0; p <= A.D + (WRITE_COST ? 0 : T); ++p) {  // + T flush steps that only drain the window
         if (p < A.D) {
             const int cur = p & 1;
             if (p + 1 < A.D) PDS_FETCHP(p + 1)
@@ -150,7 +153,25 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
             if (p + 1 < A.D) PDS_STASHP(cur ^ 1)
             __syncthreads();
         }
-        if (p >= 1) {
+        if (WRITE_COST) {
+            if (p >= 1) {  // store the finished plane p - 1
+                const int i = i0 + r, j = j0 + 2 * cp;
+                if (i < A.Hi && j < A.Wi) {
+                    const int Wo = 2 * A.Wi;
+                    float* dst0 = A.cost + (((size_t)b * A.D + (p - 1)) * 2 * A.Hi + 2 * i) * Wo + 2 * j;
+                    float* dst1 = dst0 + Wo;
+                    if (j + 1 < A.Wi) {
+                        *reinterpret_cast<float4*>(dst0) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                        *reinterpret_cast<float4*>(dst1) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+                    } else {
+                        dst0[0] = acc[0][0];
+                        dst0[1] = acc[0][1];
+                        dst1[0] = acc[0][4];
+                        dst1[1] = acc[0][5];
+                    }
+                }
+            }
+        } else if (p >= 1) {
             const int k = p - 1;          // plane entering the window (a real plane while k < D)
             const int centre = k - T;     // plane now at the centre of the window
 #pragma unroll
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
 #undef PDS_FETCHP
 #undef PDS_STASHP
 
+    if (WRITE_COST) return;
     // soft-arg-max around the best plane (estimator.py:84-91)
     const int planes = A.D;
     const int i = i0 + r, j = j0 + 2 * cp;
@@ -241,13 +263,39 @@ int launch_upsample_estimator(const float* in, const float* scale, const float* 
     dim3 grid((wi + TC - 1) / TC, (hi_ + TR - 1) / TR, batch);
     const int t = (-lo > hi) ? -lo : hi;
     if (cin != 4) return set_error(-1, "upsample_estimator: unsupported channel count %d", cin);
+    A.cost = nullptr;
     if (t <= 1)
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1>), grid, dim3(64), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, false>), grid, dim3(64), 0, s, A);
     else if (t <= 2)
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2>), grid, dim3(64), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2, false>), grid, dim3(64), 0, s, A);
     else
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4>), grid, dim3(64), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4, false>), grid, dim3(64), 0, s, A);
     return check_launch("upsample_full_subpixel");
+}
+
+bool upsample_full_valu_supported(int cin) { return cin == 4; }
+
+// Training-mode forward of _upsample_to_fullsize (regularization.py:90-92): same sweep, cost volume stored.
+int launch_upsample_full(const float* in, const float* scale, const float* shift, const float* w, const float* bias,
+                         float* cost, int batch, int cin, int d, int hi_, int wi, hipStream_t s) {
+    if (cin != 4) return set_error(-1, "upsample_full: unsupported channel count %d", cin);
+    FusedArgs A;
+    A.in = in;
+    A.scale = scale;
+    A.shift = shift;
+    A.w = w;
+    A.bias = bias;
+    A.disp = nullptr;
+    A.cost = cost;
+    A.D = d;
+    A.Hi = hi_;
+    A.Wi = wi;
+    A.lo = 0;
+    A.hi = 0;
+    A.step = 0.f;
+    dim3 grid((wi + TC - 1) / TC, (hi_ + TR - 1) / TR, batch);
+    hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, true>), grid, dim3(64), 0, s, A);
+    return check_launch("upsample_full");
 }
 
 }  // namespace pds
