@@ -214,10 +214,30 @@ def main():
         torch.cuda.synchronize(device)
         barrier()
         elapsed = time.perf_counter() - t0
+    replica_elapsed = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # Second, informational mode: every rank runs the whole (unsharded) hot path on its own pair --
+        # N independent replicas, no collective; aggregate throughput = N * steps / max time.
+        unsharded = net._matching
+
+        def replica_step():
+            return regularization.forward_with_estimator(unsharded(ld_g, rd_g), sc_g, estimator)
+        with torch.no_grad():
+            for _ in range(max(1, args.warmup // 2)):
+                replica_step()
+            barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                replica_step()
+            torch.cuda.synchronize(device)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        replica_elapsed = float(t.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -241,6 +261,11 @@ def main():
                        if world > 1 else 'single GPU',
                        'launch': 'hip graph replay' if use_graph else 'eager'},
         }
+        if replica_elapsed is not None:
+            line['replica_mode'] = {'value': world * args.steps / replica_elapsed, 'unit': 'pairs/s',
+                                    'ms_per_step': replica_elapsed / args.steps * 1e3, 'scaling': 'weak',
+                                    'note': 'one independent pair per rank, no collective (throughput mode); '
+                                            '"value" above is the disparity-sharded latency mode of north_star'}
         with torch.no_grad():
             kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)
         achieved = CONV64_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
