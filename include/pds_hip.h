@@ -166,6 +166,31 @@ int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* 
                        float* shift, int n, int cin, int cout, int d, int h, int w, int kd, int stride,
                        int per_plane, void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Backward (training: loss.backward() in reference pds_trainer.py:40-46 reaches these modules through
+ * autograd).  Each *_bwd re-derives the forward's intermediates from the forward workspace, which the
+ * caller must have kept untouched since the matching *_fwd call (the arena layout is deterministic; the
+ * library keeps no state).  `grads` mirrors `params`: every pointer is the gradient buffer of that
+ * parameter, written (not accumulated).  Input gradients are written too.
+ * ---------------------------------------------------------------------------------- */
+size_t pds_regularization_bwd_workspace_bytes(const PdsRegularizationParams* params, int batch, int d, int h, int w);
+int pds_regularization_bwd(const PdsRegularizationParams* params, const PdsRegularizationParams* grads,
+                           const float* signatures, const float* left_shortcut, const float* grad_cost,
+                           float* grad_signatures, float* grad_left_shortcut, int batch, int d, int h, int w,
+                           void* fwd_workspace, size_t fwd_workspace_bytes, void* workspace, size_t workspace_bytes,
+                           pds_stream_t stream);
+
+size_t pds_matching_operation_bwd_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w);
+int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchingParams* grads,
+                               const float* concatenated, const float* grad_signature, float* grad_concatenated,
+                               int n, int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes,
+                               void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
+/* backward of pds_shift_concat_fwd: grad_out [d_count, batch, 2*channels, h, w] -> grad_left, grad_right
+ * [batch, channels, h, w]   (reference matching.py:50-61 under autograd) */
+int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_right, int batch, int channels,
+                         int h, int w, int d_begin, int d_count, pds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

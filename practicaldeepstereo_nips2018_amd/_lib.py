@@ -89,6 +89,13 @@ SIGNATURES = {
     'pds_conv_block_workspace_bytes': (_SZ, [_I] * 9),
     'pds_conv_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _VP,
                                 _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_regularization_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(RegularizationParams), _I, _I, _I, _I]),
+    'pds_regularization_bwd': (_I, [ctypes.POINTER(RegularizationParams), ctypes.POINTER(RegularizationParams),
+                                    _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _SZ, _VP]),
+    'pds_matching_operation_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I]),
+    'pds_matching_operation_bwd': (_I, [ctypes.POINTER(MatchingParams), ctypes.POINTER(MatchingParams),
+                                        _VP, _VP, _VP, _I, _I, _I, _VP, _SZ, _VP, _SZ, _VP]),
+    'pds_shift_concat_bwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_contraction_block_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
     'pds_contraction_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), ctypes.POINTER(ConvBlockParams),
                                        _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
@@ -142,14 +149,24 @@ def stream_handle(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def conv_block_params(conv, norm=None):
-    """PdsConvBlockParams from a conv module (and its InstanceNorm, if any)."""
+def conv_block_params(conv, norm=None, tensor_of=None):
+    """PdsConvBlockParams from a conv module (and its InstanceNorm, if any).  ``tensor_of`` maps each
+    parameter to the tensor whose address is stored (identity for the values, the gradient buffers
+    for the ``grads`` structs of the backward entry points)."""
+    f = tensor_of if tensor_of is not None else (lambda t: t)
     p = ConvBlockParams()
-    p.weight = conv.weight.data_ptr()
-    p.bias = conv.bias.data_ptr()
-    p.gamma = norm.weight.data_ptr() if norm is not None else None
-    p.beta = norm.bias.data_ptr() if norm is not None else None
+    p.weight = f(conv.weight).data_ptr()
+    p.bias = f(conv.bias).data_ptr()
+    p.gamma = f(norm.weight).data_ptr() if norm is not None else None
+    p.beta = f(norm.bias).data_ptr() if norm is not None else None
     return p
+
+
+def gradient_buffers(module):
+    """One gradient tensor per parameter (written, not accumulated, by the backward kernels) and the
+    lookup ``tensor_of`` for conv_block_params."""
+    grads = {id(p): torch.empty_like(p) for p in module.parameters()}
+    return grads, (lambda p: grads[id(p)])
 
 
 class Workspace(object):
@@ -167,4 +184,4 @@ class Workspace(object):
 
 def not_differentiable(name):
     raise NotImplementedError(
-        '%s: backward kernels of the HIP path are not built yet; run under torch.no_grad()' % name)
+        '%s: backward of this entry point is not built yet; run it under torch.no_grad()' % name)

@@ -42,6 +42,36 @@ int launch_upsample_estimator(const float* in, const float* scale, const float* 
                               const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
                               int hi, int step, hipStream_t s);
 
+// ---- backward tape ---------------------------------------------------------------------------------
+// Recorded while a pipeline is (re-)walked over the forward workspace; the arena is deterministic, so the
+// backward entry points rebuild the tape from the preserved workspace instead of keeping library state.
+struct TapeTensor {
+    const float* raw = nullptr;   // stored values (raw layer output, or a plain tensor)
+    const float* scale = nullptr; // folded InstanceNorm (nullptr: plain)
+    const float* shift = nullptr;
+    const float* mean = nullptr;
+    const float* rstd = nullptr;
+    Geom g{0, 0, 0, 0, 0};
+    int per_plane = 0;
+    int bcast_d = 0;              // [N, C, H, W] tensor broadcast along D (g.d is the broadcast extent)
+};
+struct TapeLayer {
+    int type = 0;                 // 0 conv, 1 transposed conv, 2 sum (out = a^ + b^, plain)
+    int kd = 3, stride = 1;
+    int a = -1, b = -1, out = -1; // tensor ids
+    Geom in_g{0, 0, 0, 0, 0}, out_g{0, 0, 0, 0, 0};
+    const PdsConvBlockParams* P = nullptr;  // address inside the caller's parameter struct
+    bool norm = false;
+};
+struct Tape {
+    std::vector<TapeTensor> tensors;
+    std::vector<TapeLayer> layers;
+    int add(const TapeTensor& t) {
+        tensors.push_back(t);
+        return (int)tensors.size() - 1;
+    }
+};
+
 // ---- workspace arena: plan mode only measures ---------------------------------------------------
 struct Ctx {
     char* base;
@@ -50,6 +80,7 @@ struct Ctx {
     hipStream_t s;
     int err = 0;
     PackSink* sink = nullptr;
+    Tape* tape = nullptr;   // non-null: record layers for the backward pass (and keep every layer tape-friendly)
 
     template <class T>
     T* get(size_t count) {
@@ -96,10 +127,56 @@ struct DT {
     float* raw = nullptr;
     float* scale = nullptr;
     float* shift = nullptr;
+    float* mean = nullptr;
+    float* rstd = nullptr;
     Geom g{0, 0, 0, 0, 0};
     int per_plane = 0;
-    Src src() const { return Src{raw, scale, shift, per_plane, 0}; }
+    int id = -1;
+    Src src() const {
+        Src s{raw, scale, shift, per_plane, 0};
+        s.id = id;
+        return s;
+    }
 };
+
+// a caller-provided plain tensor as a source, registered on the tape when one is being recorded
+static Src external_src(Ctx& c, const float* p, const Geom& g, int bcast_d = 0) {
+    Src s{p, nullptr, nullptr, 0, bcast_d};
+    if (c.tape) {
+        TapeTensor t;
+        t.raw = p;
+        t.g = g;
+        t.bcast_d = bcast_d;
+        s.id = c.tape->add(t);
+    }
+    return s;
+}
+
+static void tape_layer(Ctx& c, int type, int kd, int stride, const Src& a, const Src& b, const Geom& in_g, DT& o,
+                       const PdsConvBlockParams* P, bool norm) {
+    if (!c.tape) return;
+    TapeTensor t;
+    t.raw = o.raw;
+    t.scale = o.scale;
+    t.shift = o.shift;
+    t.mean = o.mean;
+    t.rstd = o.rstd;
+    t.g = o.g;
+    t.per_plane = o.per_plane;
+    o.id = c.tape->add(t);
+    TapeLayer L;
+    L.type = type;
+    L.kd = kd;
+    L.stride = stride;
+    L.a = a.id;
+    L.b = b.p ? b.id : -1;
+    L.out = o.id;
+    L.in_g = in_g;
+    L.out_g = o.g;
+    L.P = P;
+    L.norm = norm;
+    c.tape->layers.push_back(L);
+}
 
 static Geom conv_out_geom(const Geom& in, int cout, int kd, int stride) {
     Geom o = in;
@@ -181,16 +258,19 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
         o.scale = scale_out ? scale_out : c.get<float>(groups);
         o.shift = shift_out ? shift_out : c.get<float>(groups);
+        o.mean = c.get<float>(groups);
+        o.rstd = c.get<float>(groups);
         if (!c.plan) {
             c.run(launch());
             const int per_group = kind == 3 ? tiles : tiles * (per_plane ? 1 : o.g.d);
             const double count = (double)o.g.h * o.g.w * (per_plane ? 1 : o.g.d);
             c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
-                                     per_plane ? o.g.d : 1, o.scale, o.shift, c.s));
+                                     per_plane ? o.g.d : 1, o.scale, o.shift, o.mean, o.rstd, c.s));
         }
     } else if (!c.plan) {
         c.run(launch());
     }
+    tape_layer(c, 0, kd, stride, a, b, in, o, &P, norm);
     return o;
 }
 
@@ -229,36 +309,42 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
         const int groups = o.g.n * o.g.c;
         o.scale = c.get<float>(groups);
         o.shift = c.get<float>(groups);
+        o.mean = c.get<float>(groups);
+        o.rstd = c.get<float>(groups);
         if (!c.plan) {
             c.run(mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s));
             c.run(launch_in_finalize(L.partials, groups, per_group, (double)o.g.volume(), P.gamma, P.beta,
-                                     o.g.c, 1, o.scale, o.shift, c.s));
+                                     o.g.c, 1, o.scale, o.shift, o.mean, o.rstd, c.s));
         }
     } else if (!c.plan) {
         c.run(mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s));
     }
+    tape_layer(c, 1, kd, kd == 4 ? 2 : 1, a, b, in, o, &P, norm);
     return o;
 }
 
 // ---- MatchingOperation after layer 0: residual blocks + last conv ---------------------------------
 // x0 plain [n, F, d, h, w]; kernel depth 1, InstanceNorm statistics per (n, c, d) plane.
-static void operation_tail(Ctx& c, const PdsMatchingParams& P, float* x0, const Geom& g, float* signature) {
+static void operation_tail(Ctx& c, const PdsMatchingParams& P, const Src& x0, const Geom& g, float* signature) {
     const int F = P.features;
-    float* cur = x0;
+    Src cur = x0;
     DT t2;
     for (int r = 0; r < P.residual_blocks; ++r) {
-        DT t1 = conv_block(c, plain_src(cur), no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
+        DT t1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
         t2 = conv_block(c, t1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
         if (r + 1 < P.residual_blocks) {
-            float* nxt = c.get<float>(g.numel());
-            if (!c.plan) c.run(launch_materialize(t2.src(), plain_src(cur), g, nxt, c.s));
-            cur = nxt;
+            DT nxt;  // plain residual sum  x_{r+1} = norm(t2) + x_r
+            nxt.raw = c.get<float>(g.numel());
+            nxt.g = g;
+            if (!c.plan) c.run(launch_materialize(t2.src(), cur, g, nxt.raw, c.s));
+            tape_layer(c, 2, 0, 0, t2.src(), cur, g, nxt, nullptr, false);
+            cur = nxt.src();
         }
     }
     if (P.residual_blocks > 0)
-        conv_block(c, t2.src(), plain_src(cur), g, P.last, P.signature_features, 1, 1, 1, signature);
+        conv_block(c, t2.src(), cur, g, P.last, P.signature_features, 1, 1, 1, signature);
     else
-        conv_block(c, plain_src(cur), no_src(), g, P.last, P.signature_features, 1, 1, 1, signature);
+        conv_block(c, cur, no_src(), g, P.last, P.signature_features, 1, 1, 1, signature);
 }
 
 // Can the fused Matching path (layer-0 terms in the loader, residual sums as side outputs) be used?
@@ -326,7 +412,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     if (!fused) {
         float* x0 = c.get<float>(g.numel());
         if (!c.plan) c.run(launch_l0_combine(l0A, l0G, l0G2, l0_cstride, x0, batch, F, h, w, d_begin, d_count, c.s));
-        operation_tail(c, P, x0, g, signatures);
+        operation_tail(c, P, plain_src(x0), g, signatures);
         return;
     }
     // Fused: x0 = A + shift_d(G) is never stored.  The first conv forms it inside its loader; the first
@@ -367,8 +453,8 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
 static void operation_pipeline(Ctx& c, const PdsMatchingParams& P, const float* concatenated, float* signature,
                                int n, int h, int w) {
     const Geom gin{n, 2 * P.features, 1, h, w};
-    DT x0 = conv_block(c, plain_src(concatenated), no_src(), gin, P.first, P.features, 1, 1, 1);
-    operation_tail(c, P, x0.raw, x0.g, signature);
+    DT x0 = conv_block(c, external_src(c, concatenated, gin), no_src(), gin, P.first, P.features, 1, 1, 1);
+    operation_tail(c, P, x0.src(), x0.g, signature);
 }
 
 // ---- Regularization (reference regularization.py:94-126) -----------------------------------------
@@ -376,10 +462,11 @@ static DT regularization_trunk(Ctx& c, const PdsRegularizationParams& P, const f
                                int batch, int d, int h, int w) {
     const int F = P.features;
     const Geom g0{batch, F, d, h, w};
-    DT out = conv_block(c, plain_src(ms), no_src(), g0, P.smoothing, F, 3, 1, 0);
+    // tape ids: 0 = signatures, 1 = left shortcut ([batch, F, h, w] broadcast along D, regularization.py:115)
+    const Src ms_src = external_src(c, ms, g0);
+    Src shortcut = external_src(c, left, g0, 1);
+    DT out = conv_block(c, ms_src, no_src(), g0, P.smoothing, F, 3, 1, 0);
     DT pushed[4];
-    Src shortcut = plain_src(left);
-    shortcut.bcast_d = 1;
     for (int i = 0; i < 4; ++i) {
         pushed[i] = out;
         const int cin = out.g.c;
@@ -409,9 +496,106 @@ static void regularization_pipeline(Ctx& c, const PdsRegularizationParams& P, co
         if (!c.plan)
             c.run(launch_upsample_full(half.raw, half.scale, half.shift, P.upsample_full.weight, P.upsample_full.bias,
                                        cost, batch, half.g.c, half.g.d, half.g.h, half.g.w, c.s));
+        DT full;
+        full.raw = cost;
+        full.g = Geom{batch, 1, half.g.d, 2 * half.g.h, 2 * half.g.w};
+        tape_layer(c, 1, 3, 1, half.src(), no_src(), half.g, full, &P.upsample_full, false);
         return;
     }
     deconv_block(c, half.src(), no_src(), half.g, P.upsample_full, 1, 3, cost);
+}
+
+
+// ====================================================================================================
+// Backward: reverse walk over a tape.
+// ====================================================================================================
+// maps the address of a layer's parameters inside the caller's struct to the same slot of the gradient struct
+struct GradMap {
+    const char* params_base;
+    const char* grads_base;
+    size_t struct_bytes;
+    const PdsConvBlockParams* blocks_params = nullptr;  // out-of-struct array (PdsMatchingParams::blocks)
+    const PdsConvBlockParams* blocks_grads = nullptr;
+    int blocks_count = 0;
+    const PdsConvBlockParams* find(const PdsConvBlockParams* p) const {
+        if (blocks_params && p >= blocks_params && p < blocks_params + blocks_count) return blocks_grads + (p - blocks_params);
+        const char* q = reinterpret_cast<const char*>(p);
+        if (q >= params_base && q < params_base + struct_bytes)
+            return reinterpret_cast<const PdsConvBlockParams*>(grads_base + (q - params_base));
+        return nullptr;
+    }
+};
+
+// dhat[i]: gradient with respect to the NORMALISED value of tensor i.  Entries preset by the caller (the
+// gradient of the output, the gradient buffers of the external inputs) are used as they are; the others
+// are carved from the backward arena on first use.
+static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<float*>& dhat,
+                          std::vector<char>& written) {
+    for (int li = (int)T.layers.size() - 1; li >= 0; --li) {
+        const TapeLayer& L = T.layers[li];
+        const TapeTensor& out = T.tensors[L.out];
+        float* g = dhat[L.out];
+        if (!written[L.out]) {
+            c.run(set_error(-1, "backward: layer %d has no upstream gradient", li));
+            return;
+        }
+        auto route = [&](int id, const float* grad_in, const Geom& in_g) {
+            if (id < 0) return;
+            const TapeTensor& t = T.tensors[id];
+            if (!dhat[id]) {
+                dhat[id] = c.get<float>(t.bcast_d ? (size_t)t.g.n * t.g.c * t.g.h * t.g.w : t.g.numel());
+                if (!dhat[id]) dhat[id] = reinterpret_cast<float*>(8);  // plan mode: mark as carved
+            }
+            if (!c.plan) {
+                if (t.bcast_d)
+                    c.run(launch_grad_reduce_d(dhat[id], grad_in, in_g, written[id], c.s));
+                else
+                    c.run(launch_grad_add(dhat[id], grad_in, in_g.numel(), written[id], c.s));
+            }
+            written[id] = 1;
+        };
+        if (L.type == 2) {  // plain sum: the gradient flows unchanged to both terms
+            route(L.a, g, L.out_g);
+            route(L.b, g, L.out_g);
+            continue;
+        }
+        const PdsConvBlockParams* gp = M.find(L.P);
+        if (!gp || !gp->weight || !gp->bias || (L.norm && (!gp->gamma || !gp->beta))) {
+            c.run(set_error(-1, "backward: missing gradient buffers for layer %d", li));
+            return;
+        }
+        // 1. through InstanceNorm + LeakyReLU
+        const float* dz = g;
+        if (L.norm) {
+            float* dzb = c.get<float>(out.g.numel());
+            double* scratch = c.get<double>(in_bwd_scratch_doubles(out.g));
+            const int groups = out.g.n * out.g.c * (out.per_plane ? out.g.d : 1);
+            float* m1 = c.get<float>(groups);
+            float* m2 = c.get<float>(groups);
+            if (!c.plan)
+                c.run(launch_in_bwd(g, out.raw, out.g, out.per_plane, out.mean, out.rstd, L.P->gamma, scratch, m1, m2,
+                                    dzb, const_cast<float*>(gp->gamma), const_cast<float*>(gp->beta), 0, c.s));
+            dz = dzb;
+        }
+        // 2. parameters
+        const TapeTensor& ta = T.tensors[L.a];
+        Src sa{ta.raw, ta.scale, ta.shift, ta.per_plane, 0};
+        Src sb = no_src();
+        if (L.b >= 0) {
+            const TapeTensor& tb = T.tensors[L.b];
+            sb = Src{tb.raw, tb.scale, tb.shift, tb.per_plane, tb.bcast_d};
+        }
+        if (!c.plan) {
+            c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, c.s));
+            c.run(launch_bwd_weight(L.type, L.kd, L.stride, sa, sb, dz, const_cast<float*>(gp->weight), L.in_g, L.out_g,
+                                    0, c.s));
+        }
+        // 3. input
+        float* dx = c.get<float>(L.in_g.numel());
+        if (!c.plan) c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, L.P->weight, dx, L.in_g, L.out_g, c.s));
+        route(L.a, dx, L.in_g);
+        route(L.b, dx, L.in_g);
+    }
 }
 
 }  // namespace pds
@@ -651,6 +835,127 @@ int pds_expansion_block_fwd(const PdsConvBlockParams* upsampling, const PdsConvB
     DT sm = conv_block(c, up.src(), plain_src(shortcut), up.g, *smoothing, c_ / 2, 3, 1, 0);
     c.run(launch_materialize(sm.src(), no_src(), sm.g, out, c.s));
     return c.err;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// backward entry points
+// ----------------------------------------------------------------------------------------------------
+static size_t regularization_fwd_bytes(const PdsRegularizationParams* params, int batch, int d, int h, int w) {
+    Ctx c{nullptr, 0, true, nullptr};
+    regularization_pipeline(c, *params, nullptr, nullptr, nullptr, batch, d, h, w);
+    return c.off;
+}
+
+static int regularization_backward(bool plan, size_t* bytes, const PdsRegularizationParams* params,
+                                   const PdsRegularizationParams* grads, const float* signatures,
+                                   const float* left_shortcut, const float* grad_cost, float* grad_signatures,
+                                   float* grad_left_shortcut, int batch, int d, int h, int w, void* fwd_workspace,
+                                   void* workspace, hipStream_t stream) {
+    Tape tape;
+    Ctx re{plan ? nullptr : (char*)fwd_workspace, 0, true, stream};  // re-walk: pointers only, no launches
+    re.tape = &tape;
+    regularization_pipeline(re, *params, signatures, left_shortcut, const_cast<float*>(grad_cost) /*placeholder*/,
+                            batch, d, h, w);
+    if (re.err) return re.err;
+    std::vector<float*> dhat(tape.tensors.size(), nullptr);
+    std::vector<char> written(tape.tensors.size(), 0);
+    // tape order: tensor 0 = signatures, 1 = left shortcut, last = cost
+    dhat[0] = grad_signatures;
+    dhat[1] = grad_left_shortcut;
+    dhat[tape.tensors.size() - 1] = const_cast<float*>(grad_cost);
+    written[tape.tensors.size() - 1] = 1;
+    GradMap M{reinterpret_cast<const char*>(params), reinterpret_cast<const char*>(grads), sizeof(PdsRegularizationParams)};
+    Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (plan) {  // the walk dereferences nothing in plan mode, but needs non-null marks for the presets
+        dhat[0] = dhat[1] = dhat[tape.tensors.size() - 1] = reinterpret_cast<float*>(8);
+    }
+    backward_walk(c, tape, M, dhat, written);
+    if (bytes) *bytes = c.off;
+    return c.err;
+}
+
+size_t pds_regularization_bwd_workspace_bytes(const PdsRegularizationParams* params, int batch, int d, int h, int w) {
+    if (check_regularization(params, batch, d, h, w)) return 0;
+    size_t bytes = 0;
+    PdsRegularizationParams dummy = *params;
+    regularization_backward(true, &bytes, params, &dummy, nullptr, nullptr, nullptr, nullptr, nullptr, batch, d, h, w,
+                            nullptr, nullptr, nullptr);
+    return bytes + 256;
+}
+
+int pds_regularization_bwd(const PdsRegularizationParams* params, const PdsRegularizationParams* grads,
+                           const float* signatures, const float* left_shortcut, const float* grad_cost,
+                           float* grad_signatures, float* grad_left_shortcut, int batch, int d, int h, int w,
+                           void* fwd_workspace, size_t fwd_workspace_bytes, void* workspace, size_t workspace_bytes,
+                           pds_stream_t stream) {
+    if (int rc = check_regularization(params, batch, d, h, w)) return rc;
+    PDS_REQUIRE(grads && signatures && left_shortcut && grad_cost && grad_signatures && grad_left_shortcut &&
+                    fwd_workspace && workspace,
+                "regularization_bwd: null pointer");
+    PDS_REQUIRE(fwd_workspace_bytes >= regularization_fwd_bytes(params, batch, d, h, w),
+                "regularization_bwd: forward workspace too small");
+    const size_t need = pds_regularization_bwd_workspace_bytes(params, batch, d, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "regularization_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return regularization_backward(false, nullptr, params, grads, signatures, left_shortcut, grad_cost,
+                                   grad_signatures, grad_left_shortcut, batch, d, h, w, fwd_workspace, workspace,
+                                   (hipStream_t)stream);
+}
+
+static int operation_backward(bool plan, size_t* bytes, const PdsMatchingParams* params, const PdsMatchingParams* grads,
+                              const float* concatenated, const float* grad_signature, float* grad_concatenated, int n,
+                              int h, int w, void* fwd_workspace, void* workspace, hipStream_t stream) {
+    Tape tape;
+    Ctx re{plan ? nullptr : (char*)fwd_workspace, 0, true, stream};
+    re.tape = &tape;
+    operation_pipeline(re, *params, concatenated, const_cast<float*>(grad_signature) /*placeholder*/, n, h, w);
+    if (re.err) return re.err;
+    std::vector<float*> dhat(tape.tensors.size(), nullptr);
+    std::vector<char> written(tape.tensors.size(), 0);
+    dhat[0] = grad_concatenated;
+    dhat[tape.tensors.size() - 1] = const_cast<float*>(grad_signature);
+    written[tape.tensors.size() - 1] = 1;
+    GradMap M{reinterpret_cast<const char*>(params), reinterpret_cast<const char*>(grads), sizeof(PdsMatchingParams)};
+    M.blocks_params = params->blocks;
+    M.blocks_grads = grads->blocks;
+    M.blocks_count = 2 * params->residual_blocks;
+    Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (plan) dhat[0] = dhat[tape.tensors.size() - 1] = reinterpret_cast<float*>(8);
+    backward_walk(c, tape, M, dhat, written);
+    if (bytes) *bytes = c.off;
+    return c.err;
+}
+
+size_t pds_matching_operation_bwd_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w) {
+    if (check_matching_params(params)) return 0;
+    size_t bytes = 0;
+    operation_backward(true, &bytes, params, params, nullptr, nullptr, nullptr, n, h, w, nullptr, nullptr, nullptr);
+    return bytes + 256;
+}
+
+int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchingParams* grads,
+                               const float* concatenated, const float* grad_signature, float* grad_concatenated, int n,
+                               int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes, void* workspace,
+                               size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_matching_params(params)) return rc;
+    if (int rc = check_matching_params(grads)) return rc;
+    PDS_REQUIRE(concatenated && grad_signature && grad_concatenated && fwd_workspace && workspace,
+                "matching_operation_bwd: null pointer");
+    PDS_REQUIRE(fwd_workspace_bytes >= pds_matching_operation_workspace_bytes(params, n, h, w),
+                "matching_operation_bwd: forward workspace too small");
+    const size_t need = pds_matching_operation_bwd_workspace_bytes(params, n, h, w);
+    PDS_REQUIRE(workspace_bytes >= need, "matching_operation_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+                need);
+    return operation_backward(false, nullptr, params, grads, concatenated, grad_signature, grad_concatenated, n, h, w,
+                              fwd_workspace, workspace, (hipStream_t)stream);
+}
+
+int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_right, int batch, int channels, int h,
+                         int w, int d_begin, int d_count, pds_stream_t stream) {
+    PDS_REQUIRE(grad_out && grad_left && grad_right, "shift_concat_bwd: null pointer");
+    PDS_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0,
+                "shift_concat_bwd: bad shape");
+    return launch_shift_concat_bwd(grad_out, grad_left, grad_right, batch, channels, h, w, d_begin, d_count,
+                                   (hipStream_t)stream);
 }
 
 }  // extern "C"

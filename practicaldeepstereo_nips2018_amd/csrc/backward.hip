@@ -1,0 +1,553 @@
+// Backward kernels of the hot path (training: reference practical_deep_stereo/pds_trainer.py:40-46 calls
+// loss.backward() through Matching and Regularization).  Correctness-first generic VALU kernels, any channel
+// count; every reduction is two-stage and deterministic (no atomics).
+//
+// Layer forward (network_blocks.py:47-85):  z = conv(x) + b;  t = LeakyReLU(z);  y = gamma * (t - mu) * r + beta
+// with mu, r = 1/sqrt(var + eps) per InstanceNorm group.  Given g = dL/dy:
+//   S1 = sum g, S2 = sum g*t over the group;  Q = r * (S2 - mu * S1) = sum g * n,  n = (t - mu) * r
+//   dgamma_c = sum_groups Q,  dbeta_c = sum_groups S1
+//   dt = gamma * r * (g - S1/N - n * Q/N);   dz = dt * (t > 0 ? 1 : 0.1)
+//   db = sum dz;  dW = correlate(x, dz);  dx = transposed-correlate(dz, W)
+#include "common.hpp"
+
+namespace pds {
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm + LeakyReLU backward
+// ---------------------------------------------------------------------------------------------------
+// partial sums of g and g*t: records [(n*C + c)][d][tile] x {S1, S2}
+__global__ __launch_bounds__(256) void in_bwd_partial_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                             const Geom geom, double* __restrict__ partials) {
+    const int nc = blockIdx.z, d = blockIdx.y, tile = blockIdx.x, tiles = gridDim.x;
+    const size_t px = geom.plane();
+    const size_t base = ((size_t)nc * geom.d + d) * px;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)tile * 256 + threadIdx.x; i < px; i += (size_t)tiles * 256) {
+        const float gv = g[base + i], tv = t[base + i];
+        s1 += gv;
+        s2 += (double)gv * tv;
+    }
+    __shared__ double red[4][2];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        partials[((((size_t)nc * geom.d + d) * tiles) + tile) * 2 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+}
+
+// per group: m1 = S1/N, m2 = Q/N, q = Q, s1 = S1 (kept for the parameter gradients)
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const double* __restrict__ partials, int per_group,
+                                                              double count, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ m1,
+                                                              float* __restrict__ m2, double* __restrict__ qs) {
+    const int grp = blockIdx.x;
+    const double* p = partials + (size_t)grp * per_group * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < per_group; i += 256) {
+        s1 += p[2 * i];
+        s2 += p[2 * i + 1];
+    }
+    __shared__ double red[4][2];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1 = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        s2 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        const double q = (double)rstd[grp] * (s2 - (double)mean[grp] * s1);
+        m1[grp] = (float)(s1 / count);
+        m2[grp] = (float)(q / count);
+        qs[2 * grp] = q;
+        qs[2 * grp + 1] = s1;
+    }
+}
+
+// dgamma[c] (+)= sum over the groups of channel c of Q, dbeta[c] (+)= sum of S1.  groups = N*C*inner, group
+// index = (n*C + c)*inner + d.
+__global__ __launch_bounds__(64) void in_bwd_params_kernel(const double* __restrict__ qs, int n_batch, int channels,
+                                                           int inner, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x;
+    double q = 0.0, s = 0.0;
+    const int per_c = n_batch * inner;
+    for (int i = threadIdx.x; i < per_c; i += 64) {
+        const int n = i / inner, d = i % inner;
+        const size_t grp = ((size_t)n * channels + c) * inner + d;
+        q += qs[2 * grp];
+        s += qs[2 * grp + 1];
+    }
+    q = wave_sum(q);
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    }
+}
+
+// dz = lrelu'(t) * gamma * r * (g - m1 - n * m2)
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                           const Geom geom, int per_plane,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ m1, const float* __restrict__ m2,
+                                                           float* __restrict__ dz) {
+    const int nc = blockIdx.z, d = blockIdx.y;
+    const int c = nc % geom.c;
+    const int grp = per_plane ? nc * geom.d + d : nc;
+    const float mu = mean[grp], r = rstd[grp], a = gamma[c] * r, b1 = m1[grp], b2 = m2[grp];
+    const size_t px = geom.plane();
+    const size_t base = ((size_t)nc * geom.d + d) * px;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < px; i += (size_t)gridDim.x * 256) {
+        const float tv = t[base + i];
+        const float n = (tv - mu) * r;
+        const float dt = a * (g[base + i] - b1 - n * b2);
+        dz[base + i] = tv > 0.f ? dt : dt * kLeakySlope;
+    }
+}
+
+static unsigned plane_tiles(const Geom& g) {
+    unsigned t = (unsigned)((g.plane() + 1023) / 1024);
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+}
+
+// scratch (doubles): partial records N*C*D*tiles*2 + group records 2*groups ; floats: m1, m2 [groups]
+size_t in_bwd_scratch_doubles(const Geom& g) {
+    return (size_t)g.n * g.c * g.d * plane_tiles(g) * 2 + (size_t)g.n * g.c * g.d * 2;
+}
+
+int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
+                  const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
+                  float* dgamma, float* dbeta, int accumulate_params, hipStream_t s) {
+    const unsigned tiles = plane_tiles(geom);
+    double* partials = scratch;
+    double* qs = scratch + (size_t)geom.n * geom.c * geom.d * tiles * 2;
+    hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(tiles, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
+                       partials);
+    const int inner = per_plane ? geom.d : 1;
+    const int groups = geom.n * geom.c * inner;
+    const int per_group = (int)tiles * (per_plane ? 1 : geom.d);
+    const double count = (double)geom.plane() * (per_plane ? 1 : geom.d);
+    hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(groups), dim3(256), 0, s, partials, per_group, count, mean, rstd,
+                       m1, m2, qs);
+    hipLaunchKernelGGL(in_bwd_params_kernel, dim3(geom.c), dim3(64), 0, s, qs, geom.n, geom.c, inner, dgamma, dbeta,
+                       accumulate_params);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(tiles * 4, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
+                       per_plane, mean, rstd, gamma, m1, m2, dz);
+    return check_launch("in_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bias gradient: db[c] (+)= sum over n, d, y, x of dz
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dz, const Geom geom,
+                                                          float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x;
+    const size_t vol = geom.volume();
+    double s = 0.0;
+    for (int n = 0; n < geom.n; ++n) {
+        const float* p = dz + ((size_t)n * geom.c + c) * vol;
+        for (size_t i = threadIdx.x; i < vol; i += 256) s += p[i];
+    }
+    __shared__ double red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(g.c), dim3(256), 0, s, dz, g, db, accumulate);
+    return check_launch("channel_sum");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward data
+// ---------------------------------------------------------------------------------------------------
+struct BwdGeom {
+    int N, Cin, Di, Hi, Wi;   // layer INPUT (the gradient being produced)
+    int Cout, Do, Ho, Wo;     // layer OUTPUT (dz)
+};
+
+// conv (KD x 3 x 3, stride S, pad k/2):  dx[c][i] = sum_oc sum_k dz[oc][(i + p - k)/S] * W[oc][c][k]  (when divisible)
+template <int KD, int S, int CB>
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                            float* __restrict__ dx, const BwdGeom G) {
+    const int cbs = (G.Cin + CB - 1) / CB;
+    const int n = blockIdx.z / cbs, c0 = (blockIdx.z % cbs) * CB;
+    const int iz = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int iy = idx / G.Wi, ix = idx % G.Wi;
+    if (iy >= G.Hi) return;
+    float acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = 0.f;
+    const size_t plane_o = (size_t)G.Ho * G.Wo;
+    for (int oc = 0; oc < G.Cout; ++oc) {
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            int oz;
+            if (KD == 1) {
+                oz = iz;
+            } else {
+                const int tz = iz + 1 - kd;
+                if (tz < 0 || tz % S != 0) continue;
+                oz = tz / S;
+                if (oz >= G.Do) continue;
+            }
+            const float* pz = dz + (((size_t)n * G.Cout + oc) * G.Do + oz) * plane_o;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ty = iy + 1 - kh;
+                if (ty < 0 || ty % S != 0) continue;
+                const int oy = ty / S;
+                if (oy >= G.Ho) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tx = ix + 1 - kw;
+                    if (tx < 0 || tx % S != 0) continue;
+                    const int ox = tx / S;
+                    if (ox >= G.Wo) continue;
+                    const float v = pz[(size_t)oy * G.Wo + ox];
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        const int ci = min(c0 + c, G.Cin - 1);
+                        acc[c] = fmaf(v, w[(((size_t)oc * G.Cin + ci) * KD + kd) * 9 + kh * 3 + kw], acc[c]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        if (c0 + c < G.Cin)
+            dx[(((size_t)n * G.Cin + c0 + c) * G.Di + iz) * G.Hi * G.Wi + (size_t)iy * G.Wi + ix] = acc[c];
+}
+
+// transposed conv (kernel (KD,4,4), stride (KD == 4 ? 2 : 1, 2, 2), pad 1; weight [Cin, Cout, KD, 4, 4]):
+//   forward out[oc][o] += x[c][i] * W[c][oc][k] for o = s*i - 1 + k   =>   dx[c][i] = sum_oc sum_k dz[oc][s*i - 1 + k] * W[c][oc][k]
+template <int KD, int CB>
+__global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __restrict__ dz,
+                                                              const float* __restrict__ w, float* __restrict__ dx,
+                                                              const BwdGeom G) {
+    constexpr int SD = KD == 4 ? 2 : 1;
+    const int cbs = (G.Cin + CB - 1) / CB;
+    const int n = blockIdx.z / cbs, c0 = (blockIdx.z % cbs) * CB;
+    const int iz = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int iy = idx / G.Wi, ix = idx % G.Wi;
+    if (iy >= G.Hi) return;
+    float acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = 0.f;
+    const size_t plane_o = (size_t)G.Ho * G.Wo;
+    for (int oc = 0; oc < G.Cout; ++oc) {
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            const int oz = SD * iz - 1 + kd;
+            if (oz < 0 || oz >= G.Do) continue;
+            const float* pz = dz + (((size_t)n * G.Cout + oc) * G.Do + oz) * plane_o;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int oy = 2 * iy - 1 + kh;
+                if (oy < 0 || oy >= G.Ho) continue;
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ox = 2 * ix - 1 + kw;
+                    if (ox < 0 || ox >= G.Wo) continue;
+                    const float v = pz[(size_t)oy * G.Wo + ox];
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        const int ci = min(c0 + c, G.Cin - 1);
+                        acc[c] = fmaf(v, w[(((size_t)ci * G.Cout + oc) * KD + kd) * 16 + kh * 4 + kw], acc[c]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        if (c0 + c < G.Cin)
+            dx[(((size_t)n * G.Cin + c0 + c) * G.Di + iz) * G.Hi * G.Wi + (size_t)iy * G.Wi + ix] = acc[c];
+}
+
+int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
+                    const Geom& out, hipStream_t s) {
+    BwdGeom G{in.n, in.c, in.d, in.h, in.w, out.c, out.d, out.h, out.w};
+    constexpr int CB = 4;
+    dim3 grid((unsigned)((in.h * in.w + 255) / 256), in.d, in.n * ((in.c + CB - 1) / CB));
+    if (!transposed) {
+        if (kd == 1 && stride == 1)
+            hipLaunchKernelGGL((conv_bwd_data_kernel<1, 1, CB>), grid, dim3(256), 0, s, dz, w, dx, G);
+        else if (kd == 3 && stride == 1)
+            hipLaunchKernelGGL((conv_bwd_data_kernel<3, 1, CB>), grid, dim3(256), 0, s, dz, w, dx, G);
+        else if (kd == 3 && stride == 2)
+            hipLaunchKernelGGL((conv_bwd_data_kernel<3, 2, CB>), grid, dim3(256), 0, s, dz, w, dx, G);
+        else
+            return set_error(-1, "bwd_data: unsupported conv kd=%d stride=%d", kd, stride);
+    } else {
+        if (kd == 4)
+            hipLaunchKernelGGL((deconv_bwd_data_kernel<4, CB>), grid, dim3(256), 0, s, dz, w, dx, G);
+        else if (kd == 3)
+            hipLaunchKernelGGL((deconv_bwd_data_kernel<3, CB>), grid, dim3(256), 0, s, dz, w, dx, G);
+        else
+            return set_error(-1, "bwd_data: unsupported deconv kd=%d", kd);
+    }
+    return check_launch("bwd_data");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward weight: one block per (oc, c) pair, TAPS running sums per thread over all positions
+// ---------------------------------------------------------------------------------------------------
+struct BwdWArgs {
+    Src a, b;      // the layer's input (deferred-normalised sources, as in the forward)
+    const float* __restrict__ dz;
+    float* __restrict__ dw;
+    BwdGeom G;
+    int accumulate;
+};
+
+__device__ __forceinline__ float src_value(const Src& a, const Src& b, int n, int C, int c, int D, int d, int H,
+                                           int W, int y, int x) {
+    // normalised input value at an in-range position
+    const size_t plane = (size_t)H * W;
+    const size_t off = (size_t)y * W + x;
+    float v;
+    {
+        float sc = 1.f, sh = 0.f;
+        if (a.scale) {
+            const int grp = a.per_plane ? ((n * C + c) * D + d) : (n * C + c);
+            sc = a.scale[grp];
+            sh = a.shift[grp];
+        }
+        v = fmaf(sc, a.p[((size_t)(n * C + c) * D + d) * plane + off], sh);
+    }
+    if (b.p) {
+        float sc = 1.f, sh = 0.f;
+        if (b.scale) {
+            const int grp = b.per_plane ? ((n * C + c) * D + d) : (n * C + c);
+            sc = b.scale[grp];
+            sh = b.shift[grp];
+        }
+        const size_t base = b.bcast_d ? (size_t)(n * C + c) * plane : ((size_t)(n * C + c) * D + d) * plane;
+        v += fmaf(sc, b.p[base + off], sh);
+    }
+    return v;
+}
+
+// conv: dW[oc][c][k] = sum_{n,o} dz[oc][o] * x[c][o*S - p + k]
+template <int KD, int S>
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs A) {
+    constexpr int TAPS = KD * 9;
+    const BwdGeom& G = A.G;
+    const int oc = blockIdx.x, c = blockIdx.y;
+    double acc[TAPS];  // fp64: each thread sums thousands of signed terms
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc[k] = 0.0;
+    const size_t vol_o = (size_t)G.Do * G.Ho * G.Wo;
+    for (int n = 0; n < G.N; ++n) {
+        const float* pz = A.dz + ((size_t)n * G.Cout + oc) * vol_o;
+        for (size_t o = threadIdx.x; o < vol_o; o += 256) {
+            const float dzv = pz[o];
+            const int ox = (int)(o % G.Wo);
+            const int oy = (int)((o / G.Wo) % G.Ho);
+            const int oz = (int)(o / ((size_t)G.Wo * G.Ho));
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                const int iz = KD == 1 ? oz : oz * S - 1 + kd;
+                if (iz < 0 || iz >= G.Di) continue;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int iy = oy * S - 1 + kh;
+                    if (iy < 0 || iy >= G.Hi) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int ix = ox * S - 1 + kw;
+                        if (ix < 0 || ix >= G.Wi) continue;
+                        const float xv = src_value(A.a, A.b, n, G.Cin, c, G.Di, iz, G.Hi, G.Wi, iy, ix);
+                        acc[(kd * 3 + kh) * 3 + kw] += (double)dzv * (double)xv;
+                    }
+                }
+            }
+        }
+    }
+    __shared__ double red[4][TAPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TAPS) {
+        const int k = threadIdx.x;
+        float* dst = A.dw + ((size_t)oc * G.Cin + c) * TAPS + k;
+        const float v = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        *dst = (A.accumulate ? *dst : 0.f) + v;
+    }
+}
+
+// transposed conv: dW[c][oc][k] = sum_{n,i} x[c][i] * dz[oc][s*i - 1 + k]
+template <int KD>
+__global__ __launch_bounds__(256) void deconv_bwd_weight_kernel(const BwdWArgs A) {
+    constexpr int TAPS = KD * 16;
+    constexpr int SD = KD == 4 ? 2 : 1;
+    const BwdGeom& G = A.G;
+    const int oc = blockIdx.x, c = blockIdx.y;
+    double acc[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc[k] = 0.0;
+    const size_t vol_i = (size_t)G.Di * G.Hi * G.Wi;
+    const size_t plane_o = (size_t)G.Ho * G.Wo;
+    for (int n = 0; n < G.N; ++n) {
+        for (size_t i = threadIdx.x; i < vol_i; i += 256) {
+            const int ix = (int)(i % G.Wi);
+            const int iy = (int)((i / G.Wi) % G.Hi);
+            const int iz = (int)(i / ((size_t)G.Wi * G.Hi));
+            const float xv = src_value(A.a, A.b, n, G.Cin, c, G.Di, iz, G.Hi, G.Wi, iy, ix);
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                const int oz = SD * iz - 1 + kd;
+                if (oz < 0 || oz >= G.Do) continue;
+                const float* pz = A.dz + (((size_t)n * G.Cout + oc) * G.Do + oz) * plane_o;
+#pragma unroll
+                for (int kh = 0; kh < 4; ++kh) {
+                    const int oy = 2 * iy - 1 + kh;
+                    if (oy < 0 || oy >= G.Ho) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) {
+                        const int ox = 2 * ix - 1 + kw;
+                        if (ox < 0 || ox >= G.Wo) continue;
+                        acc[(kd * 4 + kh) * 4 + kw] += (double)xv * (double)pz[(size_t)oy * G.Wo + ox];
+                    }
+                }
+            }
+        }
+    }
+    __shared__ double red[4][TAPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TAPS) {
+        const int k = threadIdx.x;
+        float* dst = A.dw + ((size_t)c * G.Cout + oc) * TAPS + k;
+        const float v = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        *dst = (A.accumulate ? *dst : 0.f) + v;
+    }
+}
+
+int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
+                      const Geom& in, const Geom& out, int accumulate, hipStream_t s) {
+    BwdWArgs A;
+    A.a = a;
+    A.b = b;
+    A.dz = dz;
+    A.dw = dw;
+    A.G = BwdGeom{in.n, in.c, in.d, in.h, in.w, out.c, out.d, out.h, out.w};
+    A.accumulate = accumulate;
+    dim3 grid(out.c, in.c);
+    if (!transposed) {
+        if (kd == 1 && stride == 1)
+            hipLaunchKernelGGL((conv_bwd_weight_kernel<1, 1>), grid, dim3(256), 0, s, A);
+        else if (kd == 3 && stride == 1)
+            hipLaunchKernelGGL((conv_bwd_weight_kernel<3, 1>), grid, dim3(256), 0, s, A);
+        else if (kd == 3 && stride == 2)
+            hipLaunchKernelGGL((conv_bwd_weight_kernel<3, 2>), grid, dim3(256), 0, s, A);
+        else
+            return set_error(-1, "bwd_weight: unsupported conv kd=%d stride=%d", kd, stride);
+    } else {
+        if (kd == 4)
+            hipLaunchKernelGGL((deconv_bwd_weight_kernel<4>), grid, dim3(256), 0, s, A);
+        else if (kd == 3)
+            hipLaunchKernelGGL((deconv_bwd_weight_kernel<3>), grid, dim3(256), 0, s, A);
+        else
+            return set_error(-1, "bwd_weight: unsupported deconv kd=%d", kd);
+    }
+    return check_launch("bwd_weight");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gradient routing: dst (+)= src ; dst[n,c,y,x] (+)= sum_d src[n,c,d,y,x] (broadcast source)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_add_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                       size_t count, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+        dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_d_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                            const Geom g, int accumulate) {
+    const size_t px = g.plane();
+    const int nc = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < px; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int d = 0; d < g.d; ++d) s += src[((size_t)nc * g.d + d) * px + i];
+        dst[(size_t)nc * px + i] = accumulate ? dst[(size_t)nc * px + i] + s : s;
+    }
+}
+
+int launch_grad_add(float* dst, const float* src, size_t count, int accumulate, hipStream_t s) {
+    unsigned bx = (unsigned)((count + 255) / 256);
+    if (bx > 16384) bx = 16384;
+    hipLaunchKernelGGL(grad_add_kernel, dim3(bx), dim3(256), 0, s, dst, src, count, accumulate);
+    return check_launch("grad_add");
+}
+
+int launch_grad_reduce_d(float* dst, const float* src, const Geom& g, int accumulate, hipStream_t s) {
+    unsigned bx = (unsigned)((g.plane() + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(grad_reduce_d_kernel, dim3(bx, g.n * g.c), dim3(256), 0, s, dst, src, g, accumulate);
+    return check_launch("grad_reduce_d");
+}
+
+// shift_concat backward (matching.py:50-61): g [d_count, B, 2C, h, w] ->
+//   dleft[b,c,y,x] = sum_d g[d,b,c,y,x];  dright[b,c,y,x'] = sum_d g[d,b,C+c,y,x'+d] (x'+d < w)
+__global__ __launch_bounds__(256) void shift_concat_bwd_kernel(const float* __restrict__ g, float* __restrict__ dleft,
+                                                               float* __restrict__ dright, int batch, int C, int h,
+                                                               int w, int d_begin, int d_count) {
+    const size_t rows = (size_t)batch * C * h;
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int y = (int)(row % h);
+        const int c = (int)((row / h) % C);
+        const int b = (int)(row / ((size_t)h * C));
+        for (int x = threadIdx.x; x < w; x += 256) {
+            float sl = 0.f, sr = 0.f;
+            for (int di = 0; di < d_count; ++di) {
+                const int d = d_begin + di;
+                const float* gl = g + ((((size_t)di * batch + b) * 2 * C + c) * h + y) * w;
+                const float* gr = g + ((((size_t)di * batch + b) * 2 * C + C + c) * h + y) * w;
+                sl += gl[x];
+                if (x + d < w) sr += gr[x + d];
+            }
+            dleft[row * w + x] = sl;
+            dright[row * w + x] = sr;
+        }
+    }
+}
+
+int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int batch, int channels, int h, int w,
+                            int d_begin, int d_count, hipStream_t s) {
+    const size_t rows = (size_t)batch * channels * h;
+    const unsigned grid = (unsigned)(rows < 65536 ? rows : 65536);
+    hipLaunchKernelGGL(shift_concat_bwd_kernel, dim3(grid), dim3(256), 0, s, g, dleft, dright, batch, channels, h, w,
+                       d_begin, d_count);
+    return check_launch("shift_concat_bwd");
+}
+
+}  // namespace pds

@@ -33,6 +33,7 @@ struct Src {
     const float* shift;
     int per_plane;       // statistics per (n, c, d) -- Matching's per-disparity InstanceNorm2d
     int bcast_d;         // tensor has no D axis and is broadcast along it (regularization.py:115)
+    int id = -1;         // host-side only: index of the tensor on the backward tape
 };
 
 inline Src plain_src(const float* p) { return Src{p, nullptr, nullptr, 0, 0}; }
@@ -125,7 +126,22 @@ int deconv_direct_tiles(const Geom& out_g);
 // `per_group` consecutive partial records of (sum, sumsq); count = elements per group.
 int launch_in_finalize(const double* partials, int groups, int per_group, double count,
                        const float* gamma, const float* beta, int channels, int groups_per_channel_block,
-                       float* scale, float* shift, hipStream_t s);
+                       float* scale, float* shift, float* mean, float* rstd, hipStream_t s);
+
+// ---- backward (backward.hip) ------------------------------------------------------------------------
+size_t in_bwd_scratch_doubles(const Geom& g);
+int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
+                  const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
+                  float* dgamma, float* dbeta, int accumulate_params, hipStream_t s);
+int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, hipStream_t s);
+int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
+                    const Geom& out, hipStream_t s);
+int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
+                      const Geom& in, const Geom& out, int accumulate, hipStream_t s);
+int launch_grad_add(float* dst, const float* src, size_t count, int accumulate, hipStream_t s);
+int launch_grad_reduce_d(float* dst, const float* src, const Geom& g, int accumulate, hipStream_t s);
+int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int batch, int channels, int h, int w,
+                            int d_begin, int d_count, hipStream_t s);
 
 // out = a (+ b), both deferred-normalised
 int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s);

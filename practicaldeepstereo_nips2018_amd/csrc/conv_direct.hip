@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int channels,
                                                           int inner, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+                                                          float* __restrict__ shift, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out) {
     const int g = blockIdx.x;
     const double* p = partials + (size_t)g * per_group * 2;
     double s = 0.0, q = 0.0;
@@ -411,14 +412,18 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
         const double sc = (double)gamma[c] * rstd;
         scale[g] = (float)sc;
         shift[g] = (float)((double)beta[c] - mean * sc);
+        if (mean_out) {  // kept for the backward pass
+            mean_out[g] = (float)mean;
+            rstd_out[g] = (float)rstd;
+        }
     }
 }
 
 int launch_in_finalize(const double* partials, int groups, int per_group, double count, const float* gamma,
-                       const float* beta, int channels, int inner, float* scale, float* shift,
-                       hipStream_t s) {
+                       const float* beta, int channels, int inner, float* scale, float* shift, float* mean,
+                       float* rstd, hipStream_t s) {
     hipLaunchKernelGGL(in_finalize_kernel, dim3(groups), dim3(256), 0, s, partials, per_group, count, gamma,
-                       beta, channels, inner, scale, shift);
+                       beta, channels, inner, scale, shift, mean, rstd);
     return check_launch("in_finalize");
 }
 

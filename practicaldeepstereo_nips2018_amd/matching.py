@@ -61,21 +61,22 @@ class MatchingOperation(nn.Module):
         (128 -> 64 in the reference: two 64-channel descriptors)."""
         return self.number_of_descriptor_features == self.number_of_features
 
-    def native_params(self):
-        """(PdsMatchingParams, keep-alive list) pointing at this module's parameters."""
+    def native_params(self, tensor_of=None):
+        """(PdsMatchingParams, keep-alive list) pointing at this module's parameters, or, with
+        ``tensor_of``, at the tensors it maps them to (gradient buffers)."""
         mods = self._matching_operation_modules
         blocks = []
         for residual in mods[1:-1]:
             for block in residual.convolutions:
-                blocks.append(_lib.conv_block_params(block.conv, block.norm))
+                blocks.append(_lib.conv_block_params(block.conv, block.norm, tensor_of))
         array = (_lib.ConvBlockParams * max(len(blocks), 1))(*blocks)
         params = _lib.MatchingParams()
         params.features = self.number_of_features
         params.signature_features = self.number_of_signature_features
         params.residual_blocks = self._number_of_residual_blocks
-        params.first = _lib.conv_block_params(mods[0])
+        params.first = _lib.conv_block_params(mods[0], None, tensor_of)
         params.blocks = ctypes.cast(array, ctypes.POINTER(_lib.ConvBlockParams))
-        params.last = _lib.conv_block_params(mods[-1])
+        params.last = _lib.conv_block_params(mods[-1], None, tensor_of)
         return params, array
 
     def forward(self, concatenated_descriptors):
@@ -88,6 +89,10 @@ class MatchingOperation(nn.Module):
 
 
 class _MatchingOperationFunction(torch.autograd.Function):
+    """pds_matching_operation_fwd / _bwd.  When a gradient is needed the forward runs in a workspace of its
+    own, kept (with the input) until backward: the backward entry point re-derives every intermediate
+    from it."""
+
     @staticmethod
     def forward(ctx, module, x, *unused_parameters):
         lib = _lib.load()
@@ -96,17 +101,73 @@ class _MatchingOperationFunction(torch.autograd.Function):
         out = torch.empty((n, module.number_of_signature_features, h, w), dtype=torch.float32,
                           device=x.device)
         nbytes = lib.pds_matching_operation_workspace_bytes(ctypes.byref(params), n, h, w)
-        ws = module._workspace.get(nbytes, x.device)
+        training = any(ctx.needs_input_grad)
+        if training:
+            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+        else:
+            ws = module._workspace.get(nbytes, x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.pds_matching_operation_fwd(
                 ctypes.byref(params), _lib.ptr(x), _lib.ptr(out), n, h, w,
                 _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)), 'pds_matching_operation_fwd')
         del keep
+        if training:
+            ctx.module = module
+            ctx.forward_workspace = ws
+            ctx.save_for_backward(x)
         return out
 
     @staticmethod
-    def backward(ctx, *grads):
-        _lib.not_differentiable('MatchingOperation')
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        module = ctx.module
+        x, = ctx.saved_tensors
+        n, _, h, w = x.shape
+        grad_out = grad_out.contiguous()
+        params, keep = module.native_params()
+        grads, tensor_of = _lib.gradient_buffers(module)
+        grad_params, keep_grads = module.native_params(tensor_of)
+        grad_x = torch.empty_like(x)
+        nbytes = lib.pds_matching_operation_bwd_workspace_bytes(ctypes.byref(params), n, h, w)
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+        fws = ctx.forward_workspace
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pds_matching_operation_bwd(
+                ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(x), _lib.ptr(grad_out),
+                _lib.ptr(grad_x), n, h, w, _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(),
+                _lib.stream_handle(x.device)), 'pds_matching_operation_bwd')
+        del keep, keep_grads
+        ctx.forward_workspace = None
+        return (None, grad_x) + tuple(grads[id(p)] for p in module.parameters())
+
+
+class _ShiftConcatFunction(torch.autograd.Function):
+    """cat([left, S_d(right)], 1) for a range of disparities (matching.py:50-61) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, left, right, begin, count):
+        lib = _lib.load()
+        batch, channels, h, w = left.shape
+        out = torch.empty((count, batch, 2 * channels, h, w), dtype=torch.float32, device=left.device)
+        with torch.cuda.device(left.device):
+            _lib.check(lib.pds_shift_concat_fwd(
+                _lib.ptr(left), _lib.ptr(right), _lib.ptr(out), batch, channels, h, w,
+                begin, count, _lib.stream_handle(left.device)), 'pds_shift_concat_fwd')
+        ctx.geometry = (batch, channels, h, w, begin, count)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        batch, channels, h, w, begin, count = ctx.geometry
+        grad_out = grad_out.contiguous()
+        grad_left = torch.empty((batch, channels, h, w), dtype=torch.float32, device=grad_out.device)
+        grad_right = torch.empty_like(grad_left)
+        with torch.cuda.device(grad_out.device):
+            _lib.check(lib.pds_shift_concat_bwd(
+                _lib.ptr(grad_out), _lib.ptr(grad_left), _lib.ptr(grad_right), batch, channels, h, w,
+                begin, count, _lib.stream_handle(grad_out.device)), 'pds_shift_concat_bwd')
+        return grad_left, grad_right, None, None
 
 
 class Matching(nn.Module):
@@ -146,21 +207,24 @@ class Matching(nn.Module):
                              (tuple(left.shape), tuple(right.shape)))
         begin, count = self._plane_range()
         operation = self._operation
+        needs_grad = torch.is_grad_enabled() and (
+            left.requires_grad or right.requires_grad or
+            (isinstance(operation, nn.Module) and any(p.requires_grad for p in operation.parameters())))
         if (isinstance(operation, MatchingOperation) and operation.supports_fused_matching()
                 and left.size(1) == operation.number_of_descriptor_features):
-            return _FusedMatchingFunction.apply(self, left, right, begin, count,
-                                                *operation.parameters())
+            if not needs_grad:
+                return _FusedMatchingFunction.apply(self, left, right, begin, count,
+                                                    *operation.parameters())
+            # Training: the differentiable route is shift/concat -> MatchingOperation over all planes at once
+            # (the statistics of InstanceNorm2d are per image, so planes may be folded into the batch).
+            batch = left.size(0)
+            concatenated = _ShiftConcatFunction.apply(left, right, begin, count)
+            folded = operation(concatenated.view(count * batch, *concatenated.shape[2:]))
+            return folded.view(count, batch, *folded.shape[1:]).permute(1, 2, 0, 3, 4).contiguous()
         return self._forward_generic(left, right, begin, count)
 
     def _forward_generic(self, left, right, begin, count):
-        lib = _lib.load()
-        batch, channels, h, w = left.shape
-        concatenated = torch.empty((count, batch, 2 * channels, h, w), dtype=torch.float32,
-                                   device=left.device)
-        with torch.cuda.device(left.device):
-            _lib.check(lib.pds_shift_concat_fwd(
-                _lib.ptr(left), _lib.ptr(right), _lib.ptr(concatenated), batch, channels, h, w,
-                begin, count, _lib.stream_handle(left.device)), 'pds_shift_concat_fwd')
+        concatenated = _ShiftConcatFunction.apply(left, right, begin, count)
         return torch.stack([self._operation(plane) for plane in concatenated.unbind(0)], dim=2)
 
 
@@ -185,4 +249,4 @@ class _FusedMatchingFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        _lib.not_differentiable('Matching')
+        _lib.not_differentiable('Matching (fused inference path)')

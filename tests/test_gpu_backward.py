@@ -1,0 +1,147 @@
+"""GPU (-m gpu): backward of the HIP modules against torch autograd through the oracle in fp64.
+
+Reference behaviour: pds_trainer.py:40-46 calls loss.backward() through network.py:38-52 in training mode,
+i.e. through Matching, MatchingOperation and Regularization (the estimator is inference-only, estimator.py:19).
+Tolerance: every gradient tensor within 2e-3 of the fp64 gradient, relative to that tensor's largest entry
+(fp32 accumulation over up to ~1e6 terms on both sides of an InstanceNorm)."""
+import pytest
+import torch
+
+from oracle import pds_oracle as oracle
+from tests import helpers
+import practicaldeepstereo_nips2018_amd as pds
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 2e-3
+
+
+@pytest.fixture(scope='module')
+def dev(hip_library):
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def relative_error(got, want):
+    want = want.double().cpu()
+    return float((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-12))
+
+
+def oracle_grads(function, tensors, params, weight, dtype=torch.float64):
+    """CPU autograd of sum(function(...) * weight) in ``dtype`` (fp64 = the reference gradient)."""
+    tensors64 = [t.detach().to(dtype).cpu().requires_grad_(True) for t in tensors]
+    params64 = {k: v.detach().to(dtype).cpu().requires_grad_(True) for k, v in params.items()}
+    out = function(params64, *tensors64)
+    (out * weight.to(dtype).cpu()).sum().backward()
+    return out.detach(), [t.grad for t in tensors64], {k: v.grad for k, v in params64.items()}
+
+
+def check_param_grads(module, prefix, want, noise_floor=None):
+    """Every parameter gradient within REL_TOL of the fp64 gradient -- or, where the fp32 CPU oracle itself is
+    further than that from fp64 (sums of millions of sign-cancelling terms amplify the fp32 noise of the
+    forward pass), within 3x the fp32 CPU oracle's own distance."""
+    errors, allowed = {}, {}
+    for name, p in module.named_parameters():
+        assert p.grad is not None, name
+        errors[name] = relative_error(p.grad.detach(), want[prefix + '.' + name])
+        floor = relative_error(noise_floor[prefix + '.' + name], want[prefix + '.' + name]) if noise_floor else 0.0
+        allowed[name] = max(REL_TOL, 3.0 * floor)
+    worst = sorted(errors.items(), key=lambda kv: -kv[1] / allowed[kv[0]])[:4]
+    print('largest parameter-gradient errors (error, allowed):', [(n, e, allowed[n]) for n, e in worst])
+    for name, err in errors.items():
+        assert err <= allowed[name], (name, err, allowed[name])
+    return worst[0][1]
+
+
+def test_shift_concat_backward(dev):
+    g = torch.Generator().manual_seed(1)
+    left = torch.randn(2, 3, 4, 9, generator=g).to(dev).requires_grad_(True)
+    right = torch.randn(2, 3, 4, 9, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(2, 1, 6, 4, 9, generator=g)
+
+    def op(x):  # differentiable mock operation
+        return (x * x).sum(1, keepdim=True) + x[:, :1]
+    out = pds.Matching(5, op)(left, right)
+    (out * w.to(dev)).sum().backward()
+    l64 = left.detach().double().cpu().requires_grad_(True)
+    r64 = right.detach().double().cpu().requires_grad_(True)
+    ref = oracle.matching(l64, r64, 5, op)
+    (ref * w.double()).sum().backward()
+    assert relative_error(out, ref.detach()) <= 1e-5
+    assert relative_error(left.grad, l64.grad) <= 1e-5
+    assert relative_error(right.grad, r64.grad) <= 1e-5
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 9, 11), (3, 16, 24)])
+def test_matching_operation_backward(dev, n, h, w):
+    op = helpers.seeded(pds.MatchingOperation, seed=3).to(dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, 128, h, w, generator=g).to(dev).requires_grad_(True)
+    weight = torch.randn(n, 8, h, w, generator=g)
+    out = op(x)
+    (out * weight.to(dev)).sum().backward()
+    params = helpers.prefixed(op.state_dict(), '_m')
+    ref, (gx,), gp = oracle_grads(lambda p, t: oracle.matching_operation(p, '_m', t), [x], params, weight)
+    assert relative_error(out, ref) <= 1e-4
+    assert relative_error(x.grad, gx) <= REL_TOL
+    print('matching operation worst parameter-gradient error', check_param_grads(op, '_m', gp))
+
+
+def test_matching_training_route_backward(dev):
+    """Matching(MatchingOperation) with gradients: shift/concat -> folded MatchingOperation (matching.py:34-63)."""
+    op = helpers.seeded(pds.MatchingOperation, seed=5).to(dev)
+    net = pds.Matching(7, op)
+    g = torch.Generator().manual_seed(6)
+    left = torch.randn(2, 64, 8, 12, generator=g).to(dev).requires_grad_(True)
+    right = torch.randn(2, 64, 8, 12, generator=g).to(dev).requires_grad_(True)
+    weight = torch.randn(2, 8, 8, 8, 12, generator=g)
+    out = net(left, right)
+    assert out.shape == (2, 8, 8, 8, 12)
+    with torch.no_grad():
+        fused = net(left, right)          # inference route (factorised first layer, MFMA)
+    assert helpers.maxdiff(out, fused) <= 2e-5
+    (out * weight.to(dev)).sum().backward()
+    params = helpers.prefixed(op.state_dict(), '_m._operation')
+    ref, (gl, gr), gp = oracle_grads(lambda p, a, b: oracle.matching_with_operation(p, '_m', a, b, 7),
+                                     [left, right], params, weight)
+    assert relative_error(out, ref) <= 1e-4
+    assert relative_error(left.grad, gl) <= REL_TOL
+    assert relative_error(right.grad, gr) <= REL_TOL
+    check_param_grads(op, '_m._operation', gp)
+
+
+def test_regularization_backward(dev):
+    reg = helpers.seeded(pds.Regularization, seed=7).to(dev)
+    g = torch.Generator().manual_seed(8)
+    ms = torch.randn(1, 8, 16, 32, 48, generator=g).to(dev).requires_grad_(True)
+    shortcut = torch.randn(1, 8, 32, 48, generator=g).to(dev).requires_grad_(True)
+    weight = torch.randn(1, 32, 128, 192, generator=g)
+    cost = reg(ms, shortcut)
+    (cost * weight.to(dev)).sum().backward()
+    params = helpers.prefixed(reg.state_dict(), '_r')
+    fn = lambda p, a, b: oracle.regularization(p, '_r', a, b)  # noqa: E731
+    ref, (gms, gsc), gp = oracle_grads(fn, [ms, shortcut], params, weight)
+    _, _, gp32 = oracle_grads(fn, [ms, shortcut], params, weight, dtype=torch.float32)
+    assert relative_error(cost, ref) <= 1e-4
+    assert relative_error(ms.grad, gms) <= REL_TOL
+    assert relative_error(shortcut.grad, gsc) <= REL_TOL
+    print('regularization worst parameter-gradient error', check_param_grads(reg, '_r', gp, gp32))
+
+
+def test_network_training_step(dev):
+    """config 5 in miniature: train-mode PdsNetwork -> cost volume -> a loss -> backward -> every parameter has a
+    finite gradient, and an SGD step changes the loss."""
+    net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).to(dev).train()
+    left, right = helpers.images(1, 128, 192)
+    left, right = left.to(dev), right.to(dev)
+    target = torch.randint(0, 32, (1, 128, 192), generator=torch.Generator().manual_seed(2)).to(dev)
+    cost = net(left, right)
+    assert cost.shape == (1, 32, 128, 192)
+    loss = torch.nn.functional.cross_entropy(cost, target)
+    loss.backward()
+    for name, p in net.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+    with torch.no_grad():
+        for p in net.parameters():
+            p -= 1e-3 * p.grad
+    loss2 = torch.nn.functional.cross_entropy(net(left, right), target)
+    assert float(loss2) < float(loss)
