@@ -152,24 +152,45 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
 // ---------------------------------------------------------------------------------------------------
 // bias gradient: db[c] (+)= sum over n, d, y, x of dz
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dz, const Geom geom,
-                                                          float* __restrict__ db, int accumulate) {
-    const int c = blockIdx.x;
+// two-stage: grid (C, splits) partial sums over a strided share of the positions, then one reduce
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ dz, const Geom geom,
+                                                                  double* __restrict__ partial) {
+    const int c = blockIdx.x, split = blockIdx.y, splits = gridDim.y;
     const size_t vol = geom.volume();
     double s = 0.0;
     for (int n = 0; n < geom.n; ++n) {
         const float* p = dz + ((size_t)n * geom.c + c) * vol;
-        for (size_t i = threadIdx.x; i < vol; i += 256) s += p[i];
+        for (size_t i = (size_t)split * 256 + threadIdx.x; i < vol; i += (size_t)splits * 256) s += p[i];
     }
     __shared__ double red[4];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[(size_t)split * geom.c + c] = red[0] + red[1] + red[2] + red[3];
 }
 
-int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(g.c), dim3(256), 0, s, dz, g, db, accumulate);
+__global__ __launch_bounds__(64) void channel_sum_reduce_kernel(const double* __restrict__ partial, int channels,
+                                                                int splits, float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < splits; i += 64) s += partial[(size_t)i * channels + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)s;
+}
+
+int channel_sum_splits(const Geom& g) {
+    const size_t work = g.volume() / 4096;
+    int splits = (int)(work < 1 ? 1 : work);
+    const int cap = 2048 / (g.c < 1 ? 1 : g.c);
+    if (splits > cap) splits = cap;
+    return splits < 1 ? 1 : splits;
+}
+
+// scratch: channel_sum_splits(g) * C doubles
+int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s) {
+    const int splits = channel_sum_splits(g);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(g.c, splits), dim3(256), 0, s, dz, g, scratch);
+    hipLaunchKernelGGL(channel_sum_reduce_kernel, dim3(g.c), dim3(64), 0, s, scratch, g.c, splits, db, accumulate);
     return check_launch("channel_sum");
 }
 
@@ -314,9 +335,8 @@ int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const f
 struct BwdWArgs {
     Src a, b;      // the layer's input (deferred-normalised sources, as in the forward)
     const float* __restrict__ dz;
-    float* __restrict__ dw;
+    double* __restrict__ partial;  // [split][weight element]
     BwdGeom G;
-    int accumulate;
 };
 
 __device__ __forceinline__ float src_value(const Src& a, const Src& b, int n, int C, int c, int D, int d, int H,
@@ -359,7 +379,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs A) 
     const size_t vol_o = (size_t)G.Do * G.Ho * G.Wo;
     for (int n = 0; n < G.N; ++n) {
         const float* pz = A.dz + ((size_t)n * G.Cout + oc) * vol_o;
-        for (size_t o = threadIdx.x; o < vol_o; o += 256) {
+        for (size_t o = (size_t)blockIdx.z * 256 + threadIdx.x; o < vol_o; o += (size_t)gridDim.z * 256) {
             const float dzv = pz[o];
             const int ox = (int)(o % G.Wo);
             const int oy = (int)((o / G.Wo) % G.Ho);
@@ -393,9 +413,9 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs A) 
     __syncthreads();
     if (threadIdx.x < TAPS) {
         const int k = threadIdx.x;
-        float* dst = A.dw + ((size_t)oc * G.Cin + c) * TAPS + k;
-        const float v = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
-        *dst = (A.accumulate ? *dst : 0.f) + v;
+        const size_t wcount = (size_t)G.Cout * G.Cin * TAPS;
+        A.partial[(size_t)blockIdx.z * wcount + ((size_t)oc * G.Cin + c) * TAPS + k] =
+            red[0][k] + red[1][k] + red[2][k] + red[3][k];
     }
 }
 
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(256) void deconv_bwd_weight_kernel(const BwdWArgs A
     const size_t vol_i = (size_t)G.Di * G.Hi * G.Wi;
     const size_t plane_o = (size_t)G.Ho * G.Wo;
     for (int n = 0; n < G.N; ++n) {
-        for (size_t i = threadIdx.x; i < vol_i; i += 256) {
+        for (size_t i = (size_t)blockIdx.z * 256 + threadIdx.x; i < vol_i; i += (size_t)gridDim.z * 256) {
             const int ix = (int)(i % G.Wi);
             const int iy = (int)((i / G.Wi) % G.Hi);
             const int iz = (int)(i / ((size_t)G.Wi * G.Hi));
@@ -446,22 +466,47 @@ __global__ __launch_bounds__(256) void deconv_bwd_weight_kernel(const BwdWArgs A
     __syncthreads();
     if (threadIdx.x < TAPS) {
         const int k = threadIdx.x;
-        float* dst = A.dw + ((size_t)c * G.Cout + oc) * TAPS + k;
-        const float v = (float)(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
-        *dst = (A.accumulate ? *dst : 0.f) + v;
+        const size_t wcount = (size_t)G.Cout * G.Cin * TAPS;
+        A.partial[(size_t)blockIdx.z * wcount + ((size_t)c * G.Cout + oc) * TAPS + k] =
+            red[0][k] + red[1][k] + red[2][k] + red[3][k];
     }
 }
 
+__global__ __launch_bounds__(256) void weight_reduce_kernel(const double* __restrict__ partial, size_t wcount,
+                                                            int splits, float* __restrict__ dw, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < wcount; i += (size_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * wcount + i];
+        dw[i] = (accumulate ? dw[i] : 0.f) + (float)s;
+    }
+}
+
+static int weight_taps(int transposed, int kd) { return transposed ? kd * 16 : kd * 9; }
+
+// position splits: enough workgroups to fill the chip when Cout * Cin is small
+int bwd_weight_splits(int transposed, const Geom& in, const Geom& out) {
+    const size_t positions = transposed ? in.volume() : out.volume();
+    size_t splits = positions / 8192;
+    const size_t cap = 4096 / ((size_t)in.c * out.c < 1 ? 1 : (size_t)in.c * out.c);
+    if (splits > cap) splits = cap;
+    if (splits > 512) splits = 512;
+    return splits < 1 ? 1 : (int)splits;
+}
+
+size_t bwd_weight_scratch_doubles(int transposed, int kd, const Geom& in, const Geom& out) {
+    return (size_t)bwd_weight_splits(transposed, in, out) * in.c * out.c * weight_taps(transposed, kd);
+}
+
 int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
-                      const Geom& in, const Geom& out, int accumulate, hipStream_t s) {
+                      const Geom& in, const Geom& out, int accumulate, double* scratch, hipStream_t s) {
     BwdWArgs A;
     A.a = a;
     A.b = b;
     A.dz = dz;
-    A.dw = dw;
+    A.partial = scratch;
     A.G = BwdGeom{in.n, in.c, in.d, in.h, in.w, out.c, out.d, out.h, out.w};
-    A.accumulate = accumulate;
-    dim3 grid(out.c, in.c);
+    const int splits = bwd_weight_splits(transposed, in, out);
+    dim3 grid(out.c, in.c, splits);
     if (!transposed) {
         if (kd == 1 && stride == 1)
             hipLaunchKernelGGL((conv_bwd_weight_kernel<1, 1>), grid, dim3(256), 0, s, A);
@@ -479,6 +524,10 @@ int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Sr
         else
             return set_error(-1, "bwd_weight: unsupported deconv kd=%d", kd);
     }
+    const size_t wcount = (size_t)in.c * out.c * weight_taps(transposed, kd);
+    unsigned bx = (unsigned)((wcount + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(weight_reduce_kernel, dim3(bx), dim3(256), 0, s, scratch, wcount, splits, dw, accumulate);
     return check_launch("bwd_weight");
 }
 

@@ -133,11 +133,13 @@ size_t in_bwd_scratch_doubles(const Geom& g);
 int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
                   const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
                   float* dgamma, float* dbeta, int accumulate_params, hipStream_t s);
-int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, hipStream_t s);
+int channel_sum_splits(const Geom& g);
+int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s);
 int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
                     const Geom& out, hipStream_t s);
+size_t bwd_weight_scratch_doubles(int transposed, int kd, const Geom& in, const Geom& out);
 int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
-                      const Geom& in, const Geom& out, int accumulate, hipStream_t s);
+                      const Geom& in, const Geom& out, int accumulate, double* scratch, hipStream_t s);
 int launch_grad_add(float* dst, const float* src, size_t count, int accumulate, hipStream_t s);
 int launch_grad_reduce_d(float* dst, const float* src, const Geom& g, int accumulate, hipStream_t s);
 int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int batch, int channels, int h, int w,
