@@ -191,6 +191,22 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
 int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_right, int batch, int channels,
                          int h, int w, int d_begin, int d_count, pds_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * SubpixelCrossEntropy.forward and its gradient      reference loss.py:16-78
+ * similarities [n, planes, h, w]; ground_truth [n, h, w] (inf = unknown); weights [n, h, w] or NULL.
+ * fwd writes loss[1], lse[n*h*w] (log-sum-exp per pixel, kept for bwd) and stats[2] = {sum w*entropy,
+ * denominator}; bwd writes d loss / d similarities scaled by the device scalar grad_loss[1].
+ * ---------------------------------------------------------------------------------- */
+size_t pds_subpixel_cross_entropy_workspace_bytes(int n, int h, int w);
+int pds_subpixel_cross_entropy_fwd(const float* similarities, const float* ground_truth, const float* weights,
+                                   float* loss, float* lse, float* stats, int n, int planes, int h, int w,
+                                   float diversity, int disparity_step, void* workspace, size_t workspace_bytes,
+                                   pds_stream_t stream);
+int pds_subpixel_cross_entropy_bwd(const float* similarities, const float* ground_truth, const float* weights,
+                                   const float* lse, const float* stats, const float* grad_loss,
+                                   float* grad_similarities, int n, int planes, int h, int w, float diversity,
+                                   int disparity_step, pds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

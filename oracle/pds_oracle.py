@@ -13,6 +13,7 @@ reference's arithmetic for
                                            reference practical_deep_stereo/regularization.py:11-126
   * ``SubpixelMap``                        reference practical_deep_stereo/estimator.py:10-91
   * the layer factories those use          reference practical_deep_stereo/network_blocks.py:19-144
+  * ``SubpixelCrossEntropy``               reference practical_deep_stereo/loss.py:16-78 (consumer in training)
 
 Parity pinning: ``tests/golden/make_golden.py`` (run in the build container,
 where /root/reference is importable) checks every function below against the
@@ -182,6 +183,30 @@ def subpixel_map(similarities, half_support_window=4, disparity_step=2):
     values = torch.stack(values, dim=1)
     prob = torch.softmax(taps, dim=1)
     return (prob * values).sum(1).squeeze(1)
+
+
+# --------------------------------------------------------------------------------------
+# loss.py (consumer of the path in training)
+# --------------------------------------------------------------------------------------
+def subpixel_cross_entropy(similarities, ground_truth_disparities, weights=None, diversity=1.0,
+                           disparity_step=2):
+    """SubpixelCrossEntropy.forward, loss.py:30-78, restated without the Python loop over planes:
+    cross-entropy between softmax(similarities) and the unnormalised Laplace distribution
+    exp(-|gt - k*step| / diversity) / (2*diversity) centred at the ground truth, normalised by the
+    target's mass, averaged over the pixels whose ground truth is not inf (optionally weighted)."""
+    planes = similarities.shape[1]
+    known = ground_truth_disparities != float('inf')
+    log_p = F.log_softmax(similarities, dim=1)
+    levels = (torch.arange(planes, dtype=similarities.dtype, device=similarities.device)
+              * disparity_step).view(1, planes, 1, 1)
+    target = torch.exp(-torch.abs(ground_truth_disparities.unsqueeze(1) - levels) / diversity) / (2 * diversity)
+    sum_target = target.sum(1)
+    sum_target_log_p = (log_p * target).sum(1)
+    entropy = -sum_target_log_p[known] / sum_target[known]
+    if weights is not None:
+        w = weights[known]
+        return (w * entropy).sum() / (w.sum() + 1e-15)
+    return entropy.mean()
 
 
 # --------------------------------------------------------------------------------------

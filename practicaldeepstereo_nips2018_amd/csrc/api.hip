@@ -951,6 +951,34 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
                               fwd_workspace, workspace, (hipStream_t)stream);
 }
 
+size_t pds_subpixel_cross_entropy_workspace_bytes(int n, int h, int w) {
+    return sce_partial_doubles((size_t)n * h * w) * sizeof(double) + 256;
+}
+
+int pds_subpixel_cross_entropy_fwd(const float* similarities, const float* ground_truth, const float* weights,
+                                   float* loss, float* lse, float* stats, int n, int planes, int h, int w,
+                                   float diversity, int disparity_step, void* workspace, size_t workspace_bytes,
+                                   pds_stream_t stream) {
+    PDS_REQUIRE(similarities && ground_truth && loss && lse && stats && workspace, "subpixel_cross_entropy: null pointer");
+    PDS_REQUIRE(n > 0 && planes > 0 && h > 0 && w > 0, "subpixel_cross_entropy: bad shape");
+    PDS_REQUIRE(diversity > 0.f && disparity_step >= 1, "subpixel_cross_entropy: bad diversity / step");
+    PDS_REQUIRE(workspace_bytes >= pds_subpixel_cross_entropy_workspace_bytes(n, h, w),
+                "subpixel_cross_entropy: workspace too small");
+    return launch_sce_fwd(similarities, ground_truth, weights, loss, lse, stats, (double*)workspace, n, planes, h, w,
+                          diversity, disparity_step, (hipStream_t)stream);
+}
+
+int pds_subpixel_cross_entropy_bwd(const float* similarities, const float* ground_truth, const float* weights,
+                                   const float* lse, const float* stats, const float* grad_loss,
+                                   float* grad_similarities, int n, int planes, int h, int w, float diversity,
+                                   int disparity_step, pds_stream_t stream) {
+    PDS_REQUIRE(similarities && ground_truth && lse && stats && grad_loss && grad_similarities,
+                "subpixel_cross_entropy_bwd: null pointer");
+    PDS_REQUIRE(n > 0 && planes > 0 && h > 0 && w > 0, "subpixel_cross_entropy_bwd: bad shape");
+    return launch_sce_bwd(similarities, ground_truth, weights, lse, stats, grad_loss, grad_similarities, n, planes, h,
+                          w, diversity, disparity_step, (hipStream_t)stream);
+}
+
 int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_right, int batch, int channels, int h,
                          int w, int d_begin, int d_count, pds_stream_t stream) {
     PDS_REQUIRE(grad_out && grad_left && grad_right, "shift_concat_bwd: null pointer");

@@ -170,6 +170,14 @@ int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_
 int launch_split_first_weights(const float* w0, const float* b0, float* wl, float* wr, float* wr2, float* bias3,
                                int cout, int cin_half, hipStream_t s);
 
+// ---- loss (loss.hip) --------------------------------------------------------------------------------
+size_t sce_partial_doubles(size_t total_px);
+int launch_sce_fwd(const float* sim, const float* gt, const float* weights, float* loss, float* lse, float* stats,
+                   double* partials, int n, int planes, int h, int w, float diversity, int step, hipStream_t s);
+int launch_sce_bwd(const float* sim, const float* gt, const float* weights, const float* lse, const float* stats,
+                   const float* grad_loss, float* gsim, int n, int planes, int h, int w, float diversity, int step,
+                   hipStream_t s);
+
 // ---- wave helpers ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

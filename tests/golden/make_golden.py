@@ -187,6 +187,42 @@ def g5_subpixel_map():
     REPORT['g5_subpixel_map'] = {'oracle_vs_reference_max': worst}
 
 
+def g8_loss():
+    """SubpixelCrossEntropy: the reference's own known answer (test/test_loss.py:12-37: 1.3654 and the gradient
+    table) and a seeded random case with an inf band, value + gradient."""
+    from practical_deep_stereo import loss as ref_loss
+    sim = torch.tensor([[0.1, 0.3, 0.2, 0.05], [0.2, 0.1, 0.4, 0.0], [0.2, 0.1, 0.4, 0.0]])
+    sim = sim.t().contiguous().view(1, 4, 3, 1).requires_grad_(True)
+    gt = torch.tensor([[1.3], [float('inf')], [1.9]]).view(1, 3, 1)
+    w = torch.tensor([[0.9], [0.0], [0.01]]).view(1, 3, 1)
+    value = ref_loss.SubpixelCrossEntropy(diversity=2.0, disparity_step=1)(sim, gt, w)
+    value.backward()
+    assert abs(value.item() - 1.3654) < 1e-3
+    sim_o = sim.detach().clone().requires_grad_(True)
+    value_o = oracle.subpixel_cross_entropy(sim_o, gt, w, 2.0, 1)
+    value_o.backward()
+    assert abs(value_o.item() - value.item()) < 1e-6 and maxdiff(sim_o.grad, sim.grad) < 1e-7
+    g = torch.Generator().manual_seed(21)
+    sim2 = (torch.randn(2, 32, 9, 13, generator=g) * 0.6).requires_grad_(True)
+    gt2 = torch.rand(2, 9, 13, generator=g) * 62
+    gt2[:, 2:4, :] = float('inf')
+    w2 = torch.rand(2, 9, 13, generator=g)
+    out = {}
+    for name, weights in (('plain', None), ('weighted', w2)):
+        s_ref = sim2.detach().clone().requires_grad_(True)
+        v = ref_loss.SubpixelCrossEntropy()(s_ref, gt2, weights)
+        v.backward()
+        s_or = sim2.detach().clone().requires_grad_(True)
+        vo = oracle.subpixel_cross_entropy(s_or, gt2, weights)
+        vo.backward()
+        assert abs(v.item() - vo.item()) < 1e-5 and maxdiff(s_ref.grad, s_or.grad) < 1e-7, name
+        out['random_' + name + '_value'] = v.detach()
+        out['random_' + name + '_grad'] = s_ref.grad
+    save('g8_loss', ref_sim=sim.detach(), ref_gt=gt, ref_weights=w, ref_value=value.detach(), ref_grad=sim.grad,
+         random_sim=sim2.detach(), random_gt=gt2, random_weights=w2, **out)
+    REPORT['g8_loss'] = {'reference_value': value.item()}
+
+
 def images(batch, height, width):
     g = torch.Generator().manual_seed(1)
     left = torch.rand(batch, 3, height, width, generator=g) * 255
@@ -256,6 +292,7 @@ if __name__ == '__main__':
     g4_blocks()
     g5_subpixel_map()
     g6_config1_network()
+    g8_loss()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
     REPORT['torch'] = torch.__version__

@@ -145,3 +145,46 @@ def test_network_training_step(dev):
             p -= 1e-3 * p.grad
     loss2 = torch.nn.functional.cross_entropy(net(left, right), target)
     assert float(loss2) < float(loss)
+
+
+def test_subpixel_cross_entropy_known_answer(dev):
+    """reference test/test_loss.py:12-37: value 1.3654 and the gradient table, atol 1e-3."""
+    g = helpers.golden('g8_loss')
+    sim = g['ref_sim'].to(dev).requires_grad_(True)
+    criterion = pds.SubpixelCrossEntropy(diversity=2.0, disparity_step=1)
+    value = criterion(sim, g['ref_gt'].to(dev), g['ref_weights'].to(dev))
+    value.backward()
+    assert abs(value.item() - 1.3654) < 1e-3
+    assert abs(value.item() - g['ref_value'].item()) < 1e-5
+    assert helpers.maxdiff(sim.grad, g['ref_grad']) <= 1e-6
+
+
+@pytest.mark.parametrize('weighted', [False, True])
+def test_subpixel_cross_entropy_random(dev, weighted):
+    g = helpers.golden('g8_loss')
+    name = 'weighted' if weighted else 'plain'
+    sim = g['random_sim'].to(dev).requires_grad_(True)
+    w = g['random_weights'].to(dev) if weighted else None
+    value = pds.SubpixelCrossEntropy()(sim, g['random_gt'].to(dev), w)
+    (3.0 * value).backward()
+    assert abs(value.item() - g['random_%s_value' % name].item()) < 1e-5
+    assert helpers.maxdiff(sim.grad, 3.0 * g['random_%s_grad' % name]) <= 1e-6
+
+
+def test_training_step_with_subpixel_cross_entropy(dev):
+    """config 5 in miniature with the reference's criterion: PdsNetwork (train) -> SubpixelCrossEntropy -> backward,
+    compared with the fp64 oracle for the loss value and the gradient reaching the cost volume."""
+    net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).to(dev).train()
+    left, right = helpers.images(1, 128, 192)
+    gt = torch.rand(1, 128, 192, generator=torch.Generator().manual_seed(5)) * 60
+    gt[:, :8] = float('inf')
+    cost = net(left.to(dev), right.to(dev))
+    cost.retain_grad()
+    loss = pds.SubpixelCrossEntropy()(cost, gt.to(dev))
+    loss.backward()
+    c64 = cost.detach().double().cpu().requires_grad_(True)
+    ref = oracle.subpixel_cross_entropy(c64, gt.double())
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert relative_error(cost.grad, c64.grad) <= 1e-4
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())

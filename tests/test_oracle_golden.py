@@ -113,3 +113,22 @@ def test_config1_full_network_golden():
     assert helpers.maxdiff(cost[:, ::4, ::8, ::8], g['cost_sub']) <= 1e-4
     rep = helpers.disparity_report(disparity, g['disparity'])
     assert rep['mae'] <= 1e-3, rep
+
+
+def test_subpixel_cross_entropy_golden():
+    """reference test/test_loss.py:12-37 (1.3654 + gradient table) and a seeded case with an inf band."""
+    g = helpers.golden('g8_loss')
+    sim = g['ref_sim'].clone().requires_grad_(True)
+    value = oracle.subpixel_cross_entropy(sim, g['ref_gt'], g['ref_weights'], diversity=2.0, disparity_step=1)
+    value.backward()
+    assert abs(value.item() - 1.3654) < 1e-3
+    expected = torch.tensor([[0.0262, -0.0567, -0.0219, 0.0524], [0.0, 0.0, 0.0, 0.0],
+                             [0.0011, -0.0002, -0.0007, -0.0002]]).t().reshape(1, 4, 3, 1)
+    assert torch.allclose(sim.grad, expected, atol=1e-3)
+    assert helpers.maxdiff(sim.grad, g['ref_grad']) <= 1e-7
+    for name, weights in (('plain', None), ('weighted', g['random_weights'])):
+        s2 = g['random_sim'].clone().requires_grad_(True)
+        v = oracle.subpixel_cross_entropy(s2, g['random_gt'], weights)
+        v.backward()
+        assert abs(v.item() - g['random_%s_value' % name].item()) < 1e-5
+        assert helpers.maxdiff(s2.grad, g['random_%s_grad' % name]) <= 1e-7
