@@ -429,7 +429,37 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         conv_block(c, none, none, g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr, &l0);
         return;
     }
-    DT t1 = conv_block(c, none, none, g, P.blocks[0], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &l0);
+    // Layer 1 factorised like layer 0 (misc.hip): B = conv1(A) + b1, H / Ha / Hb / H0 = conv1 of the G rows, as one
+    // 5-plane launch with tap-masked weight sets; then LeakyReLU(B + shift_d(H)) + statistics in one streaming pass.
+    DT t1;
+    {
+        const size_t wn4 = (size_t)kL1Planes * F * 2 * F * 9;
+        float* w4 = c.get<float>(wn4);
+        float* bias4 = c.get<float>(kL1Planes * F);
+        const Geom g4{batch, 2 * F, kL1Planes, h, w + 2};
+        float* x4 = c.get<float>(g4.numel());
+        if (c.before_packing()) c.run(launch_l1_weights(P.blocks[0].weight, P.blocks[0].bias, w4, bias4, F, F, c.s));
+        if (!c.plan) c.run(launch_l1_stack_inputs(y3, x4, batch, F, h, w, c.s));
+        PdsConvBlockParams p4{w4, bias4, nullptr, nullptr};
+        ConvExtra e4;
+        e4.plane_weight_sets = kL1Planes;
+        DT y4 = conv_block(c, plain_src(x4), none, g4, p4, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e4);
+        t1.g = g;
+        t1.per_plane = 1;
+        t1.raw = c.get<float>(g.numel());
+        const int tiles = l1_combine_tiles(h, w);
+        double* partials = c.get<double>((size_t)batch * F * d_count * tiles * 2);
+        const int groups = batch * F * d_count;
+        t1.scale = c.get<float>(groups);
+        t1.shift = c.get<float>(groups);
+        t1.mean = c.get<float>(groups);
+        t1.rstd = c.get<float>(groups);
+        if (!c.plan) {
+            c.run(launch_l1_combine(y4.raw, t1.raw, partials, batch, F, h, w, d_begin, d_count, c.s));
+            c.run(launch_in_finalize(partials, groups, tiles, (double)h * w, P.blocks[0].gamma, P.blocks[0].beta, F,
+                                     d_count, t1.scale, t1.shift, t1.mean, t1.rstd, c.s));
+        }
+    }
     DT t2 = conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1);
     if (P.residual_blocks == 1) {
         conv_block(c, t2.src(), none, g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr,

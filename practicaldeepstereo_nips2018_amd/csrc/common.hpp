@@ -165,6 +165,14 @@ int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cs
 int launch_l0_stack_inputs(const float* left, const float* right, float* out, size_t bc_count, int h, int w,
                            hipStream_t s);
 
+// layer-1 factorisation (misc.hip): planes B, H, Ha, Hb, H0
+constexpr int kL1Planes = 5;
+int launch_l1_stack_inputs(const float* y3, float* x4, int batch, int channels, int h, int w, hipStream_t s);
+int launch_l1_weights(const float* w1, const float* b1, float* w4, float* bias4, int cout, int channels, hipStream_t s);
+int l1_combine_tiles(int h, int w);
+int launch_l1_combine(const float* y4, float* t1, double* partials, int batch, int channels, int h, int w,
+                      int d_begin, int d_count, hipStream_t s);
+
 // small utility: zero-pad one column on the left ([.., w] -> [.., w+1]); split conv0 weights
 int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_t s);
 int launch_split_first_weights(const float* w0, const float* b0, float* wl, float* wr, float* wr2, float* bias3,

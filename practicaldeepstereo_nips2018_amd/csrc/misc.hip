@@ -157,4 +157,149 @@ int launch_split_first_weights(const float* w0, const float* b0, float* wl, floa
     return check_launch("split_first_weights");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Layer 1 factorisation.  The first residual block starts with a convolution and layer 0 has no activation
+// (reference matching.py:80-88, network_blocks.py:139-141), so with x0[d] = A + Gs_d (A = conv_L(left) + b0,
+// Gs_d[x] = G[x-d] for x-d >= -1, G2[x-d] at x = w-1 when d >= 1, else 0):
+//   conv1(x0[d])[x] = B[x] + T_d[x],   B = conv1(A) + b1 (zero padded),
+//   T_d[x] = sum_dx [x+dx <= w-1] W1[dx] * Gs_d[x+dx]
+//          = H [u]   (u = x-d)  in general: plain conv of the G row on u in [-2, w-1] (zero beyond both ends)
+//          = Ha[u]   at x = w-2, d >= 1:  taps dx=-1,0 on G, tap dx=+1 on G2   (x+1 = w-1 is the fixed-up column)
+//          = Hb[u]   at x = w-1, d >= 1:  tap dx=-1 on G, tap dx=0 on G2, tap dx=+1 is padding
+//          = 0       for u < -2,
+//   and for d = 0 (no shift: x+dx = -1 is image padding although G[-1] exists):  T_0[x] = H0[x], the conv of G with
+//   its u = -1 entry zeroed.
+// Five single-plane 128 -> 64 convolutions (inputs [A;0], [G;0], [G;G2], [G;G2], [G0;0] with tap-masked weight
+// sets) run as ONE 5-plane launch of conv2d_mfma; l1_combine then forms LeakyReLU(B + T_d) for every disparity plane and the
+// InstanceNorm partial sums -- a 122-GFLOP convolution becomes a 425 MB streaming write.
+// Column layout of the 4-plane tensors: width w + 2, column = x + 2 for A / B and u + 2 for G / H rows.
+// ---------------------------------------------------------------------------------------------------
+// y3 [bc][3][h][w+1] (A at column x+1, G/G2 at column u+1) -> x4 [b][2C][5][h][w+2]
+__global__ __launch_bounds__(256) void l1_stack_inputs_kernel(const float* __restrict__ y3, float* __restrict__ x4,
+                                                              int batch, int C, int h, int w) {
+    const int W2 = w + 2;
+    const size_t total = (size_t)batch * 2 * C * kL1Planes * h * W2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int col = (int)(i % W2);
+        size_t r = i / W2;
+        const int y = (int)(r % h);
+        r /= h;
+        const int p = (int)(r % kL1Planes);
+        r /= kL1Planes;
+        const int c2 = (int)(r % (2 * C));
+        const int b = (int)(r / (2 * C));
+        float v = 0.f;
+        const int c = c2 < C ? c2 : c2 - C;
+        const float* src = y3 + (((size_t)b * C + c) * 3) * h * (w + 1) + (size_t)y * (w + 1);
+        if (c2 < C) {
+            if (p == 0) {
+                if (col >= 2) v = src[col - 1];                                   // A[x], x = col - 2, stored at x + 1
+            } else if (col >= (p == 4 ? 2 : 1)) {                                 // plane 4: G0 = G without u = -1
+                v = src[(size_t)h * (w + 1) + col - 1];                           // G[u], u = col - 2, stored at u + 1
+            }
+        } else if ((p == 2 || p == 3) && col >= 1) {
+            v = src[(size_t)2 * h * (w + 1) + col - 1];                           // G2[u]
+        }
+        x4[i] = v;
+    }
+}
+
+// weight sets [5][Cout][2C][3][3] and bias sets [5][Cout] from W1 [Cout][C][3][3], b1
+__global__ __launch_bounds__(256) void l1_weights_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         float* __restrict__ w4, float* __restrict__ bias4, int cout,
+                                                         int C) {
+    const int total = kL1Planes * cout * 2 * C * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < kL1Planes * cout; i += gridDim.x * 256)
+        bias4[i] = i < cout ? b1[i] : 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int t = i % 9;
+        const int c2 = (i / 9) % (2 * C);
+        const int o = (i / (9 * 2 * C)) % cout;
+        const int set = i / (9 * 2 * C * cout);
+        const int dx = t % 3;  // 0,1,2 <-> -1,0,+1
+        const bool second = c2 >= C;
+        const float wv = w1[((size_t)o * C + (second ? c2 - C : c2)) * 9 + t];
+        bool keep;
+        if (set <= 1 || set == 4) keep = !second;                   // [A;0], [G;0] and [G0;0]
+        else if (set == 2) keep = second ? dx == 2 : dx != 2;       // Ha: -1,0 on G ; +1 on G2
+        else keep = second ? dx == 1 : dx == 0;                     // Hb: -1 on G ; 0 on G2 ; +1 dropped
+        w4[i] = keep ? wv : 0.f;
+    }
+}
+
+// t1[n,o,d,y,x] = LeakyReLU(B + T_d) and partial sums (records [(n*C+o)*D + d][tile] x {sum, sumsq})
+__global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict__ y4, float* __restrict__ t1,
+                                                         double* __restrict__ partials, int C, int h, int w,
+                                                         int d_begin, int d_count) {
+    // grid: x = tile, y = local disparity, z = n*C + o ; y4 [n][C][5][h][w+2]
+    const int nc = blockIdx.z, dl = blockIdx.y, tile = blockIdx.x, tiles = gridDim.x;
+    const int d = d_begin + dl;
+    const int W2 = w + 2;
+    const size_t px = (size_t)h * w;
+    const float* Bp = y4 + (size_t)nc * kL1Planes * h * W2;
+    const float* Hp = Bp + (size_t)h * W2;
+    const float* Ha = Hp + (size_t)h * W2;
+    const float* Hb = Ha + (size_t)h * W2;
+    const float* H0 = Hb + (size_t)h * W2;
+    float* dst = t1 + ((size_t)nc * d_count + dl) * px;
+    float s = 0.f, q = 0.f;
+    for (size_t i = (size_t)tile * 256 + threadIdx.x; i < px; i += (size_t)tiles * 256) {
+        const int y = (int)(i / w), x = (int)(i % w);
+        const int u = x - d;
+        const size_t row = (size_t)y * W2;
+        float v = Bp[row + x + 2];
+        if (d == 0) {
+            v += H0[row + x + 2];
+        } else if (u >= -2) {
+            const float* sel = (x == w - 2) ? Ha : ((x == w - 1) ? Hb : Hp);
+            v += sel[row + u + 2];
+        }
+        v = v > 0.f ? v : v * kLeakySlope;
+        dst[i] = v;
+        s += v;
+        q = fmaf(v, v, q);
+    }
+    __shared__ double red[4][2];
+    const double ds = wave_sum((double)s), dq = wave_sum((double)q);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = ds;
+        red[wave][1] = dq;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        partials[((((size_t)nc * d_count + dl) * tiles) + tile) * 2 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+}
+
+int launch_l1_stack_inputs(const float* y3, float* x4, int batch, int channels, int h, int w, hipStream_t s) {
+    const size_t total = (size_t)batch * 2 * channels * kL1Planes * h * (w + 2);
+    unsigned bx = (unsigned)((total + 255) / 256);
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(l1_stack_inputs_kernel, dim3(bx), dim3(256), 0, s, y3, x4, batch, channels, h, w);
+    return check_launch("l1_stack_inputs");
+}
+
+int launch_l1_weights(const float* w1, const float* b1, float* w4, float* bias4, int cout, int channels,
+                      hipStream_t s) {
+    const int total = kL1Planes * cout * 2 * channels * 9;
+    hipLaunchKernelGGL(l1_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w1, b1, w4, bias4, cout,
+                       channels);
+    return check_launch("l1_weights");
+}
+
+int l1_combine_tiles(int h, int w) {
+    const size_t px = (size_t)h * w;
+    int t = (int)((px + 2047) / 2048);
+    return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+
+int launch_l1_combine(const float* y4, float* t1, double* partials, int batch, int channels, int h, int w,
+                      int d_begin, int d_count, hipStream_t s) {
+    hipLaunchKernelGGL(l1_combine_kernel, dim3(l1_combine_tiles(h, w), d_count, batch * channels), dim3(256), 0, s, y4,
+                       t1, partials, channels, h, w, d_begin, d_count);
+    return check_launch("l1_combine");
+}
+
 }  // namespace pds
