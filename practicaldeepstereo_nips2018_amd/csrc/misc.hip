@@ -227,13 +227,15 @@ __global__ __launch_bounds__(256) void l1_weights_kernel(const float* __restrict
     }
 }
 
-// t1[n,o,d,y,x] = LeakyReLU(B + T_d) and partial sums (records [(n*C+o)*D + d][tile] x {sum, sumsq})
+// t1[n,o,d,y,x] = LeakyReLU(B + T_d) and partial sums (records [(n*C+o)*D + d][tile] x {sum, sumsq}).
+// One thread owns four consecutive x of one row for ALL disparity planes: B is loaded once, the H rows come
+// from L1, and the only streaming traffic is the 16-byte stores of t1.
+constexpr int kL1MaxPlanes = 64;  // disparity planes handled per launch (statistics scratch in LDS)
 __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict__ y4, float* __restrict__ t1,
                                                          double* __restrict__ partials, int C, int h, int w,
-                                                         int d_begin, int d_count) {
-    // grid: x = tile, y = local disparity, z = n*C + o ; y4 [n][C][5][h][w+2]
-    const int nc = blockIdx.z, dl = blockIdx.y, tile = blockIdx.x, tiles = gridDim.x;
-    const int d = d_begin + dl;
+                                                         int d_begin, int d_first, int d_launch, int d_count) {
+    // grid: x = tile over (y, x/4), y = n*C + o ; y4 [n][C][5][h][w+2]
+    const int nc = blockIdx.y, tile = blockIdx.x, tiles = gridDim.x;
     const int W2 = w + 2;
     const size_t px = (size_t)h * w;
     const float* Bp = y4 + (size_t)nc * kL1Planes * h * W2;
@@ -241,35 +243,65 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
     const float* Ha = Hp + (size_t)h * W2;
     const float* Hb = Ha + (size_t)h * W2;
     const float* H0 = Hb + (size_t)h * W2;
-    float* dst = t1 + ((size_t)nc * d_count + dl) * px;
-    float s = 0.f, q = 0.f;
-    for (size_t i = (size_t)tile * 256 + threadIdx.x; i < px; i += (size_t)tiles * 256) {
-        const int y = (int)(i / w), x = (int)(i % w);
-        const int u = x - d;
-        const size_t row = (size_t)y * W2;
-        float v = Bp[row + x + 2];
-        if (d == 0) {
-            v += H0[row + x + 2];
-        } else if (u >= -2) {
-            const float* sel = (x == w - 2) ? Ha : ((x == w - 1) ? Hb : Hp);
-            v += sel[row + u + 2];
-        }
-        v = v > 0.f ? v : v * kLeakySlope;
-        dst[i] = v;
-        s += v;
-        q = fmaf(v, v, q);
-    }
-    __shared__ double red[4][2];
-    const double ds = wave_sum((double)s), dq = wave_sum((double)q);
+    __shared__ float red[kL1MaxPlanes][4][2];
+    const int xq = (w + 3) / 4;
+    const bool vec = (w & 3) == 0;
+    const int qi = tile * 256 + threadIdx.x;
+    const bool active = qi < h * xq;
+    const int y = active ? qi / xq : 0, xb = active ? (qi - y * xq) * 4 : 0;
+    const size_t row = (size_t)y * W2;
+    float bq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bq[k] = (active && xb + k < w) ? Bp[row + xb + k + 2] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        red[wave][0] = ds;
-        red[wave][1] = dq;
+    for (int di = 0; di < d_launch; ++di) {
+        const int dl = d_first + di;
+        const int d = d_begin + dl;
+        float r[4], s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = xb + k;
+            float v = 0.f;
+            if (active && x < w) {
+                const int u = x - d;
+                v = bq[k];
+                if (d == 0) {
+                    v += H0[row + x + 2];
+                } else if (u >= -2) {
+                    const float* sel = (x == w - 2) ? Ha : ((x == w - 1) ? Hb : Hp);
+                    v += sel[row + u + 2];
+                }
+                v = v > 0.f ? v : v * kLeakySlope;
+                s += v;
+                q = fmaf(v, v, q);
+            }
+            r[k] = v;
+        }
+        if (active) {
+            float* o = t1 + ((size_t)nc * d_count + dl) * px + (size_t)y * w + xb;
+            if (vec) {
+                *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (xb + k < w) o[k] = r[k];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off, 64);
+            q += __shfl_xor(q, off, 64);
+        }
+        if (lane == 0) {
+            red[di][wave][0] = s;
+            red[di][wave][1] = q;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        const int k = threadIdx.x;
-        partials[((((size_t)nc * d_count + dl) * tiles) + tile) * 2 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    for (int i = threadIdx.x; i < d_launch * 2; i += 256) {
+        const int di = i >> 1, k = i & 1;
+        const double v = (double)red[di][0][k] + (double)red[di][1][k] + (double)red[di][2][k] + (double)red[di][3][k];
+        partials[((((size_t)nc * d_count + d_first + di) * tiles) + tile) * 2 + k] = v;
     }
 }
 
@@ -290,15 +322,17 @@ int launch_l1_weights(const float* w1, const float* b1, float* w4, float* bias4,
 }
 
 int l1_combine_tiles(int h, int w) {
-    const size_t px = (size_t)h * w;
-    int t = (int)((px + 2047) / 2048);
-    return t < 1 ? 1 : (t > 32 ? 32 : t);
+    const size_t quads = (size_t)h * ((w + 3) / 4);
+    return (int)((quads + 255) / 256);  // one quad per thread
 }
 
 int launch_l1_combine(const float* y4, float* t1, double* partials, int batch, int channels, int h, int w,
                       int d_begin, int d_count, hipStream_t s) {
-    hipLaunchKernelGGL(l1_combine_kernel, dim3(l1_combine_tiles(h, w), d_count, batch * channels), dim3(256), 0, s, y4,
-                       t1, partials, channels, h, w, d_begin, d_count);
+    for (int first = 0; first < d_count; first += kL1MaxPlanes) {
+        const int n = d_count - first < kL1MaxPlanes ? d_count - first : kL1MaxPlanes;
+        hipLaunchKernelGGL(l1_combine_kernel, dim3(l1_combine_tiles(h, w), batch * channels), dim3(256), 0, s, y4, t1,
+                           partials, channels, h, w, d_begin, first, n, d_count);
+    }
     return check_launch("l1_combine");
 }
 
