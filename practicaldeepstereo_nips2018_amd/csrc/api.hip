@@ -624,7 +624,16 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         }
         // 3. input
         float* dx = c.get<float>(L.in_g.numel());
-        if (!c.plan) c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, L.P->weight, dx, L.in_g, L.out_g, c.s));
+        if (L.type == 0 && L.stride == 1) {
+            // stride-1 convolution: dx = conv(dz, flipped weights) on the forward kernels (MFMA where supported)
+            const int taps = L.kd * 9;
+            float* wf = c.get<float>((size_t)L.out_g.c * L.in_g.c * taps);
+            if (!c.plan) c.run(launch_flip_weights(L.P->weight, wf, L.out_g.c, L.in_g.c, taps, c.s));
+            PdsConvBlockParams pf{wf, nullptr, nullptr, nullptr};
+            conv_block(c, plain_src(dz), no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);
+        } else if (!c.plan) {
+            c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, L.P->weight, dx, L.in_g, L.out_g, c.s));
+        }
         route(L.a, dx, L.in_g);
         route(L.b, dx, L.in_g);
     }

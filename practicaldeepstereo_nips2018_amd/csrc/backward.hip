@@ -304,6 +304,25 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
             dx[(((size_t)n * G.Cin + c0 + c) * G.Di + iz) * G.Hi * G.Wi + (size_t)iy * G.Wi + ix] = acc[c];
 }
 
+// Wf[c][oc][taps-1-t] = W[oc][c][t]: the data gradient of a stride-1 "same" convolution is the convolution of dz
+// with these flipped, channel-swapped weights, so the forward (MFMA) kernels can compute it.
+__global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                           int cout, int cin, int taps) {
+    const int total = cout * cin * taps;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int t = i % taps;
+        const int c = (i / taps) % cin;
+        const int oc = i / (taps * cin);
+        wf[((size_t)c * cout + oc) * taps + (taps - 1 - t)] = w[i];
+    }
+}
+
+int launch_flip_weights(const float* w, float* wf, int cout, int cin, int taps, hipStream_t s) {
+    const int total = cout * cin * taps;
+    hipLaunchKernelGGL(flip_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, wf, cout, cin, taps);
+    return check_launch("flip_weights");
+}
+
 int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
                     const Geom& out, hipStream_t s) {
     BwdGeom G{in.n, in.c, in.d, in.h, in.w, out.c, out.d, out.h, out.w};

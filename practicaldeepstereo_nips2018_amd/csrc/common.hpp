@@ -135,6 +135,7 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
                   float* dgamma, float* dbeta, int accumulate_params, hipStream_t s);
 int channel_sum_splits(const Geom& g);
 int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s);
+int launch_flip_weights(const float* w, float* wf, int cout, int cin, int taps, hipStream_t s);
 int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
                     const Geom& out, hipStream_t s);
 size_t bwd_weight_scratch_doubles(int transposed, int kd, const Geom& in, const Geom& out);
