@@ -616,11 +616,16 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             sb = Src{tb.raw, tb.scale, tb.shift, tb.per_plane, tb.bcast_d};
         }
         double* bias_scratch = c.get<double>((size_t)channel_sum_splits(out.g) * out.g.c);
-        double* weight_scratch = c.get<double>(bwd_weight_scratch_doubles(L.type, L.kd, L.in_g, L.out_g));
-        if (!c.plan) {
-            c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
-            c.run(launch_bwd_weight(L.type, L.kd, L.stride, sa, sb, dz, const_cast<float*>(gp->weight), L.in_g, L.out_g,
-                                    0, weight_scratch, c.s));
+        if (!c.plan) c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
+        if (wgrad2d_mfma_supported(L.type, L.kd, L.stride, sb, L.in_g, L.out_g)) {
+            float* ws = c.get<float>(wgrad2d_mfma_scratch_floats(L.in_g, L.out_g));
+            if (!c.plan)
+                c.run(launch_wgrad2d_mfma(sa, sb, dz, const_cast<float*>(gp->weight), L.in_g, L.out_g, 0, ws, c.s));
+        } else {
+            double* weight_scratch = c.get<double>(bwd_weight_scratch_doubles(L.type, L.kd, L.in_g, L.out_g));
+            if (!c.plan)
+                c.run(launch_bwd_weight(L.type, L.kd, L.stride, sa, sb, dz, const_cast<float*>(gp->weight), L.in_g,
+                                        L.out_g, 0, weight_scratch, c.s));
         }
         // 3. input
         float* dx = c.get<float>(L.in_g.numel());

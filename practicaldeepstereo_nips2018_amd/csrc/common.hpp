@@ -141,6 +141,11 @@ int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const f
 size_t bwd_weight_scratch_doubles(int transposed, int kd, const Geom& in, const Geom& out);
 int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
                       const Geom& in, const Geom& out, int accumulate, double* scratch, hipStream_t s);
+// MFMA weight gradient of the 2-D 3x3 convolutions (wgrad2d_mfma.hip)
+bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, const Geom& in, const Geom& out);
+size_t wgrad2d_mfma_scratch_floats(const Geom& in, const Geom& out);
+int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,
+                        int accumulate, float* scratch, hipStream_t s);
 int launch_grad_add(float* dst, const float* src, size_t count, int accumulate, hipStream_t s);
 int launch_grad_reduce_d(float* dst, const float* src, const Geom& g, int accumulate, hipStream_t s);
 int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int batch, int channels, int h, int w,

@@ -1,0 +1,194 @@
+// Weight gradient of the 2-D 3x3 convolutions of MatchingOperation on the fp32 MFMA units:
+//   dW[oc][c][tap] = sum over (n, d, y, x) of dz[oc][p] * xhat[c][p + tap]
+// GEMM view: M = output channels (16 per block), N = (tap, input channel) columns (16 channels per block),
+// K = positions, walked 4 at a time with v_mfma_f32_16x16x4_f32.
+//   work item   one row segment of 32 positions of one (n, d) plane; persistent workgroups stride over the items
+//               and keep their partial dW in registers (fp32 over a few thousand positions), then write ONE
+//               partial per workgroup; a second kernel sums the partials in fp64.
+//   workgroup   4 waves, 64 input channels (grid.y walks further groups of 64).  Cout = 64: wave = one 16-channel
+//               output block x all 36 column blocks (144 accumulator registers); Cout <= 16: the 4 waves split the
+//               36 column blocks.
+//   LDS         xhat tile [64 ch][3 rows][34] (deferred InstanceNorm, skip sum and zero padding applied while
+//               staging) and dz tile [64][32]; row strides chosen so that both fragment reads (16 channels x 4
+//               consecutive positions per instruction) are bank-conflict free: channel stride == 2 (mod 32).
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int TWG = 32;        // positions per work item
+constexpr int RSX = 54;        // xhat row stride: >= TWG + 2 and == 22 (mod 32), so 3 * RSX == 2 (mod 32)
+constexpr int XS = 3 * RSX;    // xhat channel stride
+constexpr int DS = 34;         // dz row stride, == 2 (mod 32)
+constexpr int CG = 64;         // input channels per workgroup
+constexpr int NBLK = CG * 9 / 16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WArgs {
+    Src a, b;
+    const float* __restrict__ dz;
+    float* __restrict__ partial;  // [workgroup][Cout][Cin][9]
+    int N, Cin, D, H, W, Cout;
+    int items, segs;
+};
+
+}  // namespace
+
+template <int MBW>
+__global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A) {
+    constexpr int PARTS = 4 / MBW;          // waves sharing one output block split the column blocks
+    constexpr int NB = NBLK / PARTS;        // column blocks per wave
+    __shared__ __attribute__((aligned(16))) float xl[CG * XS];
+    __shared__ __attribute__((aligned(16))) float dzl[MBW * 16 * DS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = wave % MBW, part = wave / MBW;
+    const int cg0 = blockIdx.y * CG;
+    const size_t plane = (size_t)A.H * A.W;
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
+        int r = item;
+        const int seg = r % A.segs;
+        r /= A.segs;
+        const int y = r % A.H;
+        r /= A.H;
+        const int d = r % A.D;
+        const int n = r / A.D;
+        const int x0 = seg * TWG;
+
+        // ---- stage xhat: 64 channels x 3 rows x 34 columns (x0-1 .. x0+32) -------------------------------
+        for (int e = tid; e < CG * 3 * (TWG + 2); e += THREADS) {
+            const int c = e / (3 * (TWG + 2));
+            const int rem = e - c * 3 * (TWG + 2);
+            const int rr = rem / (TWG + 2), xx = rem - rr * (TWG + 2);
+            const int yy = y - 1 + rr, x = x0 - 1 + xx;
+            const int ch = cg0 + c;
+            float v = 0.f;
+            if (yy >= 0 && yy < A.H && x >= 0 && x < A.W) {
+                const size_t off = ((size_t)(n * A.Cin + ch) * A.D + d) * plane + (size_t)yy * A.W + x;
+                float sa = 1.f, ha = 0.f;
+                if (A.a.scale) {
+                    const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                    sa = A.a.scale[g];
+                    ha = A.a.shift[g];
+                }
+                v = fmaf(sa, A.a.p[off], ha);
+                if (A.b.p) {
+                    float sb = 1.f, hb = 0.f;
+                    if (A.b.scale) {
+                        const int g = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                        sb = A.b.scale[g];
+                        hb = A.b.shift[g];
+                    }
+                    v += fmaf(sb, A.b.p[off], hb);
+                }
+            }
+            xl[c * XS + rr * RSX + xx] = v;
+        }
+        // ---- stage dz: (padded) output channels x 32 positions --------------------------------------------
+        for (int e = tid; e < MBW * 16 * TWG; e += THREADS) {
+            const int oc = e / TWG, px = e - oc * TWG;
+            const int x = x0 + px;
+            float v = 0.f;
+            if (oc < A.Cout && x < A.W)
+                v = A.dz[((size_t)(n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W + x];
+            dzl[oc * DS + px] = v;
+        }
+        __syncthreads();
+
+        const float* arow = dzl + (mb * 16 + (lane & 15)) * DS + (lane >> 4);
+        const float* brow = xl + (lane & 15) * XS + (lane >> 4);
+#pragma unroll 2
+        for (int ks = 0; ks < TWG / 4; ++ks) {
+            const float af = arow[ks * 4];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int nb = part * NB + i;           // column block: tap = nb / 4, channel block = nb % 4
+                const int t = nb / (CG / 16), cb = nb % (CG / 16);
+                const int dy = t / 3, dx = t % 3;
+                const float bf = brow[cb * 16 * XS + dy * RSX + ks * 4 + dx];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one partial per workgroup: [Cout][Cin][9] -----------------------------------------------------------
+    float* dst = A.partial + (size_t)blockIdx.x * A.Cout * A.Cin * 9;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int nb = part * NB + i;
+        const int t = nb / (CG / 16), cb = nb % (CG / 16);
+        const int c = cg0 + cb * 16 + (lane & 15);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int oc = mb * 16 + 4 * (lane >> 4) + rr;
+            if (oc < A.Cout) dst[((size_t)oc * A.Cin + c) * 9 + t] = acc[i][rr];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_f32_kernel(const float* __restrict__ partial, size_t wcount,
+                                                               int parts, float* __restrict__ dw, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < wcount; i += (size_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int k = 0; k < parts; ++k) s += (double)partial[(size_t)k * wcount + i];
+        dw[i] = (accumulate ? dw[i] : 0.f) + (float)s;
+    }
+}
+
+bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, const Geom& in, const Geom& out) {
+    if (transposed || kd != 1 || stride != 1) return false;
+    if (in.c % CG != 0) return false;
+    if (!(out.c == 64 || out.c <= 16)) return false;
+    if (b.p && b.bcast_d) return false;
+    return true;
+}
+
+static int wgrad2d_workgroups(const Geom& in) {
+    const size_t items = (size_t)in.n * in.d * in.h * ((in.w + TWG - 1) / TWG);
+    size_t wgs = items / 8;  // at least ~8 items per workgroup so the partial write amortises
+    if (wgs > 512) wgs = 512;
+    return wgs < 1 ? 1 : (int)wgs;
+}
+
+size_t wgrad2d_mfma_scratch_floats(const Geom& in, const Geom& out) {
+    return (size_t)wgrad2d_workgroups(in) * out.c * in.c * 9;
+}
+
+int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,
+                        int accumulate, float* scratch, hipStream_t s) {
+    WArgs A;
+    A.a = a;
+    A.b = b;
+    A.dz = dz;
+    A.partial = scratch;
+    A.N = in.n;
+    A.Cin = in.c;
+    A.D = in.d;
+    A.H = in.h;
+    A.W = in.w;
+    A.Cout = out.c;
+    A.segs = (in.w + TWG - 1) / TWG;
+    A.items = in.n * in.d * in.h * A.segs;
+    const int wgs = wgrad2d_workgroups(in);
+    dim3 grid(wgs, in.c / CG);
+    if (out.c == 64)
+        hipLaunchKernelGGL((wgrad2d_mfma_kernel<4>), grid, dim3(THREADS), 0, s, A);
+    else
+        hipLaunchKernelGGL((wgrad2d_mfma_kernel<1>), grid, dim3(THREADS), 0, s, A);
+    const size_t wcount = (size_t)out.c * in.c * 9;
+    unsigned bx = (unsigned)((wcount + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3(bx), dim3(256), 0, s, scratch, wcount, wgs, dw, accumulate);
+    return check_launch("wgrad2d_mfma");
+}
+
+}  // namespace pds
