@@ -186,6 +186,21 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
                                int n, int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes,
                                void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
+/* backward of the stand-alone blocks (regularization.py:28-31, 54-57 under autograd); grad_* param structs hold
+ * the gradient buffers of the two conv blocks, written */
+size_t pds_contraction_block_bwd_workspace_bytes(int batch, int c, int d, int h, int w);
+int pds_contraction_block_bwd(const PdsConvBlockParams* downsampling, const PdsConvBlockParams* smoothing,
+                              const PdsConvBlockParams* grad_downsampling, const PdsConvBlockParams* grad_smoothing,
+                              const float* x, const float* grad_down, const float* grad_smooth, float* grad_x,
+                              int batch, int c, int d, int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes,
+                              void* workspace, size_t workspace_bytes, pds_stream_t stream);
+size_t pds_expansion_block_bwd_workspace_bytes(int batch, int c, int d, int h, int w);
+int pds_expansion_block_bwd(const PdsConvBlockParams* upsampling, const PdsConvBlockParams* smoothing,
+                            const PdsConvBlockParams* grad_upsampling, const PdsConvBlockParams* grad_smoothing,
+                            const float* x, const float* shortcut, const float* grad_out, float* grad_x,
+                            float* grad_shortcut, int batch, int c, int d, int h, int w, void* fwd_workspace,
+                            size_t fwd_workspace_bytes, void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
 /* backward of pds_shift_concat_fwd: grad_out [d_count, batch, 2*channels, h, w] -> grad_left, grad_right
  * [batch, channels, h, w]   (reference matching.py:50-61 under autograd) */
 int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_right, int batch, int channels,

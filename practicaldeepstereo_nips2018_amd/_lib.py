@@ -95,6 +95,12 @@ SIGNATURES = {
     'pds_matching_operation_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I]),
     'pds_matching_operation_bwd': (_I, [ctypes.POINTER(MatchingParams), ctypes.POINTER(MatchingParams),
                                         _VP, _VP, _VP, _I, _I, _I, _VP, _SZ, _VP, _SZ, _VP]),
+    'pds_contraction_block_bwd_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
+    'pds_contraction_block_bwd': (_I, [ctypes.POINTER(ConvBlockParams)] * 4 + [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I,
+                                       _VP, _SZ, _VP, _SZ, _VP]),
+    'pds_expansion_block_bwd_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
+    'pds_expansion_block_bwd': (_I, [ctypes.POINTER(ConvBlockParams)] * 4 + [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I,
+                                     _I, _VP, _SZ, _VP, _SZ, _VP]),
     'pds_subpixel_cross_entropy_workspace_bytes': (_SZ, [_I, _I, _I]),
     'pds_subpixel_cross_entropy_fwd': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, ctypes.c_float, _I,
                                             _VP, _SZ, _VP]),

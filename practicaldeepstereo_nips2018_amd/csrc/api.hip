@@ -536,6 +536,43 @@ static void regularization_pipeline(Ctx& c, const PdsRegularizationParams& P, co
 }
 
 
+// ---- stand-alone ContractionBlock3d / ExpansionBlock3d (reference regularization.py:28-31, 54-57) ----------
+// pp[0] / pp[1]: the two conv blocks of the module.  Outputs are plain (normalised) tensors: tape ops of type 2.
+static void contraction_pipeline(Ctx& c, const PdsConvBlockParams* pp, const float* x, float* down_out,
+                                 float* smooth_out, const Geom& g, int* id_down_out = nullptr,
+                                 int* id_smooth_out = nullptr) {
+    const Src xs = external_src(c, x, g);
+    DT down = conv_block(c, xs, no_src(), g, pp[0], 2 * g.c, 3, 2, 0);
+    DT smooth = conv_block(c, down.src(), no_src(), down.g, pp[1], 2 * g.c, 3, 1, 0);
+    if (!c.plan) {
+        c.run(launch_materialize(down.src(), no_src(), down.g, down_out, c.s));
+        c.run(launch_materialize(smooth.src(), no_src(), smooth.g, smooth_out, c.s));
+    }
+    DT od, os;
+    od.raw = down_out;
+    od.g = down.g;
+    os.raw = smooth_out;
+    os.g = smooth.g;
+    tape_layer(c, 2, 0, 0, down.src(), no_src(), down.g, od, nullptr, false);
+    tape_layer(c, 2, 0, 0, smooth.src(), no_src(), smooth.g, os, nullptr, false);
+    if (id_down_out) *id_down_out = od.id;
+    if (id_smooth_out) *id_smooth_out = os.id;
+}
+
+static void expansion_pipeline(Ctx& c, const PdsConvBlockParams* pp, const float* x, const float* shortcut,
+                               float* out, const Geom& g) {
+    const Src xs = external_src(c, x, g);                                                    // tape id 0
+    const Geom gs{g.n, g.c / 2, 2 * g.d, 2 * g.h, 2 * g.w};
+    const Src ss = external_src(c, shortcut, gs);                                            // tape id 1
+    DT up = deconv_block(c, xs, no_src(), g, pp[0], g.c / 2, 4);
+    DT sm = conv_block(c, up.src(), ss, up.g, pp[1], g.c / 2, 3, 1, 0);
+    if (!c.plan) c.run(launch_materialize(sm.src(), no_src(), sm.g, out, c.s));
+    DT o;
+    o.raw = out;
+    o.g = sm.g;
+    tape_layer(c, 2, 0, 0, sm.src(), no_src(), sm.g, o, nullptr, false);                     // last tensor
+}
+
 // ====================================================================================================
 // Backward: reverse walk over a tape.
 // ====================================================================================================
@@ -830,13 +867,13 @@ int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* 
     return c.err;
 }
 
+static const PdsConvBlockParams kDummyBlocks[2] = {{nullptr, nullptr, (const float*)1, (const float*)1},
+                                                   {nullptr, nullptr, (const float*)1, (const float*)1}};
+
 size_t pds_contraction_block_workspace_bytes(int batch, int c_, int d, int h, int w) {
     Ctx c{nullptr, 0, true, nullptr};
-    PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
-    const Geom g{batch, c_, d, h, w};
-    DT down = conv_block(c, plain_src(nullptr), no_src(), g, dummy, 2 * c_, 3, 2, 0);
-    conv_block(c, down.src(), no_src(), down.g, dummy, 2 * c_, 3, 1, 0);
-    return c.off;
+    contraction_pipeline(c, kDummyBlocks, nullptr, nullptr, nullptr, Geom{batch, c_, d, h, w});
+    return c.off + 256;
 }
 
 int pds_contraction_block_fwd(const PdsConvBlockParams* downsampling, const PdsConvBlockParams* smoothing,
@@ -848,22 +885,16 @@ int pds_contraction_block_fwd(const PdsConvBlockParams* downsampling, const PdsC
     if (int rc = check_block(*smoothing, true, "contraction._smoothing")) return rc;
     const size_t need = pds_contraction_block_workspace_bytes(batch, c_, d, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "contraction: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const PdsConvBlockParams pp[2] = {*downsampling, *smoothing};
     Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
-    const Geom g{batch, c_, d, h, w};
-    DT down = conv_block(c, plain_src(x), no_src(), g, *downsampling, 2 * c_, 3, 2, 0);
-    DT smooth = conv_block(c, down.src(), no_src(), down.g, *smoothing, 2 * c_, 3, 1, 0);
-    c.run(launch_materialize(down.src(), no_src(), down.g, down_out, c.s));
-    c.run(launch_materialize(smooth.src(), no_src(), smooth.g, smooth_out, c.s));
+    contraction_pipeline(c, pp, x, down_out, smooth_out, Geom{batch, c_, d, h, w});
     return c.err;
 }
 
 size_t pds_expansion_block_workspace_bytes(int batch, int c_, int d, int h, int w) {
     Ctx c{nullptr, 0, true, nullptr};
-    PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
-    const Geom g{batch, c_, d, h, w};
-    DT up = deconv_block(c, plain_src(nullptr), no_src(), g, dummy, c_ / 2, 4);
-    conv_block(c, up.src(), no_src(), up.g, dummy, c_ / 2, 3, 1, 0);
-    return c.off;
+    expansion_pipeline(c, kDummyBlocks, nullptr, nullptr, nullptr, Geom{batch, c_, d, h, w});
+    return c.off + 256;
 }
 
 int pds_expansion_block_fwd(const PdsConvBlockParams* upsampling, const PdsConvBlockParams* smoothing, const float* x,
@@ -875,11 +906,9 @@ int pds_expansion_block_fwd(const PdsConvBlockParams* upsampling, const PdsConvB
     if (int rc = check_block(*smoothing, true, "expansion._smoothing")) return rc;
     const size_t need = pds_expansion_block_workspace_bytes(batch, c_, d, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "expansion: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const PdsConvBlockParams pp[2] = {*upsampling, *smoothing};
     Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
-    const Geom g{batch, c_, d, h, w};
-    DT up = deconv_block(c, plain_src(x), no_src(), g, *upsampling, c_ / 2, 4);
-    DT sm = conv_block(c, up.src(), plain_src(shortcut), up.g, *smoothing, c_ / 2, 3, 1, 0);
-    c.run(launch_materialize(sm.src(), no_src(), sm.g, out, c.s));
+    expansion_pipeline(c, pp, x, shortcut, out, Geom{batch, c_, d, h, w});
     return c.err;
 }
 
@@ -993,6 +1022,91 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
                 need);
     return operation_backward(false, nullptr, params, grads, concatenated, grad_signature, grad_concatenated, n, h, w,
                               fwd_workspace, workspace, (hipStream_t)stream);
+}
+
+static int block_backward(bool plan, size_t* bytes, bool expansion, const PdsConvBlockParams* pp,
+                          const PdsConvBlockParams* gg, const float* x, const float* shortcut,
+                          const float* grad_out0, const float* grad_out1, float* grad_x, float* grad_shortcut,
+                          const Geom& g, void* fwd_workspace, void* workspace, hipStream_t stream) {
+    Tape tape;
+    Ctx re{plan ? nullptr : (char*)fwd_workspace, 0, true, stream};
+    re.tape = &tape;
+    int id0 = -1, id1 = -1;
+    if (expansion) {
+        expansion_pipeline(re, pp, x, shortcut, const_cast<float*>(grad_out0), g);
+        id0 = (int)tape.tensors.size() - 1;
+    } else {
+        contraction_pipeline(re, pp, x, const_cast<float*>(grad_out0), const_cast<float*>(grad_out1), g, &id0, &id1);
+    }
+    if (re.err) return re.err;
+    std::vector<float*> dhat(tape.tensors.size(), nullptr);
+    std::vector<char> written(tape.tensors.size(), 0);
+    float* mark = reinterpret_cast<float*>(8);
+    dhat[0] = plan ? mark : grad_x;
+    if (expansion) dhat[1] = plan ? mark : grad_shortcut;
+    dhat[id0] = plan ? mark : const_cast<float*>(grad_out0);
+    written[id0] = 1;
+    if (id1 >= 0) {
+        dhat[id1] = plan ? mark : const_cast<float*>(grad_out1);
+        written[id1] = 1;
+    }
+    GradMap M{reinterpret_cast<const char*>(pp), reinterpret_cast<const char*>(gg), 2 * sizeof(PdsConvBlockParams)};
+    Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    backward_walk(c, tape, M, dhat, written);
+    if (bytes) *bytes = c.off;
+    return c.err;
+}
+
+size_t pds_contraction_block_bwd_workspace_bytes(int batch, int c_, int d, int h, int w) {
+    size_t bytes = 0;
+    block_backward(true, &bytes, false, kDummyBlocks, kDummyBlocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   Geom{batch, c_, d, h, w}, nullptr, nullptr, nullptr);
+    return bytes + 256;
+}
+
+int pds_contraction_block_bwd(const PdsConvBlockParams* downsampling, const PdsConvBlockParams* smoothing,
+                              const PdsConvBlockParams* grad_downsampling, const PdsConvBlockParams* grad_smoothing,
+                              const float* x, const float* grad_down, const float* grad_smooth, float* grad_x,
+                              int batch, int c_, int d, int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes,
+                              void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(downsampling && smoothing && grad_downsampling && grad_smoothing && x && grad_down && grad_smooth &&
+                    grad_x && fwd_workspace && workspace,
+                "contraction_bwd: null pointer");
+    PDS_REQUIRE(batch > 0 && c_ > 0 && d > 0 && h > 0 && w > 0, "contraction_bwd: bad shape");
+    PDS_REQUIRE(fwd_workspace_bytes >= pds_contraction_block_workspace_bytes(batch, c_, d, h, w),
+                "contraction_bwd: forward workspace too small");
+    PDS_REQUIRE(workspace_bytes >= pds_contraction_block_bwd_workspace_bytes(batch, c_, d, h, w),
+                "contraction_bwd: workspace too small");
+    const PdsConvBlockParams pp[2] = {*downsampling, *smoothing};
+    const PdsConvBlockParams gg[2] = {*grad_downsampling, *grad_smoothing};
+    return block_backward(false, nullptr, false, pp, gg, x, nullptr, grad_down, grad_smooth, grad_x, nullptr,
+                          Geom{batch, c_, d, h, w}, fwd_workspace, workspace, (hipStream_t)stream);
+}
+
+size_t pds_expansion_block_bwd_workspace_bytes(int batch, int c_, int d, int h, int w) {
+    size_t bytes = 0;
+    block_backward(true, &bytes, true, kDummyBlocks, kDummyBlocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   Geom{batch, c_, d, h, w}, nullptr, nullptr, nullptr);
+    return bytes + 256;
+}
+
+int pds_expansion_block_bwd(const PdsConvBlockParams* upsampling, const PdsConvBlockParams* smoothing,
+                            const PdsConvBlockParams* grad_upsampling, const PdsConvBlockParams* grad_smoothing,
+                            const float* x, const float* shortcut, const float* grad_out, float* grad_x,
+                            float* grad_shortcut, int batch, int c_, int d, int h, int w, void* fwd_workspace,
+                            size_t fwd_workspace_bytes, void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(upsampling && smoothing && grad_upsampling && grad_smoothing && x && shortcut && grad_out && grad_x &&
+                    grad_shortcut && fwd_workspace && workspace,
+                "expansion_bwd: null pointer");
+    PDS_REQUIRE(batch > 0 && c_ >= 2 && c_ % 2 == 0 && d > 0 && h > 0 && w > 0, "expansion_bwd: bad shape");
+    PDS_REQUIRE(fwd_workspace_bytes >= pds_expansion_block_workspace_bytes(batch, c_, d, h, w),
+                "expansion_bwd: forward workspace too small");
+    PDS_REQUIRE(workspace_bytes >= pds_expansion_block_bwd_workspace_bytes(batch, c_, d, h, w),
+                "expansion_bwd: workspace too small");
+    const PdsConvBlockParams pp[2] = {*upsampling, *smoothing};
+    const PdsConvBlockParams gg[2] = {*grad_upsampling, *grad_smoothing};
+    return block_backward(false, nullptr, true, pp, gg, x, shortcut, grad_out, nullptr, grad_x, grad_shortcut,
+                          Geom{batch, c_, d, h, w}, fwd_workspace, workspace, (hipStream_t)stream);
 }
 
 size_t pds_subpixel_cross_entropy_workspace_bytes(int n, int h, int w) {

@@ -42,6 +42,8 @@ class ContractionBlock3d(nn.Module):
 
 
 class _ContractionFunction(torch.autograd.Function):
+    """pds_contraction_block_fwd / _bwd."""
+
     @staticmethod
     def forward(ctx, module, x, *unused_parameters):
         lib = _lib.load()
@@ -51,17 +53,46 @@ class _ContractionFunction(torch.autograd.Function):
         smooth = torch.empty(shape, dtype=torch.float32, device=x.device)
         pd, ps = _block_params(module._downsampling_2x), _block_params(module._smoothing)
         nbytes = lib.pds_contraction_block_workspace_bytes(batch, c, d, h, w)
-        ws = module._workspace.get(nbytes, x.device)
+        training = any(ctx.needs_input_grad)
+        ws = (torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device) if training
+              else module._workspace.get(nbytes, x.device))
         with torch.cuda.device(x.device):
             _lib.check(lib.pds_contraction_block_fwd(
                 ctypes.byref(pd), ctypes.byref(ps), _lib.ptr(x), _lib.ptr(down), _lib.ptr(smooth),
                 batch, c, d, h, w, _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)),
                 'pds_contraction_block_fwd')
+        if training:
+            ctx.module = module
+            ctx.forward_workspace = ws
+            ctx.save_for_backward(x)
         return down, smooth
 
     @staticmethod
-    def backward(ctx, *grads):
-        _lib.not_differentiable('ContractionBlock3d')
+    def backward(ctx, grad_down, grad_smooth):
+        lib = _lib.load()
+        module = ctx.module
+        x, = ctx.saved_tensors
+        batch, c, d, h, w = x.shape
+        shape = (batch, 2 * c, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2)
+        grad_down = (torch.zeros(shape, dtype=torch.float32, device=x.device) if grad_down is None
+                     else grad_down.contiguous())
+        grad_smooth = (torch.zeros(shape, dtype=torch.float32, device=x.device) if grad_smooth is None
+                       else grad_smooth.contiguous())
+        grads, tensor_of = _lib.gradient_buffers(module)
+        pd, ps = _block_params(module._downsampling_2x), _block_params(module._smoothing)
+        gd, gs = _block_params(module._downsampling_2x, tensor_of), _block_params(module._smoothing, tensor_of)
+        grad_x = torch.empty_like(x)
+        ws = torch.empty(max(int(lib.pds_contraction_block_bwd_workspace_bytes(batch, c, d, h, w)), 256),
+                         dtype=torch.uint8, device=x.device)
+        fws = ctx.forward_workspace
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pds_contraction_block_bwd(
+                ctypes.byref(pd), ctypes.byref(ps), ctypes.byref(gd), ctypes.byref(gs), _lib.ptr(x),
+                _lib.ptr(grad_down), _lib.ptr(grad_smooth), _lib.ptr(grad_x), batch, c, d, h, w,
+                _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)),
+                'pds_contraction_block_bwd')
+        ctx.forward_workspace = None
+        return (None, grad_x) + tuple(grads[id(p)] for p in module.parameters())
 
 
 class ExpansionBlock3d(nn.Module):
@@ -89,6 +120,8 @@ class ExpansionBlock3d(nn.Module):
 
 
 class _ExpansionFunction(torch.autograd.Function):
+    """pds_expansion_block_fwd / _bwd."""
+
     @staticmethod
     def forward(ctx, module, x, shortcut, *unused_parameters):
         lib = _lib.load()
@@ -96,17 +129,42 @@ class _ExpansionFunction(torch.autograd.Function):
         out = torch.empty_like(shortcut)
         pu, ps = _block_params(module._upsampling_2x), _block_params(module._smoothing)
         nbytes = lib.pds_expansion_block_workspace_bytes(batch, c, d, h, w)
-        ws = module._workspace.get(nbytes, x.device)
+        training = any(ctx.needs_input_grad)
+        ws = (torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device) if training
+              else module._workspace.get(nbytes, x.device))
         with torch.cuda.device(x.device):
             _lib.check(lib.pds_expansion_block_fwd(
                 ctypes.byref(pu), ctypes.byref(ps), _lib.ptr(x), _lib.ptr(shortcut), _lib.ptr(out),
                 batch, c, d, h, w, _lib.ptr(ws), ws.numel(), _lib.stream_handle(x.device)),
                 'pds_expansion_block_fwd')
+        if training:
+            ctx.module = module
+            ctx.forward_workspace = ws
+            ctx.save_for_backward(x, shortcut)
         return out
 
     @staticmethod
-    def backward(ctx, *grads):
-        _lib.not_differentiable('ExpansionBlock3d')
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        module = ctx.module
+        x, shortcut = ctx.saved_tensors
+        batch, c, d, h, w = x.shape
+        grad_out = grad_out.contiguous()
+        grads, tensor_of = _lib.gradient_buffers(module)
+        pu, ps = _block_params(module._upsampling_2x), _block_params(module._smoothing)
+        gu, gs = _block_params(module._upsampling_2x, tensor_of), _block_params(module._smoothing, tensor_of)
+        grad_x, grad_shortcut = torch.empty_like(x), torch.empty_like(shortcut)
+        ws = torch.empty(max(int(lib.pds_expansion_block_bwd_workspace_bytes(batch, c, d, h, w)), 256),
+                         dtype=torch.uint8, device=x.device)
+        fws = ctx.forward_workspace
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pds_expansion_block_bwd(
+                ctypes.byref(pu), ctypes.byref(ps), ctypes.byref(gu), ctypes.byref(gs), _lib.ptr(x),
+                _lib.ptr(shortcut), _lib.ptr(grad_out), _lib.ptr(grad_x), _lib.ptr(grad_shortcut),
+                batch, c, d, h, w, _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(),
+                _lib.stream_handle(x.device)), 'pds_expansion_block_bwd')
+        ctx.forward_workspace = None
+        return (None, grad_x, grad_shortcut) + tuple(grads[id(p)] for p in module.parameters())
 
 
 class Regularization(nn.Module):

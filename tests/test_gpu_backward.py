@@ -188,3 +188,33 @@ def test_training_step_with_subpixel_cross_entropy(dev):
     assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
     assert relative_error(cost.grad, c64.grad) <= 1e-4
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+def test_standalone_blocks_backward(dev):
+    """ContractionBlock3d / ExpansionBlock3d (regularization.py:11-57) with gradients, odd sizes and 6 features
+    (the generic kernels: 6 channels are not MFMA-shaped)."""
+    g = torch.Generator().manual_seed(11)
+    con = helpers.seeded(lambda: pds.ContractionBlock3d(6), seed=12).to(dev)
+    x = torch.randn(2, 6, 10, 14, 16, generator=g).to(dev).requires_grad_(True)
+    wd, wsm = torch.randn(2, 12, 5, 7, 8, generator=g), torch.randn(2, 12, 5, 7, 8, generator=g)
+    down, smooth = con(x)
+    ((down * wd.to(dev)).sum() + (smooth * wsm.to(dev)).sum()).backward()
+    params = helpers.prefixed(con.state_dict(), '_c')
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    d64, s64 = oracle.contraction_block_3d(p64, '_c', x64)
+    ((d64 * wd.double()).sum() + (s64 * wsm.double()).sum()).backward()
+    assert relative_error(x.grad, x64.grad) <= REL_TOL
+    check_param_grads(con, '_c', {k: v.grad for k, v in p64.items()})
+
+    exp = helpers.seeded(lambda: pds.ExpansionBlock3d(6), seed=13).to(dev)
+    xi = torch.randn(2, 6, 5, 7, 8, generator=g).to(dev).requires_grad_(True)
+    sc = torch.randn(2, 3, 10, 14, 16, generator=g).to(dev).requires_grad_(True)
+    wo = torch.randn(2, 3, 10, 14, 16, generator=g)
+    out = exp(xi, sc)
+    (out * wo.to(dev)).sum().backward()
+    params = helpers.prefixed(exp.state_dict(), '_e')
+    ref, (gxi, gsc), gp = oracle_grads(lambda p, a, b: oracle.expansion_block_3d(p, '_e', a, b), [xi, sc], params, wo)
+    assert relative_error(out, ref) <= 1e-4
+    assert relative_error(xi.grad, gxi) <= REL_TOL and relative_error(sc.grad, gsc) <= REL_TOL
+    check_param_grads(exp, '_e', gp)
