@@ -186,6 +186,39 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
                                int n, int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes,
                                void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Embedding                                 reference embedding.py:11-65 (producer of the path's inputs)
+ *   image [batch, input_features, h, w] -> descriptor [batch, features, H4, W4], shortcut [batch, shortcut_features, H4, W4]
+ *   H4 = ceil(ceil((h + pad_top) / 2) / 2), W4 likewise.  pad_top / pad_left are the zero rows / columns
+ *   SizeAdapter.pad (size_adapter.py:29-43) would have prepended: they are applied virtually, the padded image is
+ *   never materialised (the InstanceNorm2d of embedding.py:32 still sees them, as in the reference).
+ *   `downsampling` = _embedding_modules.1 / .2 (k5 s2 blocks), `blocks` = 2 * residual_blocks conv blocks of
+ *   _embedding_modules.3.., `shortcut` = _shortcut.
+ * ---------------------------------------------------------------------------------- */
+typedef struct PdsEmbeddingParams {
+    int input_features;     /* 3  */
+    int features;           /* 64 */
+    int shortcut_features;  /* 8  */
+    int residual_blocks;    /* 2  */
+    PdsConvBlockParams downsampling[2];
+    const PdsConvBlockParams* blocks; /* [2 * residual_blocks] */
+    PdsConvBlockParams shortcut;
+} PdsEmbeddingParams;
+
+size_t pds_embedding_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,
+                                     int pad_left);
+int pds_embedding_fwd(const PdsEmbeddingParams* params, const float* image, float* descriptor, float* shortcut,
+                      int batch, int h, int w, int pad_top, int pad_left, void* workspace, size_t workspace_bytes,
+                      pds_stream_t stream);
+/* backward (pds_trainer.py:40-46): needs the untouched forward workspace and the descriptor the forward call
+ * returned; grad_descriptor is used as scratch (the shortcut branch's contribution is added to it in place) */
+size_t pds_embedding_bwd_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,
+                                         int pad_left);
+int pds_embedding_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads, const float* image,
+                      const float* descriptor, float* grad_descriptor, const float* grad_shortcut, int batch, int h,
+                      int w, int pad_top, int pad_left, void* fwd_workspace, size_t fwd_workspace_bytes, void* workspace,
+                      size_t workspace_bytes, pds_stream_t stream);
+
 /* backward of the stand-alone blocks (regularization.py:28-31, 54-57 under autograd); grad_* param structs hold
  * the gradient buffers of the two conv blocks, written */
 size_t pds_contraction_block_bwd_workspace_bytes(int batch, int c, int d, int h, int w);

@@ -14,6 +14,8 @@ reference's arithmetic for
   * ``SubpixelMap``                        reference practical_deep_stereo/estimator.py:10-91
   * the layer factories those use          reference practical_deep_stereo/network_blocks.py:19-144
   * ``SubpixelCrossEntropy``               reference practical_deep_stereo/loss.py:16-78 (consumer in training)
+  * ``Embedding``                          reference practical_deep_stereo/embedding.py:11-65 (producer of the path's
+                                           inputs) and ``SizeAdapter.pad`` size_adapter.py:29-43
 
 Parity pinning: ``tests/golden/make_golden.py`` (run in the build container,
 where /root/reference is importable) checks every function below against the
@@ -59,6 +61,12 @@ def conv_block_3d(p, prefix, x, stride=1):
 def deconv_block_3d(p, prefix, x):
     """transposed_convolutional_block_4x4x4_stride_2, network_blocks.py:124-131 -> :75-85."""
     x = F.conv_transpose3d(x, p[prefix + '.0.weight'], p[prefix + '.0.bias'], stride=2, padding=1)
+    return _act_norm(x, p[prefix + '.2.weight'], p[prefix + '.2.bias'])
+
+
+def conv_block_5x5_stride_2(p, prefix, x):
+    """convolutional_block_5x5_stride_2, network_blocks.py:86-92 -> :47-58 (kernel 5, stride 2, padding 2)."""
+    x = F.conv2d(x, p[prefix + '.0.weight'], p[prefix + '.0.bias'], stride=2, padding=2)
     return _act_norm(x, p[prefix + '.2.weight'], p[prefix + '.2.bias'])
 
 
@@ -207,6 +215,31 @@ def subpixel_cross_entropy(similarities, ground_truth_disparities, weights=None,
         w = weights[known]
         return (w * entropy).sum() / (w.sum() + 1e-15)
     return entropy.mean()
+
+
+# --------------------------------------------------------------------------------------
+# embedding.py / size_adapter.py (producers of the path's inputs)
+# --------------------------------------------------------------------------------------
+def pad_to_multiple(image, minimum_size=64):
+    """SizeAdapter.pad, size_adapter.py:29-43: zero rows on top and zero columns on the left up to the
+    next multiple of ``minimum_size``.  Returns (padded, rows, columns)."""
+    height, width = image.shape[-2:]
+    rows = -height % minimum_size
+    columns = -width % minimum_size
+    return F.pad(image, (columns, 0, rows, 0)), rows, columns
+
+
+def embedding(p, prefix, image, number_of_residual_blocks=2):
+    """Embedding.forward, embedding.py:46-65: InstanceNorm2d without affine parameters (:32), two
+    5x5 stride-2 blocks (:33-36), residual blocks (:38-41); returns (descriptor, shortcut) with
+    shortcut = convolutional_block_3x3(descriptor) (:43-44, 65)."""
+    m = prefix + '._embedding_modules'
+    x = F.instance_norm(image, eps=IN_EPS)
+    x = conv_block_5x5_stride_2(p, m + '.1', x)
+    x = conv_block_5x5_stride_2(p, m + '.2', x)
+    for i in range(number_of_residual_blocks):
+        x = residual_block_2d(p, '%s.%d' % (m, 3 + i), x)
+    return x, conv_block_2d(p, prefix + '._shortcut', x)
 
 
 # --------------------------------------------------------------------------------------

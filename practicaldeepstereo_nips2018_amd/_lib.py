@@ -36,6 +36,15 @@ class MatchingParams(ctypes.Structure):
                 ('last', ConvBlockParams)]
 
 
+class EmbeddingParams(ctypes.Structure):
+    """struct PdsEmbeddingParams"""
+    _fields_ = [('input_features', ctypes.c_int), ('features', ctypes.c_int),
+                ('shortcut_features', ctypes.c_int), ('residual_blocks', ctypes.c_int),
+                ('downsampling', ConvBlockParams * 2),
+                ('blocks', ctypes.POINTER(ConvBlockParams)),
+                ('shortcut', ConvBlockParams)]
+
+
 class RegularizationParams(ctypes.Structure):
     """struct PdsRegularizationParams"""
     _fields_ = [('features', ctypes.c_int),
@@ -101,6 +110,11 @@ SIGNATURES = {
     'pds_expansion_block_bwd_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
     'pds_expansion_block_bwd': (_I, [ctypes.POINTER(ConvBlockParams)] * 4 + [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I,
                                      _I, _VP, _SZ, _VP, _SZ, _VP]),
+    'pds_embedding_workspace_bytes': (_SZ, [ctypes.POINTER(EmbeddingParams), _I, _I, _I, _I, _I]),
+    'pds_embedding_fwd': (_I, [ctypes.POINTER(EmbeddingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_embedding_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(EmbeddingParams), _I, _I, _I, _I, _I]),
+    'pds_embedding_bwd': (_I, [ctypes.POINTER(EmbeddingParams)] * 2 + [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I,
+                               _VP, _SZ, _VP, _SZ, _VP]),
     'pds_subpixel_cross_entropy_workspace_bytes': (_SZ, [_I, _I, _I]),
     'pds_subpixel_cross_entropy_fwd': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, ctypes.c_float, _I,
                                             _VP, _SZ, _VP]),

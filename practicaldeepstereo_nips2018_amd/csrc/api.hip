@@ -22,6 +22,16 @@ int set_error(int code, const char* fmt, ...) {
 int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error((int)e, "%s: %s", what, hipGetErrorString(e));
+    // PDS_DEBUG_SYNC=1 (debugging only): wait for every launch and name it, so that a faulting kernel is the
+    // last line printed.  Off by default: the library never synchronises.
+    static const bool debug_sync = getenv("PDS_DEBUG_SYNC") != nullptr;
+    if (debug_sync) {
+        fprintf(stderr, "[pds] %s ...", what);
+        fflush(stderr);
+        const hipError_t es = hipDeviceSynchronize();
+        fprintf(stderr, " %s\n", es == hipSuccess ? "ok" : hipGetErrorString(es));
+        if (es != hipSuccess) return set_error((int)es, "%s: %s", what, hipGetErrorString(es));
+    }
     return 0;
 }
 
@@ -54,14 +64,20 @@ struct TapeTensor {
     Geom g{0, 0, 0, 0, 0};
     int per_plane = 0;
     int bcast_d = 0;              // [N, C, H, W] tensor broadcast along D (g.d is the broadcast extent)
+    bool needs_grad = true;       // false: nothing upstream wants a gradient (the image)
 };
 struct TapeLayer {
-    int type = 0;                 // 0 conv, 1 transposed conv, 2 sum (out = a^ + b^, plain)
+    int type = 0;                 // 0 conv, 1 transposed conv, 2 sum (out = a^ + b^, plain),
+                                  // 3 space-to-depth (out = s2d(a^), plain; embedding.hip)
     int kd = 3, stride = 1;
     int a = -1, b = -1, out = -1; // tensor ids
     Geom in_g{0, 0, 0, 0, 0}, out_g{0, 0, 0, 0, 0};
     const PdsConvBlockParams* P = nullptr;  // address inside the caller's parameter struct
     bool norm = false;
+    // k5 s2 convolution run as k3 s1 over space-to-depth input: the 3x3 weights actually used, and the
+    // channel count of the 5x5 kernel they were derived from (0: ordinary layer)
+    const float* weight_used = nullptr;
+    int s2d_cin = 0;
 };
 struct Tape {
     std::vector<TapeTensor> tensors;
@@ -81,12 +97,19 @@ struct Ctx {
     int err = 0;
     PackSink* sink = nullptr;
     Tape* tape = nullptr;   // non-null: record layers for the backward pass (and keep every layer tape-friendly)
+    size_t limit = ~(size_t)0;  // bytes behind `base`: carving past it is an error, never a wild write
 
     template <class T>
     T* get(size_t count) {
         const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
         T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
         off += bytes;
+        static const bool debug_arena = getenv("PDS_DEBUG_ARENA") != nullptr && atoi(getenv("PDS_DEBUG_ARENA")) > 1;
+        if (debug_arena) fprintf(stderr, "[pds]   get %zu\n", bytes);
+        if (base && off > limit) {
+            if (!err) err = set_error(-1, "workspace arena overflow (%zu > %zu bytes)", off, limit);
+            plan = true;  // nothing more is launched
+        }
         return p;
     }
     void run(int rc) {
@@ -140,13 +163,14 @@ struct DT {
 };
 
 // a caller-provided plain tensor as a source, registered on the tape when one is being recorded
-static Src external_src(Ctx& c, const float* p, const Geom& g, int bcast_d = 0) {
+static Src external_src(Ctx& c, const float* p, const Geom& g, int bcast_d = 0, bool needs_grad = true) {
     Src s{p, nullptr, nullptr, 0, bcast_d};
     if (c.tape) {
         TapeTensor t;
         t.raw = p;
         t.g = g;
         t.bcast_d = bcast_d;
+        t.needs_grad = needs_grad;
         s.id = c.tape->add(t);
     }
     return s;
@@ -198,6 +222,10 @@ struct ConvExtra {
     int d_begin = 0;
     float* side_out = nullptr;
     int plane_weight_sets = 0;
+    // a k5 s2 layer evaluated as k3 s1 over space-to-depth input (any kernel): weights to use instead of P.weight
+    const float* weight_used = nullptr;
+    int s2d_cin = 0;
+    bool matching_extras() const { return l0A || side_out || plane_weight_sets > 0; }
 };
 
 // conv (+ LeakyReLU + deferred InstanceNorm when P.gamma) ; out_raw may be caller-provided
@@ -213,7 +241,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     L.a = a;
     L.b = b;
     L.in = in;
-    L.weight = P.weight;
+    L.weight = (extra && extra->s2d_cin) ? extra->weight_used : P.weight;
     L.bias = P.bias;
     L.out = o.raw;
     L.out_g = o.g;
@@ -240,7 +268,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     if (kind == 2)
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
-    if (extra && kind != 2) {
+    if (extra && extra->matching_extras() && kind != 2) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
     }
@@ -271,6 +299,10 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         c.run(launch());
     }
     tape_layer(c, 0, kd, stride, a, b, in, o, &P, norm);
+    if (c.tape && extra && extra->s2d_cin) {  // (the pointer is null in a planning walk: test the count)
+        c.tape->layers.back().weight_used = extra->weight_used;
+        c.tape->layers.back().s2d_cin = extra->s2d_cin;
+    }
     return o;
 }
 
@@ -573,6 +605,77 @@ static void expansion_pipeline(Ctx& c, const PdsConvBlockParams* pp, const float
     tape_layer(c, 2, 0, 0, sm.src(), no_src(), sm.g, o, nullptr, false);                     // last tensor
 }
 
+// ---- Embedding (reference embedding.py:46-65) over a virtually padded image (size_adapter.py:29-43) --------
+// image [batch, C0, h, w]; descriptor [batch, F, H4, W4]; shortcut [batch, S, H4, W4] with
+// H2 = ceil((h + top) / 2), H4 = ceil(H2 / 2) (same for the width).
+static void embedding_pipeline(Ctx& c, const PdsEmbeddingParams& P, const float* image, float* descriptor,
+                               float* shortcut, int batch, int h, int w, int top, int left, int* id_descriptor = nullptr,
+                               int* id_shortcut = nullptr) {
+    const int C0 = P.input_features, F = P.features;
+    // parameter-free InstanceNorm2d of the padded image (embedding.py:32), folded into the re-layout below
+    const int chunks = image_stats_chunks(h, w);
+    double* partials = c.get<double>((size_t)batch * C0 * chunks * 2);
+    float* scale0 = c.get<float>(batch * C0);
+    float* shift0 = c.get<float>(batch * C0);
+    const Geom g1{batch, 4 * C0, 1, (h + top + 1) / 2, (w + left + 1) / 2};
+    float* s0 = c.get<float>(g1.numel());
+    if (!c.plan) {
+        c.run(launch_image_stats(image, batch * C0, h, w, partials, c.s));
+        c.run(launch_in_finalize(partials, batch * C0, chunks, (double)(h + top) * (w + left), nullptr, nullptr, C0, 1,
+                                 scale0, shift0, nullptr, nullptr, c.s));
+        c.run(launch_space_to_depth(Src{image, scale0, shift0, 0, 0}, batch, C0, h, w, top, left, s0, c.s));
+    }
+    const Src s0_src = external_src(c, s0, g1, 0, false);  // tape id 0: no gradient wanted
+    // convolutional_block_5x5_stride_2 twice (embedding.py:33-36), each as k3 s1 over space-to-depth input
+    float* w1 = c.get<float>((size_t)F * 4 * C0 * 9);
+    if (c.before_packing()) c.run(launch_s2d_weights(P.downsampling[0].weight, w1, F, C0, c.s));
+    ConvExtra e1;
+    e1.weight_used = w1;
+    e1.s2d_cin = C0;
+    DT t1 = conv_block(c, s0_src, no_src(), g1, P.downsampling[0], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e1);
+    DT s1;
+    s1.g = Geom{batch, 4 * F, 1, (t1.g.h + 1) / 2, (t1.g.w + 1) / 2};
+    s1.raw = c.get<float>(s1.g.numel());
+    if (!c.plan) c.run(launch_space_to_depth(t1.src(), batch, F, t1.g.h, t1.g.w, 0, 0, s1.raw, c.s));
+    tape_layer(c, 3, 0, 0, t1.src(), no_src(), t1.g, s1, nullptr, false);
+    float* w2 = c.get<float>((size_t)F * 4 * F * 9);
+    if (c.before_packing()) c.run(launch_s2d_weights(P.downsampling[1].weight, w2, F, F, c.s));
+    ConvExtra e2;
+    e2.weight_used = w2;
+    e2.s2d_cin = F;
+    DT t2 = conv_block(c, s1.src(), no_src(), s1.g, P.downsampling[1], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e2);
+    // residual blocks (embedding.py:38-41); the last sum is the descriptor
+    const Geom g = t2.g;
+    Src cur = t2.src();
+    for (int r = 0; r < P.residual_blocks; ++r) {
+        DT u1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
+        DT u2 = conv_block(c, u1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
+        DT nxt;
+        nxt.g = g;
+        nxt.raw = (r + 1 == P.residual_blocks) ? descriptor : c.get<float>(g.numel());
+        if (!c.plan) c.run(launch_materialize(u2.src(), cur, g, nxt.raw, c.s));
+        tape_layer(c, 2, 0, 0, u2.src(), cur, g, nxt, nullptr, false);
+        cur = nxt.src();
+    }
+    if (P.residual_blocks == 0) {
+        DT d0;
+        d0.g = g;
+        d0.raw = descriptor;
+        if (!c.plan) c.run(launch_materialize(cur, no_src(), g, descriptor, c.s));
+        tape_layer(c, 2, 0, 0, cur, no_src(), g, d0, nullptr, false);
+        cur = d0.src();
+    }
+    if (id_descriptor) *id_descriptor = cur.id;
+    // _shortcut = convolutional_block_3x3(descriptor) (embedding.py:43-44, 65)
+    DT v = conv_block(c, cur, no_src(), g, P.shortcut, P.shortcut_features, 1, 1, 1);
+    DT so;
+    so.g = v.g;
+    so.raw = shortcut;
+    if (!c.plan) c.run(launch_materialize(v.src(), no_src(), v.g, shortcut, c.s));
+    tape_layer(c, 2, 0, 0, v.src(), no_src(), v.g, so, nullptr, false);
+    if (id_shortcut) *id_shortcut = so.id;
+}
+
 // ====================================================================================================
 // Backward: reverse walk over a tape.
 // ====================================================================================================
@@ -593,21 +696,33 @@ struct GradMap {
     }
 };
 
+// bytes behind the backward arena of the entry point being served (set by the pds_*_bwd functions): a planning
+// walk that under-estimates must surface as an error, not as a write past the caller's buffer
+static thread_local size_t g_backward_arena_bytes = ~(size_t)0;
+struct ArenaLimit {
+    explicit ArenaLimit(size_t bytes) { g_backward_arena_bytes = bytes; }
+    ~ArenaLimit() { g_backward_arena_bytes = ~(size_t)0; }
+};
+
 // dhat[i]: gradient with respect to the NORMALISED value of tensor i.  Entries preset by the caller (the
 // gradient of the output, the gradient buffers of the external inputs) are used as they are; the others
 // are carved from the backward arena on first use.
 static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<float*>& dhat,
                           std::vector<char>& written) {
+    static const bool debug_arena = getenv("PDS_DEBUG_ARENA") != nullptr;
     for (int li = (int)T.layers.size() - 1; li >= 0; --li) {
         const TapeLayer& L = T.layers[li];
         const TapeTensor& out = T.tensors[L.out];
         float* g = dhat[L.out];
+        if (debug_arena)
+            fprintf(stderr, "[pds] backward %s layer %d type %d a %d b %d: arena at %zu\n", c.base ? "run " : "plan", li,
+                    L.type, L.a, L.b, c.off);
         if (!written[L.out]) {
             c.run(set_error(-1, "backward: layer %d has no upstream gradient", li));
             return;
         }
         auto route = [&](int id, const float* grad_in, const Geom& in_g) {
-            if (id < 0) return;
+            if (id < 0 || !T.tensors[id].needs_grad) return;
             const TapeTensor& t = T.tensors[id];
             if (!dhat[id]) {
                 dhat[id] = c.get<float>(t.bcast_d ? (size_t)t.g.n * t.g.c * t.g.h * t.g.w : t.g.numel());
@@ -624,6 +739,13 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         if (L.type == 2) {  // plain sum: the gradient flows unchanged to both terms
             route(L.a, g, L.out_g);
             route(L.b, g, L.out_g);
+            continue;
+        }
+        if (L.type == 3) {  // space-to-depth: the adjoint is the inverse permutation
+            if (!T.tensors[L.a].needs_grad) continue;
+            float* dx = c.get<float>(L.in_g.numel());
+            if (!c.plan) c.run(launch_depth_to_space(g, L.in_g.n, L.in_g.c, L.in_g.h, L.in_g.w, dx, c.s));
+            route(L.a, dx, L.in_g);
             continue;
         }
         const PdsConvBlockParams* gp = M.find(L.P);
@@ -654,27 +776,33 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         }
         double* bias_scratch = c.get<double>((size_t)channel_sum_splits(out.g) * out.g.c);
         if (!c.plan) c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
+        const float* weight = L.s2d_cin ? L.weight_used : L.P->weight;
+        const int taps = L.kd * 9;
+        // space-to-depth layer: the gradient of the 3x3 weights is formed in scratch, then gathered into the 5x5 one
+        float* dweight = L.s2d_cin ? c.get<float>((size_t)L.out_g.c * L.in_g.c * taps) : const_cast<float*>(gp->weight);
         if (wgrad2d_mfma_supported(L.type, L.kd, L.stride, sb, L.in_g, L.out_g)) {
             float* ws = c.get<float>(wgrad2d_mfma_scratch_floats(L.in_g, L.out_g));
             if (!c.plan)
-                c.run(launch_wgrad2d_mfma(sa, sb, dz, const_cast<float*>(gp->weight), L.in_g, L.out_g, 0, ws, c.s));
+                c.run(launch_wgrad2d_mfma(sa, sb, dz, dweight, L.in_g, L.out_g, 0, ws, c.s));
         } else {
             double* weight_scratch = c.get<double>(bwd_weight_scratch_doubles(L.type, L.kd, L.in_g, L.out_g));
             if (!c.plan)
-                c.run(launch_bwd_weight(L.type, L.kd, L.stride, sa, sb, dz, const_cast<float*>(gp->weight), L.in_g,
-                                        L.out_g, 0, weight_scratch, c.s));
+                c.run(launch_bwd_weight(L.type, L.kd, L.stride, sa, sb, dz, dweight, L.in_g, L.out_g, 0, weight_scratch,
+                                        c.s));
         }
+        if (L.s2d_cin && !c.plan)
+            c.run(launch_s2d_weights_bwd(dweight, const_cast<float*>(gp->weight), L.out_g.c, L.s2d_cin, 0, c.s));
         // 3. input
+        if (!ta.needs_grad && (L.b < 0 || !T.tensors[L.b].needs_grad)) continue;
         float* dx = c.get<float>(L.in_g.numel());
         if (L.type == 0 && L.stride == 1) {
             // stride-1 convolution: dx = conv(dz, flipped weights) on the forward kernels (MFMA where supported)
-            const int taps = L.kd * 9;
             float* wf = c.get<float>((size_t)L.out_g.c * L.in_g.c * taps);
-            if (!c.plan) c.run(launch_flip_weights(L.P->weight, wf, L.out_g.c, L.in_g.c, taps, c.s));
+            if (!c.plan) c.run(launch_flip_weights(weight, wf, L.out_g.c, L.in_g.c, taps, c.s));
             PdsConvBlockParams pf{wf, nullptr, nullptr, nullptr};
             conv_block(c, plain_src(dz), no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);
         } else if (!c.plan) {
-            c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, L.P->weight, dx, L.in_g, L.out_g, c.s));
+            c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, weight, dx, L.in_g, L.out_g, c.s));
         }
         route(L.a, dx, L.in_g);
         route(L.b, dx, L.in_g);
@@ -867,8 +995,11 @@ int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* 
     return c.err;
 }
 
-static const PdsConvBlockParams kDummyBlocks[2] = {{nullptr, nullptr, (const float*)1, (const float*)1},
-                                                   {nullptr, nullptr, (const float*)1, (const float*)1}};
+// stand-in parameters of the planning walks: non-null marks (never dereferenced), so that the same checks that
+// guard a real call pass
+#define PDS_MARK reinterpret_cast<const float*>(8)
+static const PdsConvBlockParams kDummyBlocks[2] = {{PDS_MARK, PDS_MARK, PDS_MARK, PDS_MARK},
+                                                   {PDS_MARK, PDS_MARK, PDS_MARK, PDS_MARK}};
 
 size_t pds_contraction_block_workspace_bytes(int batch, int c_, int d, int h, int w) {
     Ctx c{nullptr, 0, true, nullptr};
@@ -941,6 +1072,7 @@ static int regularization_backward(bool plan, size_t* bytes, const PdsRegulariza
     written[tape.tensors.size() - 1] = 1;
     GradMap M{reinterpret_cast<const char*>(params), reinterpret_cast<const char*>(grads), sizeof(PdsRegularizationParams)};
     Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (!plan) c.limit = g_backward_arena_bytes;
     if (plan) {  // the walk dereferences nothing in plan mode, but needs non-null marks for the presets
         dhat[0] = dhat[1] = dhat[tape.tensors.size() - 1] = reinterpret_cast<float*>(8);
     }
@@ -953,8 +1085,9 @@ size_t pds_regularization_bwd_workspace_bytes(const PdsRegularizationParams* par
     if (check_regularization(params, batch, d, h, w)) return 0;
     size_t bytes = 0;
     PdsRegularizationParams dummy = *params;
-    regularization_backward(true, &bytes, params, &dummy, nullptr, nullptr, nullptr, nullptr, nullptr, batch, d, h, w,
-                            nullptr, nullptr, nullptr);
+    if (regularization_backward(true, &bytes, params, &dummy, nullptr, nullptr, nullptr, nullptr, nullptr, batch, d, h,
+                                w, nullptr, nullptr, nullptr))
+        return 0;
     return bytes + 256;
 }
 
@@ -971,6 +1104,7 @@ int pds_regularization_bwd(const PdsRegularizationParams* params, const PdsRegul
                 "regularization_bwd: forward workspace too small");
     const size_t need = pds_regularization_bwd_workspace_bytes(params, batch, d, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "regularization_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    ArenaLimit limit(workspace_bytes);
     return regularization_backward(false, nullptr, params, grads, signatures, left_shortcut, grad_cost,
                                    grad_signatures, grad_left_shortcut, batch, d, h, w, fwd_workspace, workspace,
                                    (hipStream_t)stream);
@@ -994,6 +1128,7 @@ static int operation_backward(bool plan, size_t* bytes, const PdsMatchingParams*
     M.blocks_grads = grads->blocks;
     M.blocks_count = 2 * params->residual_blocks;
     Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (!plan) c.limit = g_backward_arena_bytes;
     if (plan) dhat[0] = dhat[tape.tensors.size() - 1] = reinterpret_cast<float*>(8);
     backward_walk(c, tape, M, dhat, written);
     if (bytes) *bytes = c.off;
@@ -1003,7 +1138,8 @@ static int operation_backward(bool plan, size_t* bytes, const PdsMatchingParams*
 size_t pds_matching_operation_bwd_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w) {
     if (check_matching_params(params)) return 0;
     size_t bytes = 0;
-    operation_backward(true, &bytes, params, params, nullptr, nullptr, nullptr, n, h, w, nullptr, nullptr, nullptr);
+    if (operation_backward(true, &bytes, params, params, nullptr, nullptr, nullptr, n, h, w, nullptr, nullptr, nullptr))
+        return 0;
     return bytes + 256;
 }
 
@@ -1020,6 +1156,7 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
     const size_t need = pds_matching_operation_bwd_workspace_bytes(params, n, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "matching_operation_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                 need);
+    ArenaLimit limit(workspace_bytes);
     return operation_backward(false, nullptr, params, grads, concatenated, grad_signature, grad_concatenated, n, h, w,
                               fwd_workspace, workspace, (hipStream_t)stream);
 }
@@ -1052,6 +1189,7 @@ static int block_backward(bool plan, size_t* bytes, bool expansion, const PdsCon
     }
     GradMap M{reinterpret_cast<const char*>(pp), reinterpret_cast<const char*>(gg), 2 * sizeof(PdsConvBlockParams)};
     Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (!plan) c.limit = g_backward_arena_bytes;
     backward_walk(c, tape, M, dhat, written);
     if (bytes) *bytes = c.off;
     return c.err;
@@ -1059,8 +1197,9 @@ static int block_backward(bool plan, size_t* bytes, bool expansion, const PdsCon
 
 size_t pds_contraction_block_bwd_workspace_bytes(int batch, int c_, int d, int h, int w) {
     size_t bytes = 0;
-    block_backward(true, &bytes, false, kDummyBlocks, kDummyBlocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   Geom{batch, c_, d, h, w}, nullptr, nullptr, nullptr);
+    if (block_backward(true, &bytes, false, kDummyBlocks, kDummyBlocks, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, Geom{batch, c_, d, h, w}, nullptr, nullptr, nullptr))
+        return 0;
     return bytes + 256;
 }
 
@@ -1079,14 +1218,16 @@ int pds_contraction_block_bwd(const PdsConvBlockParams* downsampling, const PdsC
                 "contraction_bwd: workspace too small");
     const PdsConvBlockParams pp[2] = {*downsampling, *smoothing};
     const PdsConvBlockParams gg[2] = {*grad_downsampling, *grad_smoothing};
+    ArenaLimit limit(workspace_bytes);
     return block_backward(false, nullptr, false, pp, gg, x, nullptr, grad_down, grad_smooth, grad_x, nullptr,
                           Geom{batch, c_, d, h, w}, fwd_workspace, workspace, (hipStream_t)stream);
 }
 
 size_t pds_expansion_block_bwd_workspace_bytes(int batch, int c_, int d, int h, int w) {
     size_t bytes = 0;
-    block_backward(true, &bytes, true, kDummyBlocks, kDummyBlocks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   Geom{batch, c_, d, h, w}, nullptr, nullptr, nullptr);
+    if (block_backward(true, &bytes, true, kDummyBlocks, kDummyBlocks, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, Geom{batch, c_, d, h, w}, nullptr, nullptr, nullptr))
+        return 0;
     return bytes + 256;
 }
 
@@ -1105,8 +1246,125 @@ int pds_expansion_block_bwd(const PdsConvBlockParams* upsampling, const PdsConvB
                 "expansion_bwd: workspace too small");
     const PdsConvBlockParams pp[2] = {*upsampling, *smoothing};
     const PdsConvBlockParams gg[2] = {*grad_upsampling, *grad_smoothing};
+    ArenaLimit limit(workspace_bytes);
     return block_backward(false, nullptr, true, pp, gg, x, shortcut, grad_out, nullptr, grad_x, grad_shortcut,
                           Geom{batch, c_, d, h, w}, fwd_workspace, workspace, (hipStream_t)stream);
+}
+
+// ---- Embedding ------------------------------------------------------------------------------------------
+static int check_embedding(const PdsEmbeddingParams* P, int batch, int h, int w, int top, int left) {
+    PDS_REQUIRE(P, "embedding: null params");
+    PDS_REQUIRE(P->input_features > 0 && P->features > 0 && P->shortcut_features > 0 && P->residual_blocks >= 0,
+                "embedding: bad feature counts");
+    PDS_REQUIRE(P->residual_blocks == 0 || P->blocks, "embedding: residual block parameters missing");
+    PDS_REQUIRE(batch > 0 && h > 0 && w > 0 && top >= 0 && left >= 0, "embedding: bad shape");
+    return 0;
+}
+
+static PdsEmbeddingParams plan_embedding_params(const PdsEmbeddingParams* P, std::vector<PdsConvBlockParams>& blocks) {
+    // workspace planning never dereferences parameter pointers, but gamma decides whether a layer normalises
+    PdsEmbeddingParams q{};
+    q.input_features = P->input_features;
+    q.features = P->features;
+    q.shortcut_features = P->shortcut_features;
+    q.residual_blocks = P->residual_blocks;
+    const float* const mark = reinterpret_cast<const float*>(8);  // never dereferenced
+    const PdsConvBlockParams normed{mark, mark, mark, mark};
+    q.downsampling[0] = q.downsampling[1] = q.shortcut = normed;
+    blocks.assign((size_t)2 * P->residual_blocks + 1, normed);
+    q.blocks = blocks.data();
+    return q;
+}
+
+size_t pds_embedding_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,
+                                     int pad_left) {
+    if (check_embedding(params, batch, h, w, pad_top, pad_left)) return 0;
+    std::vector<PdsConvBlockParams> blocks;
+    const PdsEmbeddingParams q = plan_embedding_params(params, blocks);
+    Ctx c{nullptr, 0, true, nullptr};
+    embedding_pipeline(c, q, nullptr, nullptr, nullptr, batch, h, w, pad_top, pad_left);
+    return c.off + 256;
+}
+
+static int check_embedding_blocks(const PdsEmbeddingParams* P) {
+    if (int rc = check_block(P->downsampling[0], true, "embedding._embedding_modules.1")) return rc;
+    if (int rc = check_block(P->downsampling[1], true, "embedding._embedding_modules.2")) return rc;
+    for (int i = 0; i < 2 * P->residual_blocks; ++i)
+        if (int rc = check_block(P->blocks[i], true, "embedding residual block")) return rc;
+    return check_block(P->shortcut, true, "embedding._shortcut");
+}
+
+int pds_embedding_fwd(const PdsEmbeddingParams* params, const float* image, float* descriptor, float* shortcut,
+                      int batch, int h, int w, int pad_top, int pad_left, void* workspace, size_t workspace_bytes,
+                      pds_stream_t stream) {
+    if (int rc = check_embedding(params, batch, h, w, pad_top, pad_left)) return rc;
+    PDS_REQUIRE(image && descriptor && shortcut && workspace, "embedding: null pointer");
+    if (int rc = check_embedding_blocks(params)) return rc;
+    const size_t need = pds_embedding_workspace_bytes(params, batch, h, w, pad_top, pad_left);
+    PDS_REQUIRE(workspace_bytes >= need, "embedding: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
+        embedding_pipeline(c, *params, image, descriptor, shortcut, batch, h, w, pad_top, pad_left);
+    });
+}
+
+static int embedding_backward(bool plan, size_t* bytes, const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads,
+                              const float* image, const float* descriptor, float* grad_descriptor,
+                              const float* grad_shortcut, int batch, int h, int w, int top, int left,
+                              void* fwd_workspace, void* workspace, hipStream_t stream) {
+    Tape tape;
+    Ctx re{plan ? nullptr : (char*)fwd_workspace, 0, true, stream};
+    re.tape = &tape;
+    int id_d = -1, id_s = -1;
+    // the descriptor feeds the shortcut block, so its forward values are needed; the shortcut output is not
+    embedding_pipeline(re, *params, image, const_cast<float*>(descriptor), const_cast<float*>(grad_shortcut), batch, h,
+                       w, top, left, &id_d, &id_s);
+    if (re.err) return re.err;
+    std::vector<float*> dhat(tape.tensors.size(), nullptr);
+    std::vector<char> written(tape.tensors.size(), 0);
+    float* mark = reinterpret_cast<float*>(8);
+    dhat[id_d] = plan ? mark : grad_descriptor;   // accumulated in place: the shortcut branch adds to it
+    dhat[id_s] = plan ? mark : const_cast<float*>(grad_shortcut);
+    written[id_d] = written[id_s] = 1;
+    GradMap M{reinterpret_cast<const char*>(params), reinterpret_cast<const char*>(grads), sizeof(PdsEmbeddingParams)};
+    M.blocks_params = params->blocks;
+    M.blocks_grads = grads->blocks;
+    M.blocks_count = 2 * params->residual_blocks;
+    Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (!plan) c.limit = g_backward_arena_bytes;
+    backward_walk(c, tape, M, dhat, written);
+    if (bytes) *bytes = c.off;
+    return c.err;
+}
+
+size_t pds_embedding_bwd_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,
+                                         int pad_left) {
+    if (check_embedding(params, batch, h, w, pad_top, pad_left)) return 0;
+    std::vector<PdsConvBlockParams> blocks, gblocks;
+    const PdsEmbeddingParams q = plan_embedding_params(params, blocks);
+    const PdsEmbeddingParams gq = plan_embedding_params(params, gblocks);
+    size_t bytes = 0;
+    if (embedding_backward(true, &bytes, &q, &gq, nullptr, nullptr, nullptr, nullptr, batch, h, w, pad_top, pad_left,
+                           nullptr, nullptr, nullptr))
+        return 0;
+    return bytes + 256;
+}
+
+int pds_embedding_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads, const float* image,
+                      const float* descriptor, float* grad_descriptor, const float* grad_shortcut, int batch, int h,
+                      int w, int pad_top, int pad_left, void* fwd_workspace, size_t fwd_workspace_bytes, void* workspace,
+                      size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_embedding(params, batch, h, w, pad_top, pad_left)) return rc;
+    PDS_REQUIRE(grads && image && descriptor && grad_descriptor && grad_shortcut && fwd_workspace && workspace,
+                "embedding_bwd: null pointer");
+    PDS_REQUIRE(params->residual_blocks == 0 || grads->blocks, "embedding_bwd: gradient blocks missing");
+    if (int rc = check_embedding_blocks(params)) return rc;
+    PDS_REQUIRE(fwd_workspace_bytes >= pds_embedding_workspace_bytes(params, batch, h, w, pad_top, pad_left),
+                "embedding_bwd: forward workspace too small");
+    PDS_REQUIRE(workspace_bytes >= pds_embedding_bwd_workspace_bytes(params, batch, h, w, pad_top, pad_left),
+                "embedding_bwd: workspace too small");
+    ArenaLimit limit(workspace_bytes);
+    return embedding_backward(false, nullptr, params, grads, image, descriptor, grad_descriptor, grad_shortcut, batch, h,
+                              w, pad_top, pad_left, fwd_workspace, workspace, (hipStream_t)stream);
 }
 
 size_t pds_subpixel_cross_entropy_workspace_bytes(int n, int h, int w) {

@@ -184,6 +184,15 @@ int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_
 int launch_split_first_weights(const float* w0, const float* b0, float* wl, float* wr, float* wr2, float* bias3,
                                int cout, int cin_half, hipStream_t s);
 
+// ---- descriptor network helpers (embedding.hip) --------------------------------------------------------
+int image_stats_chunks(int h, int w);
+int launch_image_stats(const float* img, int nc, int h, int w, double* partials, hipStream_t s);
+// [N, C, H, W] (virtually zero-padded by top rows / left columns) -> [N, 4C, ceil((H+top)/2), ceil((W+left)/2)]
+int launch_space_to_depth(const Src& a, int n, int c, int h, int w, int top, int left, float* out, hipStream_t s);
+int launch_depth_to_space(const float* g, int n, int c, int h, int w, float* out, hipStream_t s);
+int launch_s2d_weights(const float* w5, float* w3, int cout, int cin, hipStream_t s);
+int launch_s2d_weights_bwd(const float* g3, float* g5, int cout, int cin, int accumulate, hipStream_t s);
+
 // ---- loss (loss.hip) --------------------------------------------------------------------------------
 size_t sce_partial_doubles(size_t total_px);
 int launch_sce_fwd(const float* sim, const float* gt, const float* weights, float* loss, float* lse, float* stats,

@@ -409,9 +409,9 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + kInEps);
         const int c = (g / inner) % channels;
-        const double sc = (double)gamma[c] * rstd;
+        const double sc = (gamma ? (double)gamma[c] : 1.0) * rstd;  // no affine: embedding.py:32
         scale[g] = (float)sc;
-        shift[g] = (float)((double)beta[c] - mean * sc);
+        shift[g] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
         if (mean_out) {  // kept for the backward pass
             mean_out[g] = (float)mean;
             rstd_out[g] = (float)rstd;

@@ -1,8 +1,19 @@
-"""Siamese descriptor network (off the hot path: stays on PyTorch-ROCm / MIOpen by design,
-BASELINE.json north_star).  Same layer stack, outputs and state-dict keys as
-reference practical_deep_stereo/embedding.py:11-65 so one checkpoint serves both."""
+"""Siamese descriptor network on the HIP library.
+
+Same constructor, layer stack, outputs and state-dict keys as reference
+practical_deep_stereo/embedding.py:11-65, so one checkpoint serves both.  The arithmetic runs in
+``pds_embedding_fwd`` / ``pds_embedding_bwd``: the parameter-free InstanceNorm2d of the image, the two
+5x5 stride-2 blocks (evaluated as 3x3 stride-1 convolutions over the four pixel-parity sub-images on the
+MFMA kernel), the residual blocks and the shortcut block, with every InstanceNorm deferred into the
+consumer's loader.  ``forward_padded`` additionally folds ``SizeAdapter.pad`` (size_adapter.py:29-43) into
+the first layer's loader instead of materialising the padded image.
+"""
+import ctypes
+
+import torch
 from torch import nn
 
+from practicaldeepstereo_nips2018_amd import _lib
 from practicaldeepstereo_nips2018_amd import network_blocks
 
 
@@ -23,10 +34,102 @@ class Embedding(nn.Module):
         self._embedding_modules = nn.ModuleList(stack)
         self._shortcut = network_blocks.convolutional_block_3x3(number_of_embedding_features,
                                                                 number_of_shortcut_features)
+        self._number_of_residual_blocks = number_of_residual_blocks
+        self._workspace = _lib.Workspace()
+
+    def native_params(self, tensor_of=None):
+        """(PdsEmbeddingParams, keep-alive) over this module's parameters or, with ``tensor_of``, over the
+        tensors it maps them to (gradient buffers)."""
+        mods = self._embedding_modules
+        blocks = []
+        for residual in mods[3:]:
+            for block in residual.convolutions:
+                blocks.append(_lib.conv_block_params(block.conv, block.norm, tensor_of))
+        array = (_lib.ConvBlockParams * max(len(blocks), 1))(*blocks)
+        params = _lib.EmbeddingParams()
+        params.input_features = mods[1].conv.in_channels
+        params.features = mods[1].conv.out_channels
+        params.shortcut_features = self._shortcut.conv.out_channels
+        params.residual_blocks = self._number_of_residual_blocks
+        params.downsampling[0] = _lib.conv_block_params(mods[1].conv, mods[1].norm, tensor_of)
+        params.downsampling[1] = _lib.conv_block_params(mods[2].conv, mods[2].norm, tensor_of)
+        params.blocks = ctypes.cast(array, ctypes.POINTER(_lib.ConvBlockParams))
+        params.shortcut = _lib.conv_block_params(self._shortcut.conv, self._shortcut.norm, tensor_of)
+        return params, array
+
+    def forward_padded(self, image, pad_top=0, pad_left=0):
+        """``forward(ZeroPad2d((pad_left, 0, pad_top, 0))(image))`` without building the padded image."""
+        x = _lib.require_gpu_tensor(image, 'image', 4)
+        if x.size(1) != self._embedding_modules[1].conv.in_channels:
+            raise ValueError('expected %d image channels, got %d' %
+                             (self._embedding_modules[1].conv.in_channels, x.size(1)))
+        return _EmbeddingFunction.apply(self, x, int(pad_top), int(pad_left), *self.parameters())
 
     def forward(self, image):
-        """image [batch, 3, H, W] -> (descriptor [batch, 64, H/4, W/4], shortcut [batch, 8, H/4, W/4])."""
-        descriptor = image
-        for layer in self._embedding_modules:
-            descriptor = layer(descriptor)
-        return descriptor, self._shortcut(descriptor)
+        """image [batch, 3, H, W] -> (descriptor [batch, 64, H/4, W/4], shortcut [batch, 8, H/4, W/4])
+        (embedding.py:46-65)."""
+        return self.forward_padded(image, 0, 0)
+
+
+def _quarter(size):
+    return ((size + 1) // 2 + 1) // 2
+
+
+class _EmbeddingFunction(torch.autograd.Function):
+    """pds_embedding_fwd / _bwd; the image itself never receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, module, image, pad_top, pad_left, *unused_parameters):
+        lib = _lib.load()
+        batch, _, h, w = image.shape
+        params, keep = module.native_params()
+        h4, w4 = _quarter(h + pad_top), _quarter(w + pad_left)
+        descriptor = torch.empty((batch, params.features, h4, w4), dtype=torch.float32, device=image.device)
+        shortcut = torch.empty((batch, params.shortcut_features, h4, w4), dtype=torch.float32,
+                               device=image.device)
+        nbytes = lib.pds_embedding_workspace_bytes(ctypes.byref(params), batch, h, w, pad_top, pad_left)
+        training = any(ctx.needs_input_grad)
+        ws = (torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device) if training
+              else module._workspace.get(nbytes, image.device))
+        with torch.cuda.device(image.device):
+            _lib.check(lib.pds_embedding_fwd(
+                ctypes.byref(params), _lib.ptr(image), _lib.ptr(descriptor), _lib.ptr(shortcut), batch, h, w,
+                pad_top, pad_left, _lib.ptr(ws), ws.numel(), _lib.stream_handle(image.device)),
+                'pds_embedding_fwd')
+        del keep
+        if training:
+            ctx.module = module
+            ctx.forward_workspace = ws
+            ctx.padding = (pad_top, pad_left)
+            ctx.save_for_backward(image, descriptor)
+        return descriptor, shortcut
+
+    @staticmethod
+    def backward(ctx, grad_descriptor, grad_shortcut):
+        lib = _lib.load()
+        module = ctx.module
+        image, descriptor = ctx.saved_tensors
+        batch, _, h, w = image.shape
+        pad_top, pad_left = ctx.padding
+        # the library accumulates the shortcut branch into grad_descriptor: give it a buffer of its own
+        grad_descriptor = (torch.zeros_like(descriptor) if grad_descriptor is None
+                           else grad_descriptor.contiguous().clone())
+        if grad_shortcut is None:
+            grad_shortcut = torch.zeros((batch, module._shortcut.conv.out_channels) + tuple(descriptor.shape[2:]),
+                                        dtype=torch.float32, device=image.device)
+        grad_shortcut = grad_shortcut.contiguous()
+        params, keep = module.native_params()
+        grads, tensor_of = _lib.gradient_buffers(module)
+        grad_params, keep_grads = module.native_params(tensor_of)
+        nbytes = lib.pds_embedding_bwd_workspace_bytes(ctypes.byref(params), batch, h, w, pad_top, pad_left)
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device)
+        fws = ctx.forward_workspace
+        with torch.cuda.device(image.device):
+            _lib.check(lib.pds_embedding_bwd(
+                ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(image), _lib.ptr(descriptor),
+                _lib.ptr(grad_descriptor), _lib.ptr(grad_shortcut), batch, h, w, pad_top, pad_left,
+                _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_handle(image.device)),
+                'pds_embedding_bwd')
+        del keep, keep_grads
+        ctx.forward_workspace = None
+        return (None, None, None, None) + tuple(grads[id(p)] for p in module.parameters())

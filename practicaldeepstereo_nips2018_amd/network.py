@@ -6,6 +6,7 @@ can use it unchanged; ``default()`` wires the MI355X modules of this package ins
 reference classes.  In eval mode, when the injected modules are this package's Regularization and
 SubpixelMap, the last regularization layer and the estimator run fused.
 """
+import torch
 from torch import nn
 
 from practicaldeepstereo_nips2018_amd import embedding
@@ -40,6 +41,20 @@ class PdsNetwork(nn.Module):
         right_descriptor = self._embedding(right_image)[0]
         return self._matching(left_descriptor, right_descriptor), shortcut_from_left
 
+    def _can_fuse_padding(self, left_image, right_image):
+        return (isinstance(self._embedding, embedding.Embedding)
+                and isinstance(self._size_adapter, size_adapter.SizeAdapter)
+                and left_image.shape == right_image.shape and left_image.is_cuda)
+
+    def _signatures_from_unpadded(self, left_image, right_image):
+        """Both images through ONE embedding call (InstanceNorm statistics are per image, so batching them is
+        the same arithmetic as network.py:38-40) with SizeAdapter.pad applied inside its loader."""
+        pad_top, pad_left = self._size_adapter.measure(left_image)
+        batch = left_image.size(0)
+        descriptors, shortcuts = self._embedding.forward_padded(
+            torch.cat([left_image, right_image], 0), pad_top, pad_left)
+        return self._matching(descriptors[:batch], descriptors[batch:]), shortcuts[:batch]
+
     def pass_through_network(self, left_image, right_image):
         signatures, shortcut_from_left = self._signatures(left_image, right_image)
         return self._regularization(signatures, shortcut_from_left), shortcut_from_left
@@ -50,14 +65,16 @@ class PdsNetwork(nn.Module):
 
     def forward(self, left_image, right_image):
         """Sub-pixel disparity in eval mode, matching cost in training mode (network.py:45-52)."""
-        left = self._size_adapter.pad(left_image)
-        right = self._size_adapter.pad(right_image)
+        if self._can_fuse_padding(left_image, right_image):
+            signatures, shortcut_from_left = self._signatures_from_unpadded(left_image, right_image)
+        else:
+            signatures, shortcut_from_left = self._signatures(self._size_adapter.pad(left_image),
+                                                              self._size_adapter.pad(right_image))
         if not self.training and self._can_fuse():
-            signatures, shortcut_from_left = self._signatures(left, right)
             output = self._regularization.forward_with_estimator(signatures, shortcut_from_left,
                                                                  self._estimator)
         else:
-            output = self.pass_through_network(left, right)[0]
+            output = self._regularization(signatures, shortcut_from_left)
             if not self.training:
                 output = self._estimator(output)
         return self._size_adapter.unpad(output)

@@ -16,10 +16,16 @@ class SizeAdapter(object):
     def _padding_for(self, size):
         return (-size) % self._minimum_size
 
-    def pad(self, network_input):
+    def measure(self, network_input):
+        """Records (and returns) the padding ``pad`` would apply, without building the padded tensor: the HIP
+        embedding applies it in its loader."""
         height, width = network_input.shape[-2:]
         self._pixels_pad_to_height = self._padding_for(height)
         self._pixels_pad_to_width = self._padding_for(width)
+        return self._pixels_pad_to_height, self._pixels_pad_to_width
+
+    def pad(self, network_input):
+        self.measure(network_input)
         return F.pad(network_input, (self._pixels_pad_to_width, 0, self._pixels_pad_to_height, 0))
 
     def unpad(self, network_output):

@@ -23,10 +23,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, '/root/reference')
 
+from practical_deep_stereo import embedding as ref_embedding  # noqa: E402
 from practical_deep_stereo import estimator as ref_estimator  # noqa: E402
 from practical_deep_stereo import matching as ref_matching  # noqa: E402
 from practical_deep_stereo import network as ref_network  # noqa: E402
 from practical_deep_stereo import regularization as ref_regularization  # noqa: E402
+from practical_deep_stereo import size_adapter as ref_size_adapter  # noqa: E402
 
 from oracle import pds_oracle as oracle  # noqa: E402
 
@@ -223,6 +225,32 @@ def g8_loss():
     REPORT['g8_loss'] = {'reference_value': value.item()}
 
 
+@torch.no_grad()
+def g9_embedding():
+    """Embedding (embedding.py:11-65) after SizeAdapter.pad (size_adapter.py:29-43) on an image whose size is
+    not a multiple of 64 (rows on top and columns on the left are padded), plus a bare odd-sized call."""
+    torch.manual_seed(0)
+    emb = ref_embedding.Embedding()
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(2, 3, 100, 150, generator=g) * 255
+    adapter = ref_size_adapter.SizeAdapter()
+    padded = adapter.pad(image)
+    descriptor, shortcut = emb(padded)
+    p = prefixed(emb.state_dict(), '_embedding')
+    padded_o, rows, columns = oracle.pad_to_multiple(image)
+    assert torch.equal(padded_o, padded) and (rows, columns) == (28, 42)
+    d_o, s_o = oracle.embedding(p, '_embedding', padded_o)
+    odd = torch.rand(1, 3, 37, 51, generator=g) * 255
+    d_odd, s_odd = emb(odd)
+    d_odd_o, s_odd_o = oracle.embedding(p, '_embedding', odd)
+    rep = {'descriptor_max': maxdiff(descriptor, d_o), 'shortcut_max': maxdiff(shortcut, s_o),
+           'odd_max': max(maxdiff(d_odd, d_odd_o), maxdiff(s_odd, s_odd_o))}
+    assert max(rep.values()) <= 1e-5, rep
+    save('g9_embedding', image=image, descriptor=descriptor, shortcut=shortcut, odd_image=odd,
+         odd_descriptor=d_odd, odd_shortcut=s_odd, weight_checksum=checksum(emb.state_dict()))
+    REPORT['g9_embedding'] = rep
+
+
 def images(batch, height, width):
     g = torch.Generator().manual_seed(1)
     left = torch.rand(batch, 3, height, width, generator=g) * 255
@@ -293,6 +321,7 @@ if __name__ == '__main__':
     g5_subpixel_map()
     g6_config1_network()
     g8_loss()
+    g9_embedding()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
     REPORT['torch'] = torch.__version__

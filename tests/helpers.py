@@ -47,3 +47,14 @@ def disparity_report(gpu, cpu):
     return {'mae': float(delta.mean()), 'max': float(delta.max()),
             'flips': float((delta > 0.5).double().mean()),
             'mae_noflip': float(smooth.mean()) if smooth.numel() else 0.0}
+
+
+def host_descriptors(net, image):
+    """(descriptor, shortcut) of a padded image on the host through the oracle's restatement of the descriptor
+    network (the package's Embedding runs on the GPU only): hot-path tests feed these bit-identical inputs to
+    both the HIP path and the CPU oracle."""
+    from oracle import pds_oracle
+    params = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    padded = pds_oracle.pad_to_multiple(image)[0]
+    with torch.no_grad():
+        return pds_oracle.embedding(params, '_embedding', padded)

@@ -101,10 +101,28 @@ def test_size_adapter_round_trip():
     assert adapter.pad(torch.rand(1, 3, 64, 128)).shape == (1, 3, 64, 128)
 
 
-def test_embedding_shapes_on_cpu():
-    # reference test/test_embedding.py
-    emb = helpers.seeded(lambda: __import__('practicaldeepstereo_nips2018_amd.embedding',
-                                            fromlist=['Embedding']).Embedding())
-    with torch.no_grad():
-        d, s = emb(torch.rand(2, 3, 100, 100))
-    assert d.shape == (2, 64, 25, 25) and s.shape == (2, 8, 25, 25)
+def test_embedding_has_no_cpu_fallback():
+    # the descriptor network runs on the HIP library only (shapes of reference test/test_embedding.py are
+    # checked on the GPU in tests/test_gpu_embedding.py); here: same state-dict keys, loud failure on CPU
+    from practicaldeepstereo_nips2018_amd.embedding import Embedding
+    emb = helpers.seeded(Embedding)
+    keys = set(emb.state_dict().keys())
+    assert '_embedding_modules.1.0.weight' in keys and '_shortcut.2.bias' in keys
+    assert emb.state_dict()['_embedding_modules.1.0.weight'].shape == (64, 3, 5, 5)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        emb(torch.rand(2, 3, 100, 100))
+
+
+def test_backward_workspace_planning_succeeds():
+    # the planning walks run on the host: every *_bwd_workspace_bytes must cover at least the gradient of its
+    # largest activation (a failed planning walk used to return a few hundred bytes)
+    import ctypes
+    from practicaldeepstereo_nips2018_amd.embedding import Embedding
+    lib = _lib.load()
+    params, keep = Embedding().native_params()
+    fwd = lib.pds_embedding_workspace_bytes(ctypes.byref(params), 2, 40, 56, 0, 0)
+    bwd = lib.pds_embedding_bwd_workspace_bytes(ctypes.byref(params), 2, 40, 56, 0, 0)
+    assert fwd > 2 * 64 * 20 * 28 * 4 and bwd > 2 * 64 * 20 * 28 * 4
+    assert lib.pds_contraction_block_bwd_workspace_bytes(1, 8, 16, 16, 16) > 16 * 8 * 8 * 8 * 4
+    assert lib.pds_expansion_block_bwd_workspace_bytes(1, 16, 8, 8, 8) > 8 * 16 * 16 * 16 * 4
+    del keep

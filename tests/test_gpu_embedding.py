@@ -1,0 +1,85 @@
+"""GPU (-m gpu): the descriptor network on the HIP library against the golden fixture and the CPU oracle.
+
+Reference: practical_deep_stereo/embedding.py:11-65 fed by SizeAdapter.pad (size_adapter.py:29-43).
+Tolerances (fp32, stated): descriptor / shortcut max-abs <= 2e-4 against the fp32 reference values (unit-variance
+outputs after five to seven InstanceNorm layers; the first InstanceNorm divides pixel values of up to 255 by their
+standard deviation, so rounding differences of the statistics are amplified once), mean-abs <= 1e-5; gradients within
+2e-3 of the fp64 gradient relative to the tensor's largest entry."""
+import pytest
+import torch
+
+from oracle import pds_oracle as oracle
+from tests import helpers
+from tests.test_gpu_backward import check_param_grads, relative_error
+import practicaldeepstereo_nips2018_amd as pds
+
+pytestmark = pytest.mark.gpu
+MAX_TOL, MEAN_TOL = 2e-4, 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev(hip_library):
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def check(got, want, what):
+    worst, mean = helpers.maxdiff(got, want), helpers.meandiff(got, want)
+    print('%s: max %.3g mean %.3g' % (what, worst, mean))
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert worst <= MAX_TOL and mean <= MEAN_TOL, (what, worst, mean)
+
+
+def test_embedding_golden(dev):
+    g = helpers.golden('g9_embedding')
+    emb = helpers.seeded(pds.Embedding).to(dev).eval()
+    assert abs(helpers.checksum(emb.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    image = g['image'].to(dev)
+    with torch.no_grad():
+        # SizeAdapter.pad folded into the loader: 28 zero rows on top, 42 zero columns on the left
+        descriptor, shortcut = emb.forward_padded(image, 28, 42)
+        check(descriptor, g['descriptor'], 'descriptor (virtual padding)')
+        check(shortcut, g['shortcut'], 'shortcut (virtual padding)')
+        # the reference's own call sequence: materialised padding, then the module
+        padded = torch.nn.functional.pad(image, (42, 0, 28, 0))
+        descriptor2, shortcut2 = emb(padded)
+        assert torch.equal(descriptor2, descriptor) and torch.equal(shortcut2, shortcut)
+        odd_descriptor, odd_shortcut = emb(g['odd_image'].to(dev))
+        check(odd_descriptor, g['odd_descriptor'], 'descriptor (37x51)')
+        check(odd_shortcut, g['odd_shortcut'], 'shortcut (37x51)')
+
+
+def test_embedding_rejects_cpu_and_wrong_channels(dev):
+    emb = pds.Embedding().to(dev)
+    with pytest.raises((RuntimeError, ValueError)):
+        emb(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(ValueError):
+        emb(torch.zeros(1, 4, 8, 8, device=dev))
+
+
+@pytest.mark.parametrize('shape,pad,blocks', [((2, 3, 40, 56), (0, 0), 2), ((1, 3, 37, 51), (27, 13), 1),
+                                              ((1, 1, 32, 32), (0, 0), 0)])
+def test_embedding_backward(dev, shape, pad, blocks):
+    g = torch.Generator().manual_seed(5)
+    emb = helpers.seeded(lambda: pds.Embedding(number_of_input_features=shape[1],
+                                               number_of_embedding_features=16 if blocks != 2 else 64,
+                                               number_of_residual_blocks=blocks), seed=6).to(dev)
+    image = (torch.rand(*shape, generator=g) * 255)
+    descriptor, shortcut = emb.forward_padded(image.to(dev), pad[0], pad[1])
+    wd = torch.randn(descriptor.shape, generator=g)
+    wsh = torch.randn(shortcut.shape, generator=g)
+    ((descriptor * wd.to(dev)).sum() + (shortcut * wsh.to(dev)).sum()).backward()
+
+    params = helpers.prefixed(emb.state_dict(), '_e')
+
+    def run(dtype):
+        p = {k: v.to(dtype).requires_grad_(True) for k, v in params.items()}
+        padded = torch.nn.functional.pad(image.to(dtype), (pad[1], 0, pad[0], 0))
+        d, s = oracle.embedding(p, '_e', padded, number_of_residual_blocks=blocks)
+        ((d * wd.to(dtype)).sum() + (s * wsh.to(dtype)).sum()).backward()
+        return d.detach(), s.detach(), {k: v.grad for k, v in p.items()}
+
+    d64, s64, g64 = run(torch.float64)
+    _, _, g32 = run(torch.float32)
+    assert relative_error(descriptor, d64) <= 1e-4 and relative_error(shortcut, s64) <= 1e-4
+    check_param_grads(emb, '_e', g64, noise_floor=g32)

@@ -239,9 +239,9 @@ def hot_path_inputs(maximum_disparity, batch, height, width):
     """SURVEY.md 8c recipe: seed-0 default network, seed-1 images, descriptors computed once on CPU."""
     net = helpers.seeded(lambda: pds.PdsNetwork.default(maximum_disparity)).eval()
     left, right = helpers.images(batch, height, width)
-    with torch.no_grad():
-        ld, shortcut = net._embedding(net._size_adapter.pad(left))
-        rd = net._embedding(net._size_adapter.pad(right))[0]
+    net._size_adapter.measure(left)   # records the padding for a later unpad, as SizeAdapter.pad would
+    ld, shortcut = helpers.host_descriptors(net, left)
+    rd = helpers.host_descriptors(net, right)[0]
     return net, ld, rd, shortcut
 
 

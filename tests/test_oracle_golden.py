@@ -99,20 +99,41 @@ def test_blocks_golden():
 
 def test_config1_full_network_golden():
     """Config 1 (BASELINE.json configs[0]): 128x256, D=64, the whole pipeline on CPU with this
-    repo's own embedding feeding the oracle hot path."""
+    oracle's embedding feeding the oracle hot path."""
     g = helpers.golden('g6_config1')
     net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).eval()
     assert abs(helpers.checksum(net.state_dict()) - g['weight_checksum'].item()) < 1e-9
     left, right = helpers.images(1, 128, 256)
     with torch.no_grad():
-        ld, shortcut = net._embedding(net._size_adapter.pad(left))
-        rd = net._embedding(net._size_adapter.pad(right))[0]
         p = {k: v for k, v in net.state_dict().items()}
+        ld, shortcut = oracle.embedding(p, '_embedding', oracle.pad_to_multiple(left)[0])
+        rd = oracle.embedding(p, '_embedding', oracle.pad_to_multiple(right)[0])[0]
         ms, cost, disparity = oracle.hot_path(p, ld, rd, shortcut, 63, return_stages=True)
     assert helpers.maxdiff(ms[:, :, ::2, ::4, ::4], g['signatures_sub']) <= 2e-5
     assert helpers.maxdiff(cost[:, ::4, ::8, ::8], g['cost_sub']) <= 1e-4
     rep = helpers.disparity_report(disparity, g['disparity'])
     assert rep['mae'] <= 1e-3, rep
+
+
+def test_embedding_golden():
+    """Embedding after SizeAdapter.pad on a 100x150 image (28 rows / 42 columns of padding) and a bare odd-sized
+    call (reference embedding.py:11-65, size_adapter.py:29-43)."""
+    g = helpers.golden('g9_embedding')
+    emb = helpers.seeded(pds.Embedding)
+    assert abs(helpers.checksum(emb.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    p = helpers.prefixed(emb.state_dict(), '_embedding')
+    with torch.no_grad():
+        padded, rows, columns = oracle.pad_to_multiple(g['image'])
+        assert (rows, columns) == (28, 42) and padded.shape[-2:] == (128, 192)
+        assert float(padded[..., :28, :].abs().max()) == 0.0 and float(padded[..., :, :42].abs().max()) == 0.0
+        descriptor, shortcut = oracle.embedding(p, '_embedding', padded)
+        odd_descriptor, odd_shortcut = oracle.embedding(p, '_embedding', g['odd_image'])
+    assert descriptor.shape == (2, 64, 32, 48) and shortcut.shape == (2, 8, 32, 48)
+    assert odd_descriptor.shape == (1, 64, 10, 13)
+    assert helpers.maxdiff(descriptor, g['descriptor']) <= 1e-5
+    assert helpers.maxdiff(shortcut, g['shortcut']) <= 1e-5
+    assert helpers.maxdiff(odd_descriptor, g['odd_descriptor']) <= 1e-5
+    assert helpers.maxdiff(odd_shortcut, g['odd_shortcut']) <= 1e-5
 
 
 def test_subpixel_cross_entropy_golden():

@@ -22,9 +22,9 @@ g = torch.Generator().manual_seed(1)
 left = torch.rand(1, 3, H, W, generator=g) * 255
 right = torch.rand(1, 3, H, W, generator=g) * 255
 with torch.no_grad():
-    ld, sc = net._embedding(net._size_adapter.pad(left))
-    rd = net._embedding(net._size_adapter.pad(right))[0]
     p32 = {k: v.clone() for k, v in net.state_dict().items()}
+    ld, sc = oracle.embedding(p32, '_embedding', oracle.pad_to_multiple(left)[0])
+    rd = oracle.embedding(p32, '_embedding', oracle.pad_to_multiple(right)[0])[0]
     p64 = oracle.cast_params(p32, torch.float64)
     t = time.time(); ms32, c32, d32 = oracle.hot_path(p32, ld, rd, sc, MD, return_stages=True); t32 = time.time() - t
     t = time.time(); ms64, c64, d64 = oracle.hot_path(p64, ld.double(), rd.double(), sc.double(), MD, return_stages=True); t64 = time.time() - t
