@@ -255,6 +255,19 @@ int pds_subpixel_cross_entropy_bwd(const float* similarities, const float* groun
                                    float* grad_similarities, int n, int planes, int h, int w, float diversity,
                                    int disparity_step, pds_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Evaluation metrics                         reference errors.py:9-74 (pds_trainer.py:48-58)
+ *   estimated / ground_truth: `count` floats each (any shape, contiguous); unknown ground truth is +-inf.
+ *   pixelwise_absolute_error[count]  = known ? |est - gt| : 0            (may be NULL)
+ *   pixelwise_n_pixels_error[count]  = known && |est - gt| > n ? 1 : 0   (may be NULL)
+ *   stats[3] (fp64) = { sum of absolute errors over known pixels, known pixels, pixels with error > n }
+ *   => mean absolute error = stats[0] / stats[1], n-pixels error [%] = 100 * stats[2] / stats[1] (0 if no pixel known)
+ * ---------------------------------------------------------------------------------- */
+size_t pds_disparity_errors_workspace_bytes(size_t count);
+int pds_disparity_errors_fwd(const float* estimated, const float* ground_truth, size_t count, float n,
+                             float* pixelwise_absolute_error, float* pixelwise_n_pixels_error, double* stats,
+                             void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

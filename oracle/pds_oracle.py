@@ -218,6 +218,33 @@ def subpixel_cross_entropy(similarities, ground_truth_disparities, weights=None,
 
 
 # --------------------------------------------------------------------------------------
+# errors.py (evaluation metrics)
+# --------------------------------------------------------------------------------------
+def absolute_error(estimated, ground_truth, use_mean=True):
+    """compute_absolute_error, errors.py:9-44: |est - gt| with unknown (inf) ground truth shown as 0 and left
+    out of the average; 0.0 when nothing is known."""
+    difference = (estimated - ground_truth).abs()
+    unknown = torch.isinf(ground_truth)
+    pixelwise = torch.where(unknown, torch.zeros_like(difference), difference)
+    known = difference[~unknown]
+    if known.numel() == 0:
+        return pixelwise, 0.0
+    return pixelwise, (known.mean() if use_mean else known.median()).item()
+
+
+def n_pixels_error(estimated, ground_truth, n=3.0):
+    """compute_n_pixels_error, errors.py:47-74: 1 where |est - gt| > n (unknown pixels: 0), and the percentage of
+    such pixels among the known ones."""
+    unknown = torch.isinf(ground_truth)
+    beyond = (estimated - ground_truth).abs().gt(n).float()
+    pixelwise = torch.where(unknown, torch.zeros_like(beyond), beyond)
+    known = beyond[~unknown]
+    if known.numel() == 0:
+        return pixelwise, 0.0
+    return pixelwise, known.mean().item() * 100
+
+
+# --------------------------------------------------------------------------------------
 # embedding.py / size_adapter.py (producers of the path's inputs, SURVEY.md 8 f2 / f3)
 # --------------------------------------------------------------------------------------
 def pad_to_multiple(image, minimum_size=64):

@@ -1367,6 +1367,22 @@ int pds_embedding_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams
                               w, pad_top, pad_left, fwd_workspace, workspace, (hipStream_t)stream);
 }
 
+// ---- evaluation metrics (errors.py:9-74) ---------------------------------------------------------------
+size_t pds_disparity_errors_workspace_bytes(size_t count) {
+    return disparity_errors_partial_doubles(count) * sizeof(double) + 256;
+}
+
+int pds_disparity_errors_fwd(const float* estimated, const float* ground_truth, size_t count, float n,
+                             float* pixelwise_absolute_error, float* pixelwise_n_pixels_error, double* stats,
+                             void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(estimated && ground_truth && stats && workspace, "disparity_errors: null pointer");
+    PDS_REQUIRE(count > 0, "disparity_errors: empty input");
+    PDS_REQUIRE(workspace_bytes >= pds_disparity_errors_workspace_bytes(count), "disparity_errors: workspace too small");
+    return launch_disparity_errors(estimated, ground_truth, count, n, pixelwise_absolute_error,
+                                   pixelwise_n_pixels_error, stats, reinterpret_cast<double*>(workspace),
+                                   (hipStream_t)stream);
+}
+
 size_t pds_subpixel_cross_entropy_workspace_bytes(int n, int h, int w) {
     return sce_partial_doubles((size_t)n * h * w) * sizeof(double) + 256;
 }

@@ -193,6 +193,11 @@ int launch_depth_to_space(const float* g, int n, int c, int h, int w, float* out
 int launch_s2d_weights(const float* w5, float* w3, int cout, int cin, hipStream_t s);
 int launch_s2d_weights_bwd(const float* g3, float* g5, int cout, int cin, int accumulate, hipStream_t s);
 
+// ---- evaluation metrics (errors.hip) ----------------------------------------------------------------
+size_t disparity_errors_partial_doubles(size_t total);
+int launch_disparity_errors(const float* est, const float* gt, size_t total, float n, float* abs_out, float* bad_out,
+                            double* stats, double* partials, hipStream_t s);
+
 // ---- loss (loss.hip) --------------------------------------------------------------------------------
 size_t sce_partial_doubles(size_t total_px);
 int launch_sce_fwd(const float* sim, const float* gt, const float* weights, float* loss, float* lse, float* stats,

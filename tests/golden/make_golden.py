@@ -251,6 +251,47 @@ def g9_embedding():
     REPORT['g9_embedding'] = rep
 
 
+def g10_errors():
+    """errors.py:9-74: the reference's own known answers (test/test_errors.py:13-66) and a seeded random case with
+    an inf band; pixel-wise maps, mean / median absolute error and n-pixels error."""
+    from practical_deep_stereo import errors as ref_errors
+    est = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    gt = torch.tensor([[2.0, 2.0], [float('inf'), 1.0]])
+    pix, mean = ref_errors.compute_absolute_error(est, gt, use_mean=True)
+    _, median = ref_errors.compute_absolute_error(est, gt, use_mean=False)
+    bad, percent = ref_errors.compute_n_pixels_error(est, gt, n=1.0)
+    assert torch.equal(pix, torch.tensor([[1.0, 0.0], [0.0, 3.0]])) and abs(mean - 4.0 / 3.0) < 1e-3
+    assert median == 1.0 and torch.equal(bad, torch.tensor([[0.0, 0.0], [0.0, 1.0]]))
+    assert abs(percent - 100.0 / 3.0) < 1e-3
+    nothing = torch.full((2, 2), float('inf'))
+    assert ref_errors.compute_absolute_error(est, nothing)[1] == 0.0
+    assert ref_errors.compute_n_pixels_error(est, nothing, n=1.0)[1] == 0.0
+    g = torch.Generator().manual_seed(31)
+    est2 = torch.rand(2, 37, 53, generator=g) * 190
+    gt2 = est2 + torch.randn(2, 37, 53, generator=g) * 4
+    gt2[:, 5:9, :] = float('inf')
+    gt2[0, 20, 3] = -float('inf')
+    pix2, mean2 = ref_errors.compute_absolute_error(est2, gt2, use_mean=True)
+    _, median2 = ref_errors.compute_absolute_error(est2, gt2, use_mean=False)
+    bad2, percent2 = ref_errors.compute_n_pixels_error(est2, gt2)
+    worst = 0.0
+    for (e, t) in ((est, gt), (est2, gt2), (est, nothing)):
+        for use_mean in (True, False):
+            a_ref = ref_errors.compute_absolute_error(e, t, use_mean)
+            a_or = oracle.absolute_error(e, t, use_mean)
+            assert torch.equal(a_ref[0], a_or[0])
+            worst = max(worst, abs(a_ref[1] - a_or[1]))
+        n_ref = ref_errors.compute_n_pixels_error(e, t, n=1.0)
+        n_or = oracle.n_pixels_error(e, t, n=1.0)
+        assert torch.equal(n_ref[0], n_or[0])
+        worst = max(worst, abs(n_ref[1] - n_or[1]))
+    assert worst == 0.0
+    save('g10_errors', ref_est=est, ref_gt=gt, ref_pixelwise=pix, ref_mean=mean, ref_median=median, ref_bad=bad,
+         ref_percent=percent, random_est=est2, random_gt=gt2, random_pixelwise=pix2, random_mean=mean2,
+         random_median=median2, random_bad=bad2, random_percent=percent2)
+    REPORT['g10_errors'] = {'oracle_vs_reference_max': worst, 'reference_mean': mean, 'reference_percent': percent}
+
+
 def images(batch, height, width):
     g = torch.Generator().manual_seed(1)
     left = torch.rand(batch, 3, height, width, generator=g) * 255
@@ -314,6 +355,15 @@ def g7_config2_statistics():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if '--only' in sys.argv:  # regenerate one fixture, keep the rest of the report
+        name = sys.argv[sys.argv.index('--only') + 1]
+        with open(os.path.join(HERE, 'pinning_report.json')) as f:
+            REPORT.update(json.load(f))
+        globals()[name]()
+        with open(os.path.join(HERE, 'pinning_report.json'), 'w') as f:
+            json.dump(REPORT, f, indent=2, sort_keys=True)
+        print(json.dumps(REPORT[name], indent=2, sort_keys=True))
+        sys.exit(0)
     g1_matching_mock()
     g2_matching_operation()
     g3_regularization()
@@ -322,6 +372,7 @@ if __name__ == '__main__':
     g6_config1_network()
     g8_loss()
     g9_embedding()
+    g10_errors()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
     REPORT['torch'] = torch.__version__

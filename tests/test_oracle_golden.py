@@ -153,3 +153,21 @@ def test_subpixel_cross_entropy_golden():
         v.backward()
         assert abs(v.item() - g['random_%s_value' % name].item()) < 1e-5
         assert helpers.maxdiff(s2.grad, g['random_%s_grad' % name]) <= 1e-7
+
+
+def test_errors_golden():
+    """reference test/test_errors.py:13-66 known answers and a seeded case with an inf band (errors.py:9-74)."""
+    g = helpers.golden('g10_errors')
+    pixelwise, mean = oracle.absolute_error(g['ref_est'], g['ref_gt'])
+    assert torch.equal(pixelwise, torch.tensor([[1.0, 0.0], [0.0, 3.0]])) and abs(mean - 4.0 / 3.0) < 1e-3 * 4 / 3
+    assert abs(oracle.absolute_error(g['ref_est'], g['ref_gt'], use_mean=False)[1] - 1.0) < 1e-3
+    bad, percent = oracle.n_pixels_error(g['ref_est'], g['ref_gt'], n=1.0)
+    assert torch.equal(bad, torch.tensor([[0.0, 0.0], [0.0, 1.0]])) and abs(percent - 100.0 / 3.0) < 1e-3 * 100 / 3
+    nothing = torch.full((2, 2), float('inf'))
+    assert oracle.absolute_error(g['ref_est'], nothing)[1] == 0.0
+    assert oracle.n_pixels_error(g['ref_est'], nothing, n=1.0)[1] == 0.0
+    pixelwise, mean = oracle.absolute_error(g['random_est'], g['random_gt'])
+    assert torch.equal(pixelwise, g['random_pixelwise']) and abs(mean - g['random_mean'].item()) < 1e-6
+    assert abs(oracle.absolute_error(g['random_est'], g['random_gt'], False)[1] - g['random_median'].item()) < 1e-6
+    bad, percent = oracle.n_pixels_error(g['random_est'], g['random_gt'])
+    assert torch.equal(bad, g['random_bad']) and abs(percent - g['random_percent'].item()) < 1e-5
