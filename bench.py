@@ -8,8 +8,11 @@ A step = one stereo pair through Matching -> Regularization -> SubpixelMap (eval
 BASELINE.json configs[1]: 960x540 (padded 576x960), D=192 (maximum_disparity 191), fp32, random-init
 weights (seed 0), descriptors of seeded uniform images (SURVEY.md 8c recipe) resident in HBM before
 the timed region.  N > 1 follows configs[2]: the disparity axis of Matching is sharded over the
-ranks, one all-gather (RCCL) reassembles the signatures, Regularization + estimator run replicated;
-the total work is one pair per step, so scaling is "strong".  Rank 0 prints ONE JSON line.
+ranks and one all-gather (RCCL) per pair reassembles the signatures on every rank; Regularization + the
+estimator cannot be sharded, so the tail of pair i runs on rank i % N (side stream) while all ranks match
+pair i + 1 -- not N redundant copies.  The total work is one pair per step, so scaling is "strong";
+"latency_mode" (one pair at a time, tail replicated) and "replica_mode" (independent pairs, no collective)
+are reported beside it.  Rank 0 prints ONE JSON line.
 
 The line also carries
   roofline     - the dominant kernel (conv2d 3x3 64->64 over all disparity planes, fp32 MFMA): its
@@ -35,7 +38,7 @@ if ROOT not in sys.path:
 
 import practicaldeepstereo_nips2018_amd as pds  # noqa: E402
 from practicaldeepstereo_nips2018_amd import _lib  # noqa: E402
-from practicaldeepstereo_nips2018_amd.distributed import ShardedMatching  # noqa: E402
+from practicaldeepstereo_nips2018_amd.distributed import ShardedHotPath, ShardedMatching  # noqa: E402
 
 HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
@@ -171,12 +174,24 @@ def main():
             dist.init_process_group(args.backend)
 
     net, ld_g, rd_g, sc_g, images = make_inputs(device)
-    matching = ShardedMatching(net._matching) if world > 1 else net._matching
     regularization, estimator = net._regularization, net._estimator
 
+    def tail(signatures, shortcut):
+        return regularization.forward_with_estimator(signatures, shortcut, estimator)
+
+    # N > 1: Matching sharded along the disparity axis + one all-gather per pair on every rank; the tail of
+    # pair i (Regularization + estimator, not shardable) runs on rank i % N on a side stream instead of being
+    # replicated N times (distributed.ShardedHotPath).
+    pipeline = ShardedHotPath(net._matching, tail) if world > 1 else None
+
     def step():
-        signatures = matching(ld_g, rd_g)
-        return regularization.forward_with_estimator(signatures, sc_g, estimator)
+        if pipeline is not None:
+            return pipeline.submit(ld_g, rd_g, sc_g)
+        return tail(net._matching(ld_g, rd_g), sc_g)
+
+    def finish():
+        if pipeline is not None:
+            pipeline.drain()
 
     def barrier():
         if world > 1:
@@ -205,19 +220,47 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             disparity = step()
+        finish()
         barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
+        mine = []
         for _ in range(args.steps):
             disparity = step()
+            if disparity is not None:
+                mine.append(disparity)
+        finish()
         torch.cuda.synchronize(device)
         barrier()
         elapsed = time.perf_counter() - t0
-    replica_elapsed = None
+    replica_elapsed = latency_elapsed = sharded_ok = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # untimed check: every disparity map this rank produced in the timed region equals the unsharded hot path
+        # on the same inputs bit for bit (same kernels, same planes)
+        with torch.no_grad():
+            unsharded_result = tail(net._matching(ld_g, rd_g), sc_g)
+        good = all(torch.equal(m, unsharded_result) for m in mine)
+        flag = torch.tensor([1.0 if good else 0.0, float(len(mine))], device=device, dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        sharded_ok = bool(flag[0].item() == world) and int(flag[1].item()) == args.steps
+        # latency mode, informational: one pair at a time, tail replicated on every rank (no overlap across pairs)
+        latency_matching = ShardedMatching(net._matching)
+        with torch.no_grad():
+            for _ in range(max(1, args.warmup // 2)):
+                tail(latency_matching(ld_g, rd_g), sc_g)
+            barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tail(latency_matching(ld_g, rd_g), sc_g)
+            torch.cuda.synchronize(device)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        latency_elapsed = float(t.item())
         # Second, informational mode: every rank runs the whole (unsharded) hot path on its own pair --
         # N independent replicas, no collective; aggregate throughput = N * steps / max time.
         unsharded = net._matching
@@ -248,7 +291,7 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
-            'ms_per_frame': ms_per_step,
+            'ms_per_frame': latency_elapsed / args.steps * 1e3 if latency_elapsed is not None else ms_per_step,
             'higher_is_better': True,
             'scaling': 'strong' if world > 1 else 'weak',
             'vs_baseline': None,
@@ -256,15 +299,21 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: 960x540 pair padded to 576x960, D=192 (48 matching planes, 96 cost '
                                    'planes), batch 1, eval mode, random-init weights seed 0',
-                       'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL)' % world)
+                       'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL) per pair; Regularization + '
+                                       'estimator of pair i on rank i %% %d, overlapped with the next pair' % (world, world))
                        if world > 1 else 'single GPU',
                        'launch': 'hip graph replay' if use_graph else 'eager'},
         }
+        if sharded_ok is not None:
+            line['sharded_equals_unsharded'] = sharded_ok
+            line['latency_mode'] = {'ms_per_frame': latency_elapsed / args.steps * 1e3,
+                                    'note': 'one pair at a time: sharded Matching + all-gather + tail replicated on '
+                                            'every rank, no overlap across pairs'}
         if replica_elapsed is not None:
             line['replica_mode'] = {'value': world * args.steps / replica_elapsed, 'unit': 'pairs/s',
                                     'ms_per_step': replica_elapsed / args.steps * 1e3, 'scaling': 'weak',
                                     'note': 'one independent pair per rank, no collective (throughput mode); '
-                                            '"value" above is the disparity-sharded latency mode of north_star'}
+                                            '"value" above is the disparity-sharded mode of north_star'}
         if world == 1:
             # informational: the whole PdsNetwork.forward (network.py:45-52: pad, descriptor network on both images,
             # hot path, crop), everything on the library; the headline value stays the hot path of the metric

@@ -68,3 +68,73 @@ class ShardedMatching(nn.Module):
         finally:
             self._matching.set_disparity_shard(None)
         return gather_planes(local, self._group)
+
+
+class ShardedHotPath(object):
+    """The whole hot path over N GPUs for a STREAM of stereo pairs.
+
+    Per pair: every rank evaluates its slice of the disparity planes and ONE all-gather reassembles the
+    matching signatures (exactly ``ShardedMatching``).  What cannot be sharded -- Regularization and the
+    estimator couple all planes -- is not replicated N times: the tail of pair ``i`` runs on rank
+    ``i % N`` only, on a side HIP stream, while every rank already matches pair ``i + 1`` on its main
+    stream.  Per pair and rank that is Matching / N + tail / N of GPU time instead of Matching / N + tail,
+    and the latency of one pair stays Matching / N + all-gather + tail.
+
+    ``tail(signatures, shortcut)`` is any callable, normally
+    ``lambda s, c: regularization.forward_with_estimator(s, c, estimator)``.  ``submit`` returns the
+    pair's result on its owner rank (a tensor that is valid once ``drain()`` -- or a wait on the side
+    stream -- has returned) and ``None`` on the other ranks.
+    """
+
+    def __init__(self, matching_module, tail, group=None, max_pending=4):
+        self._sharded = ShardedMatching(matching_module, group)
+        self._tail = tail
+        self._group = group
+        self._max_pending = max(1, int(max_pending))
+        self._submitted = 0
+        self._side = None
+        self._pending = []   # completion events of this rank's unfinished tails (GPU only)
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self._group), dist.get_world_size(self._group)
+        return 0, 1
+
+    def owner_of(self, pair_index):
+        return pair_index % self._world()[1]
+
+    def submit(self, left_embedding, right_embedding, shortcut_from_left):
+        rank, world = self._world()
+        index = self._submitted
+        self._submitted += 1
+        signatures = self._sharded(left_embedding, right_embedding)
+        if index % world != rank:
+            return None
+        if not signatures.is_cuda:
+            return self._tail(signatures, shortcut_from_left)
+        device = signatures.device
+        main = torch.cuda.current_stream(device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device)
+        # bounded backlog: the main stream waits for this rank's oldest unfinished tail before running ahead
+        while len(self._pending) >= self._max_pending:
+            main.wait_event(self._pending.pop(0))
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            result = self._tail(signatures, shortcut_from_left)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        # both were allocated on the main stream and are read on the side stream
+        signatures.record_stream(self._side)
+        shortcut_from_left.record_stream(self._side)
+        self._pending.append(done)
+        return result
+
+    def drain(self):
+        """Blocks the main stream (and the host) until every tail submitted on this rank has finished."""
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._side.synchronize()
+        self._pending = []

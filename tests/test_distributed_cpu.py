@@ -67,6 +67,52 @@ def worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
+def mock_tail(signatures, shortcut):
+    return (signatures * shortcut.unsqueeze(2)).sum(dim=(1, 2))
+
+
+def pipeline_worker(rank, world, port, results):
+    """ShardedHotPath: pair i's tail runs on rank i % world only and equals the unsharded result."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        hot_path = pdist.ShardedHotPath(CpuShardMatching(15), mock_tail)
+        ok = True
+        for i in range(5):
+            g = torch.Generator().manual_seed(10 + i)
+            left = torch.randn(1, 5, 6, 9, generator=g)
+            right = torch.randn(1, 5, 6, 9, generator=g)
+            shortcut = torch.randn(1, 1, 6, 9, generator=g)
+            out = hot_path.submit(left, right, shortcut)
+            if i % world == rank:
+                expected = mock_tail(oracle.matching(left, right, 15, mock_operation), shortcut)
+                ok = ok and out is not None and torch.equal(out, expected)
+            else:
+                ok = ok and out is None
+            ok = ok and hot_path.owner_of(i) == i % world
+        hot_path.drain()
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_hot_path_round_robin_tail(world):
+    if 16 % world != 0:
+        pytest.skip('16 planes do not divide over %d ranks' % world)
+    ctx = mp.get_context('spawn')
+    results = ctx.Manager().dict()
+    port = free_port()
+    procs = [ctx.Process(target=pipeline_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(results.get(r) for r in range(world)), dict(results)
+
+
 @pytest.mark.parametrize('world', [2, 4])
 def test_sharded_matching_equals_unsharded(world):
     ctx = mp.get_context('spawn')
