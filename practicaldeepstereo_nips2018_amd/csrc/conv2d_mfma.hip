@@ -217,6 +217,9 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
         if (more) PDS_FETCH(chunk + 1)
         const float* xin = buf + b_lane;
         const float* win = buf + IN_CHUNK + lane;
+#ifdef PDS_SETPRIO
+        __builtin_amdgcn_s_setprio(PDS_SETPRIO);
+#endif
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -234,6 +237,9 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
                         acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[m][j], 0, 0, 0);
             }
         }
+#ifdef PDS_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (more) PDS_STASH(chunk + 1, nxt)
         __syncthreads();
     }
