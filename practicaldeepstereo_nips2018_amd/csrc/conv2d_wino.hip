@@ -1,0 +1,318 @@
+// Winograd-domain variant of the dominant kernel: 3x3 stride-1 convolution Cin -> 64 over a stack of 2-D
+// planes (the 64 -> 64 layers of reference practical_deep_stereo/matching.py:85-88, network_blocks.py:47-58,
+// 97-103, 134-144), exact-fp32 MFMA, F(2,3) along x.
+//
+// Why: the direct kernel (conv2d_mfma.hip) sits on the chip's power/clock plateau -- issue
+// efficiency gained is returned as clock -- so the lever left is fewer MFMAs per output.  With the 1-D minimal
+// filtering algorithm F(2,3) two neighbouring outputs of a row cost 4 multiplies per (dy, ic, oc) instead of 6:
+//
+//   input  d0..d3 = x[2t-1 .. 2t+2]         V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3
+//   filter g0..g2 = w[dy][-1, 0, +1]        U0 = g0   U1 = (g0 + g1 + g2) / 2   U2 = (g0 - g1 + g2) / 2   U3 = g2
+//   M_p = sum over (dy, ic) of U_p * V_p    out[2t] = M0 + M1 + M2      out[2t + 1] = M1 - M2 - M3
+//
+//   GEMM view   per position p and row offset dy: M = output channels (16 per MFMA block, 4 blocks),
+//               N = 16 consecutive Winograd tiles (32 pixels) of a row, K = Cin; v_mfma_f32_16x16x4_f32.
+//               12 (p, dy) products per 2 pixels instead of 9 taps per pixel: 2/3 of the MFMAs.
+//   workgroup   4 waves; output tile 4 rows x 64 columns (32 tiles) of one (n, d) plane, all 64 channels;
+//               wave r owns row r: accumulators [4 positions][4 channel blocks][2 tile blocks] = 128 VGPRs.
+//   LDS         double-buffered [V of 4 channels: [ic][6 rows][4 positions][32 tiles] | U fragments of the chunk];
+//               the input transform (with the producer's deferred InstanceNorm and the literal zero padding)
+//               is applied while staging; the filter transform is part of the weight packing (pack.hip mode 3).
+//   epilogue    output transform, + bias, LeakyReLU(0.1), 8-byte stores, per-(plane, channel) sum / sum of
+//               squares partials in fp64 (one deterministic record per tile), as in conv2d_mfma.hip.
+// Rounding: transforms are additions and one exact halving; measured against the fp64 oracle the layer is as
+// close as the direct kernel to within a factor ~2 (tests/test_gpu_parity.py).
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int TH = 4, TWX = 64, NT = TWX / 2, NBT = NT / 16, KC = 4, MB = 4;
+constexpr int PS = NT;                    // floats between the 4 positions of one row
+constexpr int RSV = 4 * PS;               // row stride
+constexpr int CS = (TH + 2) * RSV + 16;   // channel stride, == 16 (mod 32): the two k-halves of a 32-lane group
+                                          // read disjoint banks
+constexpr int IN_CHUNK = KC * CS;
+constexpr int W_CHUNK = 12 * MB * 64;     // 12 (dy, p) products x 4 channel blocks x 64 lanes
+constexpr int BUF = IN_CHUNK + W_CHUNK;
+constexpr int THREADS = 256;
+constexpr int ITEMS = KC * (TH + 2) * NT;  // (channel, row, tile) items per chunk
+constexpr int IPT = ITEMS / THREADS;       // 3
+constexpr int W_ITERS = W_CHUNK / 4 / THREADS;
+static_assert(ITEMS % THREADS == 0 && (W_CHUNK / 4) % THREADS == 0, "staging must divide evenly");
+static_assert(CS % 32 == 16, "bank layout");
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoArgs {
+    Src a;
+    const float* __restrict__ wpk;   // [chunk][dy*4 + p][mb][64 lanes]
+    const float* __restrict__ bias;
+    float* __restrict__ out;
+    double* __restrict__ partials;
+    int N, Cin, D, H, W, Cout;
+    int lrelu;
+    int tiles_x, tiles;
+};
+
+__device__ __forceinline__ float row16_sum_w(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(THREADS, 2) void conv2d_wino_kernel(const WinoArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][V chunk | U chunk]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int d = blockIdx.y, n = blockIdx.z;
+    const int ty = tile / A.tiles_x, tx = tile % A.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TWX;
+    const size_t plane = (size_t)A.H * A.W;
+    const size_t cstride = (size_t)A.D * plane;
+    const int nchunks = A.Cin / KC;
+
+    // ---- staging map: thread -> IPT items (channel c of the chunk, halo row r, tile t); an item reads the four
+    // raw columns x0 - 1 + 2t .. x0 + 2 + 2t of input row y0 - 1 + r (clamped addresses, padding as a select)
+    int off[IPT][4], l_off[IPT], csub[IPT];
+    unsigned inmask[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int e = tid + k * THREADS;
+        const int c = e / ((TH + 2) * NT), pos = e % ((TH + 2) * NT);
+        const int r = pos / NT, t = pos % NT;
+        const int y = y0 - 1 + r;
+        const bool rowok = y >= 0 && y < A.H;
+        const int yc = min(max(y, 0), A.H - 1);
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 - 1 + 2 * t + j;
+            if (rowok && x >= 0 && x < A.W) m |= 1u << j;
+            off[k][j] = yc * A.W + min(max(x, 0), A.W - 1);
+        }
+        inmask[k] = m;
+        csub[k] = c;
+        l_off[k] = c * CS + r * RSV + t;
+    }
+    const float* pa = A.a.p + ((size_t)n * A.Cin * A.D + d) * plane;
+    const int wlast = W_CHUNK / 4 - 1;
+
+    float va[IPT][4], vs[IPT], vh[IPT];
+    f32x4 vw[W_ITERS];
+
+#define PDS_WFETCH(chunk_)                                                                           \
+    {                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < IPT; ++k) {                                            \
+            const int ch = (chunk_) * KC + csub[k];                                                  \
+            const float* src = pa + (size_t)ch * cstride;                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) va[k][j] = src[off[k][j]];                 \
+            if (A.a.scale) {                                                                         \
+                const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);        \
+                vs[k] = A.a.scale[g];                                                                \
+                vh[k] = A.a.shift[g];                                                                \
+            } else {                                                                                 \
+                vs[k] = 1.f;                                                                         \
+                vh[k] = 0.f;                                                                         \
+            }                                                                                        \
+        }                                                                                            \
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(A.wpk + (size_t)(chunk_) * W_CHUNK);       \
+        _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
+            vw[it] = wsrc[min(it * THREADS + tid, wlast)];                                           \
+    }
+
+#define PDS_WSTASH(buf_)                                                                             \
+    {                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < IPT; ++k) {                                            \
+            float dd[4];                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+                dd[j] = (inmask[k] >> j & 1u) ? fmaf(vs[k], va[k][j], vh[k]) : 0.f;                  \
+            float* dst = (buf_) + l_off[k];                                                          \
+            dst[0 * PS] = dd[0] - dd[2];                                                             \
+            dst[1 * PS] = dd[1] + dd[2];                                                             \
+            dst[2 * PS] = dd[2] - dd[1];                                                             \
+            dst[3 * PS] = dd[1] - dd[3];                                                             \
+        }                                                                                            \
+        f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + IN_CHUNK);                                   \
+        _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
+            wdst[min(it * THREADS + tid, wlast)] = vw[it];                                           \
+    }
+
+    f32x4 acc[4][MB][NBT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) acc[p][m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PDS_WFETCH(0)
+    PDS_WSTASH(lds)
+    __syncthreads();
+
+    const int b_lane = (lane >> 4) * CS + wave * RSV + (lane & 15);
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        float* buf = lds + (chunk & 1) * BUF;
+        float* nxt = lds + ((chunk + 1) & 1) * BUF;
+        const bool more = chunk + 1 < nchunks;
+        if (more) PDS_WFETCH(chunk + 1)
+        const float* xin = buf + b_lane;
+        const float* win = buf + IN_CHUNK + lane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float af[MB], bf[NBT];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) af[m] = win[((dy * 4 + p) * MB + m) * 64];
+#pragma unroll
+                for (int j = 0; j < NBT; ++j) bf[j] = xin[dy * RSV + p * PS + j * 16];
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int j = 0; j < NBT; ++j)
+                        acc[p][m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[p][m][j], 0, 0, 0);
+            }
+        }
+        if (more) PDS_WSTASH(nxt)
+        __syncthreads();
+    }
+#undef PDS_WFETCH
+#undef PDS_WSTASH
+
+    // ---- epilogue: output transform, bias, LeakyReLU, store, statistics ----------------------------------
+    const int y = y0 + wave;
+    const bool rowok = y < A.H;
+    const int jx = lane & 15, q = lane >> 4;
+    const bool pairs = (A.W & 1) == 0;  // rows start 8-byte aligned
+    float* red = lds;  // [4 waves][64 channels][2]
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = m * 16 + q * 4 + r;
+            const float bv = A.bias ? A.bias[oc] : 0.f;
+            float* po = A.out + (((size_t)n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W;
+            float s = 0.f, sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) {
+                const int x = x0 + 2 * (j * 16 + jx);
+                const float m0 = acc[0][m][j][r], m1 = acc[1][m][j][r], m2 = acc[2][m][j][r], m3 = acc[3][m][j][r];
+                float t0 = (m0 + m1) + m2 + bv;
+                float t1 = (m1 - m2) - m3 + bv;
+                if (A.lrelu) {
+                    t0 = t0 > 0.f ? t0 : t0 * kLeakySlope;
+                    t1 = t1 > 0.f ? t1 : t1 * kLeakySlope;
+                }
+                if (rowok && x + 1 < A.W && pairs) {
+                    *reinterpret_cast<float2*>(po + x) = make_float2(t0, t1);
+                    s += t0 + t1;
+                    sq = fmaf(t0, t0, fmaf(t1, t1, sq));
+                } else if (rowok) {
+                    if (x < A.W) {
+                        po[x] = t0;
+                        s += t0;
+                        sq = fmaf(t0, t0, sq);
+                    }
+                    if (x + 1 < A.W) {
+                        po[x + 1] = t1;
+                        s += t1;
+                        sq = fmaf(t1, t1, sq);
+                    }
+                }
+            }
+            if (A.partials) {
+                s = row16_sum_w(s);
+                sq = row16_sum_w(sq);
+                if (jx == 15) {
+                    red[((wave * MB * 16) + oc) * 2 + 0] = s;
+                    red[((wave * MB * 16) + oc) * 2 + 1] = sq;
+                }
+            }
+        }
+    }
+    if (A.partials) {
+        __syncthreads();
+        if (tid < MB * 16 * 2) {
+            const int oc = tid >> 1, k = tid & 1;
+            double v = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) v += (double)red[((wv * MB * 16) + oc) * 2 + k];
+            A.partials[((((size_t)n * A.Cout + oc) * A.D + d) * A.tiles + tile) * 2 + k] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+bool conv2d_wino_eligible(const ConvLayer& L) {
+    static const bool enabled = []() {  // PDS_WINOGRAD=0 selects the direct kernel (A/B, debugging)
+        const char* e = getenv("PDS_WINOGRAD");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return false;
+    if (L.kd != 1 || L.stride != 1 || L.out_g.c != 64) return false;
+    if (L.in.c % KC != 0 || L.in.c > 256) return false;
+    if (L.b.p || L.l0A || L.side_out || L.plane_weight_sets > 0) return false;
+    if ((size_t)L.in.d * L.in.h * L.in.w * KC >= ((size_t)1 << 31)) return false;
+    if (L.in.d > 65535 || L.in.n > 65535) return false;
+    return true;
+}
+
+int conv2d_wino_tiles(const Geom& o) { return ((o.h + TH - 1) / TH) * ((o.w + TWX - 1) / TWX); }
+
+size_t conv2d_wino_packed_floats(int cin, int cout) { return (size_t)(cin / KC) * W_CHUNK; }
+
+int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
+    if (!L.packed) return set_error(-1, "conv2d_wino: packed weights missing");
+    const int total = (int)conv2d_wino_packed_floats(L.in.c, L.out_g.c);
+    const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+    if (phase != kPackDone) {
+        PackJob j;
+        j.src = L.weight;
+        j.dst = L.packed;
+        j.cout = L.out_g.c;
+        j.cin = L.in.c;
+        j.mblocks = MB;
+        j.kc = KC;
+        j.taps = 12;
+        j.mode = 3;  // F(2,3) filter transform along x
+        j.total = total;
+        if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
+        if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+    }
+    WinoArgs A;
+    A.a = L.a;
+    A.wpk = L.packed;
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.N = L.in.n;
+    A.Cin = L.in.c;
+    A.D = L.in.d;
+    A.H = L.in.h;
+    A.W = L.in.w;
+    A.Cout = L.out_g.c;
+    A.lrelu = L.lrelu;
+    A.tiles_x = (A.W + TWX - 1) / TWX;
+    A.tiles = conv2d_wino_tiles(L.out_g);
+    const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv2d_wino_kernel, dim3(A.tiles, A.D, A.N), dim3(THREADS), lds_bytes, s, A);
+    return check_launch("conv2d_wino");
+}
+
+}  // namespace pds

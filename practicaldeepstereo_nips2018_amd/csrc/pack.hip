@@ -36,7 +36,7 @@ __device__ __forceinline__ bool deconv_tap_valid(int mode, int cls, int tap, int
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const PackJob J = T.j[blockIdx.y];
     const int ks_n = J.kc / 4;
-    const int ncls = J.mode == 1 ? 8 : (J.mode == 2 ? 4 : 1);
+    const int ncls = J.mode == 1 ? 8 : (J.mode == 2 ? 4 : 1);  // modes 0 and 3: plain convolutions
     const int kdn = J.mode == 1 ? 4 : 3;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
@@ -54,6 +54,14 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
         float val = 0.f;
         if (J.mode == 0) {
             if (v < J.cout && c < J.cin) val = J.src[((size_t)v * J.cin + c) * J.taps + tap];
+        } else if (J.mode == 3) {
+            // F(2,3) filter transform along x of a 3x3 kernel (conv2d_wino.hip): tap = dy * 4 + position
+            if (v < J.cout && c < J.cin) {
+                const float* g = J.src + ((size_t)v * J.cin + c) * 9 + (tap >> 2) * 3;
+                const double g0 = g[0], g1 = g[1], g2 = g[2];
+                const int pos = tap & 3;
+                val = pos == 0 ? g[0] : pos == 3 ? g[2] : (float)(pos == 1 ? 0.5 * (g0 + g1 + g2) : 0.5 * (g0 - g1 + g2));
+            }
         } else if (v < ncls * J.cout && c < J.cin) {
             const int cls = v / J.cout, oc = v % J.cout;
             int kd, kh, kw;
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
         J.dst[e] = val;
     }
     // tap masks of the transposed convolutions: one 27-bit word per 16-channel block
-    if (J.mode != 0 && blockIdx.x == 0) {
+    if ((J.mode == 1 || J.mode == 2) && blockIdx.x == 0) {
         for (int mb = threadIdx.x; mb < J.mblocks; mb += 256) {
             unsigned m = 0;
             for (int i = 0; i < 16; ++i) {

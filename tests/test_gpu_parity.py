@@ -264,9 +264,22 @@ def test_config1_hot_path_vs_golden(dev):
     assert ms.shape == (1, 8, 16, 32, 64) and cost.shape == (1, 32, 128, 256)
     assert helpers.maxdiff(ms[:, :, ::2, ::4, ::4], g['signatures_sub']) <= TOL_SIGNATURES
     assert helpers.maxdiff(cost[:, ::4, ::8, ::8], g['cost_sub']) <= TOL_COST_MAX
+    # End-to-end disparity: on 32 768 pixels ONE flipped arg-max (a near-tie of the random-weight cost volume
+    # resolved the other way, ~30 px) is already 9e-4 of MAE, so the raw MAE is printed and loosely bounded while
+    # the gates are the smooth error, the number of flips, and the fp64 arbiter (as for config 2 below).
     rep = helpers.disparity_report(disparity, g['disparity'])
     print('config1 disparity', rep)
-    assert rep['mae'] <= TOL_DISPARITY_MAE, rep
+    assert rep['mae_noflip'] <= 1e-4, rep
+    assert rep['flips'] <= 1e-4, rep           # at most 3 pixels
+    assert rep['mae'] <= 5e-3, rep
+    p32 = {k: v.cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        disp64 = oracle.hot_path(oracle.cast_params(p32, torch.float64), ld.double(), rd.double(),
+                                 shortcut.double(), 63)
+    cpu64 = helpers.disparity_report(g['disparity'], disp64)
+    gpu64 = helpers.disparity_report(disparity, disp64)
+    print('config1 arbiter: reference fp32 vs fp64', cpu64, ' gpu vs fp64', gpu64)
+    assert gpu64['mae_noflip'] <= 1e-4 and gpu64['flips'] <= cpu64['flips'] + 1e-4, (gpu64, cpu64)
     # estimator alone on the identical (GPU) cost volume
     est = oracle.subpixel_map(cost.cpu())
     assert helpers.maxdiff(disparity, est) <= TOL_EST_MAX
