@@ -36,14 +36,30 @@ constexpr int CS = (TH + 2) * RSV + 16;   // channel stride, == 16 (mod 32): the
 constexpr int IN_CHUNK = KC * CS;
 constexpr int W_CHUNK = 12 * MB * 64;     // 12 (dy, p) products x 4 channel blocks x 64 lanes
 constexpr int BUF = IN_CHUNK + W_CHUNK;
-constexpr int THREADS = 256;
-constexpr int ITEMS = KC * (TH + 2) * NT;  // (channel, row, tile) items per chunk
-constexpr int IPT = ITEMS / THREADS;       // 3
-constexpr int W_ITERS = W_CHUNK / 4 / THREADS;
-static_assert(ITEMS % THREADS == 0 && (W_CHUNK / 4) % THREADS == 0, "staging must divide evenly");
+constexpr int ITEMS = KC * (TH + 2) * NT;  // (channel, row, tile) items per chunk: 768
+static_assert(ITEMS % 64 == 0 && ((TH + 2) * NT) % 64 == 0, "a wave stages whole rows of one channel");
 static_assert(CS % 32 == 16, "bank layout");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// timing-decomposition hooks (tools/build_variant.sh): any of them set makes the results wrong
+#ifdef PDS_X_NOLOADIN
+#define PDS_X_LOADIN(x) (float)(tid)
+#define PDS_X_LOADIN2(x) make_float2((float)tid, 1.f)
+#else
+#define PDS_X_LOADIN(x) (x)
+#define PDS_X_LOADIN2(x) (x)
+#endif
+#ifdef PDS_X_NOLOADW
+#define PDS_X_LOADW(x) f32x4{(float)tid, 1.f, 2.f, 3.f}
+#else
+#define PDS_X_LOADW(x) (x)
+#endif
+#ifdef PDS_X_NOMFMA
+#define PDS_X_MFMA(c, a, b) (c)[0] += (a) * (b)
+#else
+#define PDS_X_MFMA(c, a, b) (c) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
 
 struct WinoArgs {
     Src a;
@@ -64,14 +80,31 @@ __device__ __forceinline__ float row16_sum_w(float v) {
     return v;
 }
 
+// lane i receives lane i - 1 (DPP wave_shr:1) / lane i + 1 (DPP wave_shl:1): whole-wave shifts of GFX9, no LDS
+__device__ __forceinline__ float wave_shift_up(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_shift_down(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
 }  // namespace
 
-__global__ __launch_bounds__(THREADS, 2) void conv2d_wino_kernel(const WinoArgs A) {
+// NORM: the source carries a deferred InstanceNorm (scale / shift per channel or per (channel, plane)).
+// HALVES: 1 = 4 waves, wave r owns row r and all 64 output channels (128 accumulator registers, 2 waves/SIMD);
+//         2 = 8 waves, wave (r, half) owns row r and 32 output channels (64 accumulator registers, 4 waves/SIMD).
+template <bool NORM, int HALVES>
+__global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(const WinoArgs A) {
+    constexpr int THREADS = 256 * HALVES;
+    constexpr int MBW = MB / HALVES;                              // channel blocks per wave
+    constexpr int IPT = (ITEMS + THREADS - 1) / THREADS;          // 3 or 2 (the last one only on waves 0-3)
+    constexpr int W_ITERS = (W_CHUNK / 4 + THREADS - 1) / THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][V chunk | U chunk]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3, half = wave_id >> 2;
     const int tile = blockIdx.x;
     const int d = blockIdx.y, n = blockIdx.z;
     const int ty = tile / A.tiles_x, tx = tile % A.tiles_x;
@@ -80,77 +113,90 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino_kernel(const WinoArgs 
     const size_t cstride = (size_t)A.D * plane;
     const int nchunks = A.Cin / KC;
 
-    // ---- staging map: thread -> IPT items (channel c of the chunk, halo row r, tile t); an item reads the four
-    // raw columns x0 - 1 + 2t .. x0 + 2 + 2t of input row y0 - 1 + r (clamped addresses, padding as a select)
-    int off[IPT][4], l_off[IPT], csub[IPT];
-    unsigned inmask[IPT];
+    // ---- staging map: thread -> IPT items (channel c of the chunk, halo row r, tile t).  64 | 6 * 32, so a wave's
+    // 64 consecutive items are two full rows of one channel and t == lane & 31 for every item.  An item loads the
+    // aligned pair (d1, d2) = x[x0 + 2t, x0 + 2t + 1] with ONE 8-byte load (fully coalesced rows); d0 and d3 are the
+    // neighbouring lanes' d2 / d1, except at the ends of the row segment (t == 0 / 31), whose halo value comes from
+    // one extra 4-byte load.  Addresses are clamped, padding is a select, offsets are 32-bit relative to a pointer
+    // that is uniform per chunk.
+    unsigned offp[IPT], offe[IPT], goff[IPT];
+    int l_off[IPT];
+    bool in1[IPT], in2[IPT], ine[IPT];
+    const unsigned gstride = NORM ? (A.a.per_plane ? (unsigned)A.D : 1u) : 0u;
+    const int t = lane & 31;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        const int e = tid + k * THREADS;
-        const int c = e / ((TH + 2) * NT), pos = e % ((TH + 2) * NT);
-        const int r = pos / NT, t = pos % NT;
+        const int e = min(tid + k * THREADS, ITEMS - 1);  // surplus items (8-wave form) are skipped below
+        const int c = e / ((TH + 2) * NT), r = (e % ((TH + 2) * NT)) / NT;
         const int y = y0 - 1 + r;
         const bool rowok = y >= 0 && y < A.H;
         const int yc = min(max(y, 0), A.H - 1);
-        unsigned m = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = x0 - 1 + 2 * t + j;
-            if (rowok && x >= 0 && x < A.W) m |= 1u << j;
-            off[k][j] = yc * A.W + min(max(x, 0), A.W - 1);
-        }
-        inmask[k] = m;
-        csub[k] = c;
+        const int x = x0 + 2 * t;                       // d1; d2 = x + 1 (W is even: both or neither inside)
+        const int xe = t == 0 ? x0 - 1 : x0 + TWX;      // halo value of the row segment (used by t == 0 / 31)
+        in1[k] = rowok && x < A.W;
+        in2[k] = rowok && x + 1 < A.W;
+        ine[k] = rowok && xe >= 0 && xe < A.W && (t == 0 || t == NT - 1);
+        const unsigned rowbase = (unsigned)c * (unsigned)cstride + (unsigned)(yc * A.W);
+        offp[k] = rowbase + (unsigned)min(x, A.W - 2);
+        offe[k] = rowbase + (unsigned)((t == 0 || t == NT - 1) ? min(max(xe, 0), A.W - 1) : min(x, A.W - 2));
+        goff[k] = (unsigned)c * gstride;
         l_off[k] = c * CS + r * RSV + t;
     }
     const float* pa = A.a.p + ((size_t)n * A.Cin * A.D + d) * plane;
+    const size_t chunk_stride = (size_t)KC * cstride;
+    const float* ps = NORM ? A.a.scale + (A.a.per_plane ? ((size_t)n * A.Cin * A.D + d) : (size_t)n * A.Cin) : nullptr;
+    const float* ph = NORM ? A.a.shift + (A.a.per_plane ? ((size_t)n * A.Cin * A.D + d) : (size_t)n * A.Cin) : nullptr;
     const int wlast = W_CHUNK / 4 - 1;
 
-    float va[IPT][4], vs[IPT], vh[IPT];
+    float2 vp[IPT];
+    float ve[IPT], vs[IPT], vh[IPT];
     f32x4 vw[W_ITERS];
 
 #define PDS_WFETCH(chunk_)                                                                           \
     {                                                                                                \
+        const float* src = pa + (size_t)(chunk_) * chunk_stride;          /* uniform */              \
+        const float* ssrc = NORM ? ps + (size_t)(chunk_) * KC * gstride : nullptr;                   \
+        const float* hsrc = NORM ? ph + (size_t)(chunk_) * KC * gstride : nullptr;                   \
         _Pragma("unroll") for (int k = 0; k < IPT; ++k) {                                            \
-            const int ch = (chunk_) * KC + csub[k];                                                  \
-            const float* src = pa + (size_t)ch * cstride;                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) va[k][j] = src[off[k][j]];                 \
-            if (A.a.scale) {                                                                         \
-                const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);        \
-                vs[k] = A.a.scale[g];                                                                \
-                vh[k] = A.a.shift[g];                                                                \
-            } else {                                                                                 \
-                vs[k] = 1.f;                                                                         \
-                vh[k] = 0.f;                                                                         \
+            if ((k + 1) * THREADS > ITEMS && tid + k * THREADS >= ITEMS) continue;                   \
+            vp[k] = PDS_X_LOADIN2(*reinterpret_cast<const float2*>(src + offp[k]));                  \
+            ve[k] = PDS_X_LOADIN(src[offe[k]]);                                                      \
+            if (NORM) {                                                                              \
+                vs[k] = ssrc[goff[k]];                                                               \
+                vh[k] = hsrc[goff[k]];                                                               \
             }                                                                                        \
         }                                                                                            \
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(A.wpk + (size_t)(chunk_) * W_CHUNK);       \
         _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
-            vw[it] = wsrc[min(it * THREADS + tid, wlast)];                                           \
+            vw[it] = PDS_X_LOADW(wsrc[min(it * THREADS + tid, wlast)]);                               \
     }
 
 #define PDS_WSTASH(buf_)                                                                             \
     {                                                                                                \
         _Pragma("unroll") for (int k = 0; k < IPT; ++k) {                                            \
-            float dd[4];                                                                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
-                dd[j] = (inmask[k] >> j & 1u) ? fmaf(vs[k], va[k][j], vh[k]) : 0.f;                  \
+            if ((k + 1) * THREADS > ITEMS && tid + k * THREADS >= ITEMS) continue;                   \
+            const float d1 = in1[k] ? (NORM ? fmaf(vs[k], vp[k].x, vh[k]) : vp[k].x) : 0.f;          \
+            const float d2 = in2[k] ? (NORM ? fmaf(vs[k], vp[k].y, vh[k]) : vp[k].y) : 0.f;          \
+            const float de = ine[k] ? (NORM ? fmaf(vs[k], ve[k], vh[k]) : ve[k]) : 0.f;              \
+            const float up = wave_shift_up(d2), dn = wave_shift_down(d1);                            \
+            const float d0 = t == 0 ? de : up;                                                       \
+            const float d3 = t == NT - 1 ? de : dn;                                                  \
             float* dst = (buf_) + l_off[k];                                                          \
-            dst[0 * PS] = dd[0] - dd[2];                                                             \
-            dst[1 * PS] = dd[1] + dd[2];                                                             \
-            dst[2 * PS] = dd[2] - dd[1];                                                             \
-            dst[3 * PS] = dd[1] - dd[3];                                                             \
+            dst[0 * PS] = d0 - d2;                                                                   \
+            dst[1 * PS] = d1 + d2;                                                                   \
+            dst[2 * PS] = d2 - d1;                                                                   \
+            dst[3 * PS] = d1 - d3;                                                                   \
         }                                                                                            \
         f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + IN_CHUNK);                                   \
         _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
             wdst[min(it * THREADS + tid, wlast)] = vw[it];                                           \
     }
 
-    f32x4 acc[4][MB][NBT];
+    f32x4 acc[4][MBW][NBT];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MBW; ++m)
 #pragma unroll
             for (int j = 0; j < NBT; ++j) acc[p][m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -166,21 +212,21 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino_kernel(const WinoArgs 
         const bool more = chunk + 1 < nchunks;
         if (more) PDS_WFETCH(chunk + 1)
         const float* xin = buf + b_lane;
-        const float* win = buf + IN_CHUNK + lane;
+        const float* win = buf + IN_CHUNK + half * MBW * 64 + lane;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                float af[MB], bf[NBT];
+                float af[MBW], bf[NBT];
 #pragma unroll
-                for (int m = 0; m < MB; ++m) af[m] = win[((dy * 4 + p) * MB + m) * 64];
+                for (int m = 0; m < MBW; ++m) af[m] = win[((dy * 4 + p) * MB + m) * 64];
 #pragma unroll
                 for (int j = 0; j < NBT; ++j) bf[j] = xin[dy * RSV + p * PS + j * 16];
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+                for (int m = 0; m < MBW; ++m)
 #pragma unroll
                     for (int j = 0; j < NBT; ++j)
-                        acc[p][m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[p][m][j], 0, 0, 0);
+                        PDS_X_MFMA(acc[p][m][j], af[m], bf[j]);
             }
         }
         if (more) PDS_WSTASH(nxt)
@@ -194,12 +240,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino_kernel(const WinoArgs 
     const bool rowok = y < A.H;
     const int jx = lane & 15, q = lane >> 4;
     const bool pairs = (A.W & 1) == 0;  // rows start 8-byte aligned
-    float* red = lds;  // [4 waves][64 channels][2]
+    float* red = lds;  // [4 rows][64 channels][2]
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
+    for (int m = 0; m < MBW; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int oc = m * 16 + q * 4 + r;
+            const int oc = (half * MBW + m) * 16 + q * 4 + r;
             const float bv = A.bias ? A.bias[oc] : 0.f;
             float* po = A.out + (((size_t)n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W;
             float s = 0.f, sq = 0.f;
@@ -262,6 +308,7 @@ bool conv2d_wino_eligible(const ConvLayer& L) {
     if (L.kd != 1 || L.stride != 1 || L.out_g.c != 64) return false;
     if (L.in.c % KC != 0 || L.in.c > 256) return false;
     if (L.b.p || L.l0A || L.side_out || L.plane_weight_sets > 0) return false;
+    if (L.in.w % 2 != 0 || L.in.w < 2) return false;  // rows are read as aligned 8-byte pairs
     if ((size_t)L.in.d * L.in.h * L.in.w * KC >= ((size_t)1 << 31)) return false;
     if (L.in.d > 65535 || L.in.n > 65535) return false;
     return true;
@@ -305,13 +352,31 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     A.tiles_x = (A.W + TWX - 1) / TWX;
     A.tiles = conv2d_wino_tiles(L.out_g);
     const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
+    static const int halves = []() {  // PDS_WINO_WAVES=4 selects the 4-wave form (A/B)
+        const char* e = getenv("PDS_WINO_WAVES");
+        return (e && e[0] == '4') ? 1 : 2;
+    }();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        const int bytes = (int)(160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv2d_wino_kernel, dim3(A.tiles, A.D, A.N), dim3(THREADS), lds_bytes, s, A);
+    const dim3 grid(A.tiles, A.D, A.N);
+    if (halves == 2) {
+        if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2>), grid, dim3(512), lds_bytes, s, A);
+        else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2>), grid, dim3(512), lds_bytes, s, A);
+    } else {
+        if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 1>), grid, dim3(256), lds_bytes, s, A);
+        else hipLaunchKernelGGL((conv2d_wino_kernel<false, 1>), grid, dim3(256), lds_bytes, s, A);
+    }
     return check_launch("conv2d_wino");
 }
 
