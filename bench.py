@@ -17,7 +17,8 @@ are reported beside it.  Rank 0 prints ONE JSON line.
 The line also carries
   roofline     - the dominant kernel (conv2d 3x3 64->64 over all disparity planes, fp32 MFMA): its
                  launch is timed in isolation with HIP events through pds_conv_block_fwd;
-                 achieved = 122.31 GFLOP per launch / mean duration against the 157.3 TFLOP/s peak.
+                 achieved = 122.31 algorithmic GFLOP per launch / mean duration against the 157.3 TFLOP/s
+                 peak (the kernel works in the Winograd domain and executes 2/3 of them: executed_tflops).
   cpu_baseline - the oracle (oracle/pds_oracle.py, PyTorch-CPU restatement of the reference) on the
                  same inputs on this host's cores (rank 0, N=1 only), and the parity of the GPU result
                  against it.
@@ -44,9 +45,12 @@ HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 # dense 2*MAC count of one 64->64 3x3 convolution over [1, 64, 48, 144, 240] (122.31 GF)
 CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
-# HBM bytes per launch of that kernel from the PMC counters (profiles/r01_conv64_pmc.txt); a recorded
+# HBM bytes per launch of that kernel from the PMC counters (profiles/r01_conv64_wino_pmc.txt); a recorded
 # measurement, not re-collected by this script (counters need rocprofv3 around the process)
-CONV64_HBM_BYTES = 884.3e6
+CONV64_HBM_BYTES = 961.5e6
+# The layer runs in the Winograd domain (csrc/conv2d_wino.hip, F(2,3) along x): 2/3 of the multiplies of the direct
+# form, over 64-column tiles (256 columns computed for 240)
+CONV64_EXECUTED_GFLOP = CONV64_GFLOP * (2.0 / 3.0) * (256.0 / 240.0)
 
 
 def parse():
@@ -334,8 +338,17 @@ def main():
                             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                             'traffic': CONV64_HBM_BYTES, 'traffic_unit': 'bytes per launch',
                             'traffic_source': 'rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes, see '
-                                              'profiles/r01_conv64_pmc.txt (algorithmic 849e6)',
-                            'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP}
+                                              'profiles/r01_conv64_wino_pmc.txt (algorithmic 849e6)',
+                            'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP,
+                            'algorithm': 'Winograd F(2,3) along x on the fp32 MFMA units: "achieved" counts the '
+                                         'ALGORITHMIC flops of the direct convolution; the MFMA pipe executes '
+                                         'executed_gflop_per_launch',
+                            'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
+                            'executed_tflops': CONV64_EXECUTED_GFLOP / kernel_ms}
+        if os.environ.get('PDS_WINOGRAD', '1')[:1] == '0':
+            line['roofline']['algorithm'] = 'direct implicit GEMM (PDS_WINOGRAD=0)'
+            line['roofline']['executed_gflop_per_launch'] = CONV64_GFLOP
+            line['roofline']['executed_tflops'] = achieved
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(net, ld_g.cpu(), rd_g.cpu(), sc_g.cpu(), disparity)
             line['cpu_baseline'] = base
