@@ -246,6 +246,7 @@ def main():
         # on the same inputs bit for bit (same kernels, same planes)
         with torch.no_grad():
             unsharded_result = tail(net._matching(ld_g, rd_g), sc_g)
+        torch.cuda.synchronize(device)
         good = all(torch.equal(m, unsharded_result) for m in mine)
         flag = torch.tensor([1.0 if good else 0.0, float(len(mine))], device=device, dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
