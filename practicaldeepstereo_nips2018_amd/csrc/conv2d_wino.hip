@@ -105,8 +105,19 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_id & 3, half = wave_id >> 2;
-    const int tile = blockIdx.x;
-    const int d = blockIdx.y, n = blockIdx.z;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, so
+    // the launch index is re-mapped to make every XCD work on whole planes: neighbouring tiles (shared halo rows)
+    // and the plane's statistics stay in one L2.  Needs D % 8 == 0; otherwise the identity mapping.
+    int tile = blockIdx.x, d = blockIdx.y;
+    const int n = blockIdx.z;
+#ifndef PDS_WINO_NO_XCD_MAP
+    if ((A.D & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3;
+        d = (slot / A.tiles) * 8 + xcd;
+        tile = slot % A.tiles;
+    }
+#endif
     const int ty = tile / A.tiles_x, tx = tile % A.tiles_x;
     const int y0 = ty * TH, x0 = tx * TWX;
     const size_t plane = (size_t)A.H * A.W;

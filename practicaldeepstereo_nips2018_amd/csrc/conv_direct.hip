@@ -507,8 +507,83 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
     }
 }
 
+// Plane-sweeping form of the above for rows that are a multiple of 4 wide: one thread owns four consecutive x of
+// one (n, c, y) for ALL disparity planes.  A is loaded once.  The four G values of a thread, G[x - d] for its x, form
+// a window that slides by one column per plane: the value entering on the left is the neighbouring lane's right-most
+// one (a whole-wave DPP shift), so only lane 0 of a wave and the first quad of a row load it.  The streaming traffic
+// is one 16-byte load of a and one 16-byte store per plane (the per-plane G loads of the first version cost as
+// much as that stream: 276 -> 157 us without them).
+__global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, const Geom g, const float* __restrict__ A,
+                                                                   const float* __restrict__ G,
+                                                                   const float* __restrict__ G2, size_t l0_cstride,
+                                                                   int d_begin, float* __restrict__ out) {
+    const int nc = blockIdx.y;
+    const int n = nc / g.c, c = nc % g.c;
+    const size_t px = g.plane();
+    const int xq = g.w / 4;
+    const int total = g.h * xq;
+    const int q = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);  // surplus threads shadow the last quad
+    const bool active = (int)(blockIdx.x * 256 + threadIdx.x) < total;
+    const int y = q / xq, xi = q - y * xq, x0 = xi * 4;
+    const size_t i = (size_t)y * g.w + x0;
+    const size_t row = (size_t)y * (g.w + 1);
+    const float* pa = a.p + (size_t)nc * g.d * px + i;
+    float* po = out + (size_t)nc * g.d * px + i;
+    const float* pA = A + (size_t)nc * l0_cstride + row + x0;   // already at column 1
+    const float* pG = G + (size_t)nc * l0_cstride + row;        // column u + 1 holds G[u], u >= -1
+    const float* pG2 = G2 + (size_t)nc * l0_cstride + row;
+    float lv[4], gw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lv[k] = pA[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = x0 + k - d_begin;
+        gw[k] = u >= -1 ? pG[u + 1] : 0.f;
+    }
+    const bool last_quad = x0 + 4 == g.w;
+    const bool loads_left = xi == 0 || (threadIdx.x & 63) == 0;  // no left neighbour in this wave / this row
+    constexpr int UN = 4;
+    for (int d0 = 0; d0 < g.d; d0 += UN) {
+        float4 t[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j)
+            if (d0 + j < g.d) t[j] = *reinterpret_cast<const float4*>(pa + (size_t)(d0 + j) * px);
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int d = d0 + j;
+            if (d >= g.d) break;
+            float sa, ha;
+            src_coeffs(a, n, g.c, c, g.d, d, sa, ha);
+            const int disp = d_begin + d;
+            // right-most column of the image: the dx = +1 taps of the right descriptor do not exist there (G2)
+            float g3 = gw[3];
+            if (last_quad && disp >= 1) g3 = disp <= g.w ? pG2[g.w - disp] : 0.f;  // u = w - 1 - disp >= -1
+            const float4 r = make_float4(fmaf(sa, t[j].x, ha) + (lv[0] + gw[0]), fmaf(sa, t[j].y, ha) + (lv[1] + gw[1]),
+                                         fmaf(sa, t[j].z, ha) + (lv[2] + gw[2]), fmaf(sa, t[j].w, ha) + (lv[3] + g3));
+            if (active) *reinterpret_cast<float4*>(po + (size_t)d * px) = r;
+            // slide the window to disparity disp + 1
+            const float from_left = __builtin_bit_cast(
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw[3]), 0x138, 0xf, 0xf, true));
+            gw[3] = gw[2];
+            gw[2] = gw[1];
+            gw[1] = gw[0];
+            gw[0] = from_left;
+            if (loads_left) {
+                const int u = x0 - (disp + 1);
+                gw[0] = u >= -1 ? pG[u + 1] : 0.f;
+            }
+        }
+    }
+}
+
 int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
                           size_t l0_cstride, int d_begin, float* out, hipStream_t s) {
+    if ((g.w & 3) == 0) {
+        const int quads = g.h * (g.w / 4);
+        hipLaunchKernelGGL(materialize_l0_sweep_kernel, dim3((quads + 255) / 256, g.n * g.c), dim3(256), 0, s, a, g, A, G,
+                           G2, l0_cstride, d_begin, out);
+        return check_launch("materialize_l0");
+    }
     const int quads = g.h * ((g.w + 3) / 4);
     unsigned bx = (unsigned)((quads + 255) / 256);
     if (bx > 64) bx = 64;
