@@ -228,9 +228,20 @@ __global__ __launch_bounds__(256) void l1_weights_kernel(const float* __restrict
 }
 
 // t1[n,o,d,y,x] = LeakyReLU(B + T_d) and partial sums (records [(n*C+o)*D + d][tile] x {sum, sumsq}).
-// One thread owns four consecutive x of one row for ALL disparity planes: B is loaded once, the H rows come
-// from L1, and the only streaming traffic is the 16-byte stores of t1.
+// One thread owns four consecutive x of one row for ALL disparity planes: B is loaded once; the four H values of a
+// thread, H[x - d] for its x, form a window that slides by one column per plane, the entering value being the
+// left neighbour lane's right-most one (whole-wave DPP shift; only lane 0 of a wave and the first quad of a row load
+// it, and the last quad loads its two special columns from Ha / Hb).  The only streaming traffic is the 16-byte
+// stores of t1; per-plane statistics are reduced with DPP row sums (no LDS permutes).
 constexpr int kL1MaxPlanes = 64;  // disparity planes handled per launch (statistics scratch in LDS)
+__device__ __forceinline__ float l1_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;  // lane 15 of every 16-lane row holds the row's total
+}
+
 __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict__ y4, float* __restrict__ t1,
                                                          double* __restrict__ partials, int C, int h, int w,
                                                          int d_begin, int d_first, int d_launch, int d_count) {
@@ -243,34 +254,46 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
     const float* Ha = Hp + (size_t)h * W2;
     const float* Hb = Ha + (size_t)h * W2;
     const float* H0 = Hb + (size_t)h * W2;
-    __shared__ float red[kL1MaxPlanes][4][2];
+    __shared__ float red[kL1MaxPlanes][16][2];   // [plane][wave * 4 + DPP row]
     const int xq = (w + 3) / 4;
     const bool vec = (w & 3) == 0;
     const int qi = tile * 256 + threadIdx.x;
     const bool active = qi < h * xq;
-    const int y = active ? qi / xq : 0, xb = active ? (qi - y * xq) * 4 : 0;
+    const int y = active ? qi / xq : 0, xi = active ? qi - y * xq : 0, xb = xi * 4;
     const size_t row = (size_t)y * W2;
-    float bq[4];
+    float bq[4], hw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) bq[k] = (active && xb + k < w) ? Bp[row + xb + k + 2] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool loads_left = xi == 0 || lane == 0;
+    const int d0 = d_begin + d_first;  // disparity of the first plane of this launch
+    // window for the first plane: hw[k] = Hp[x_k - d0] (column u + 2 holds H[u], u >= -2)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = xb + k - d0;
+        hw[k] = (active && xb + k < w && u >= -2) ? Hp[row + u + 2] : 0.f;
+    }
     for (int di = 0; di < d_launch; ++di) {
         const int dl = d_first + di;
         const int d = d_begin + dl;
         float r[4], s = 0.f, q = 0.f;
+        float tk[4] = {hw[0], hw[1], hw[2], hw[3]};
+        if (d == 0) {  // the image border is padding at zero disparity: its own H plane
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tk[k] = (active && xb + k < w) ? H0[row + xb + k + 2] : 0.f;
+        } else {
+            // the two right-most columns of the image take their terms from Ha / Hb
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = xb + k, u = x - d;
+                if (active && x >= w - 2 && x < w) tk[k] = u >= -2 ? (x == w - 2 ? Ha : Hb)[row + u + 2] : 0.f;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int x = xb + k;
             float v = 0.f;
-            if (active && x < w) {
-                const int u = x - d;
-                v = bq[k];
-                if (d == 0) {
-                    v += H0[row + x + 2];
-                } else if (u >= -2) {
-                    const float* sel = (x == w - 2) ? Ha : ((x == w - 1) ? Hb : Hp);
-                    v += sel[row + u + 2];
-                }
+            if (active && xb + k < w) {
+                v = bq[k] + tk[k];
                 v = v > 0.f ? v : v * kLeakySlope;
                 s += v;
                 q = fmaf(v, v, q);
@@ -287,20 +310,30 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
                     if (xb + k < w) o[k] = r[k];
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s += __shfl_xor(s, off, 64);
-            q += __shfl_xor(q, off, 64);
+        s = l1_row16_sum(s);
+        q = l1_row16_sum(q);
+        if ((lane & 15) == 15) {
+            red[di][wave * 4 + (lane >> 4)][0] = s;
+            red[di][wave * 4 + (lane >> 4)][1] = q;
         }
-        if (lane == 0) {
-            red[di][wave][0] = s;
-            red[di][wave][1] = q;
+        // slide the window to disparity d + 1
+        const float from_left = __builtin_bit_cast(
+            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hw[3]), 0x138, 0xf, 0xf, true));
+        hw[3] = hw[2];
+        hw[2] = hw[1];
+        hw[1] = hw[0];
+        hw[0] = from_left;
+        if (loads_left) {
+            const int u = xb - (d + 1);
+            hw[0] = (active && u >= -2) ? Hp[row + u + 2] : 0.f;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < d_launch * 2; i += 256) {
         const int di = i >> 1, k = i & 1;
-        const double v = (double)red[di][0][k] + (double)red[di][1][k] + (double)red[di][2][k] + (double)red[di][3][k];
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += (double)red[di][j][k];
         partials[((((size_t)nc * d_count + d_first + di) * tiles) + tile) * 2 + k] = v;
     }
 }
