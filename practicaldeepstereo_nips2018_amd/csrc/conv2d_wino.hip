@@ -224,6 +224,9 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
         if (more) PDS_WFETCH(chunk + 1)
         const float* xin = buf + b_lane;
         const float* win = buf + IN_CHUNK + half * MBW * 64 + lane;
+#ifdef PDS_WINO_SETPRIO
+        __builtin_amdgcn_s_setprio(PDS_WINO_SETPRIO);
+#endif
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -240,6 +243,9 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
                         PDS_X_MFMA(acc[p][m][j], af[m], bf[j]);
             }
         }
+#ifdef PDS_WINO_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (more) PDS_WSTASH(nxt)
         __syncthreads();
     }

@@ -32,6 +32,18 @@ namespace {
 constexpr int THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// timing-decomposition hooks (tools/build_variant.sh): any of them set makes the results wrong
+#ifdef PDS_X3_NOLOAD
+#define PDS_X3_LOAD(x) (float)(tid)
+#else
+#define PDS_X3_LOAD(x) (x)
+#endif
+#ifdef PDS_X3_NOMFMA
+#define PDS_X3_MFMA(c, a, b) (c)[0] += (a) * (b)
+#else
+#define PDS_X3_MFMA(c, a, b) (c) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
 struct Args3 {
     Src a, b;
     const float* __restrict__ wpk;
@@ -126,8 +138,8 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
         _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                                \
             const int ch = min((chunk_) * KC + c, A.Cin - 1);                                           \
             _Pragma("unroll") for (int k = 0; k < C::POS; ++k) {                                        \
-                va[c][k] = pa[(size_t)ch * cstride_a + ga[k]];                                          \
-                if (hasb) vb[c][k] = pb[(size_t)ch * cstride_b + gb[k]];                                \
+                va[c][k] = PDS_X3_LOAD(pa[(size_t)ch * cstride_a + ga[k]]);                             \
+                if (hasb) vb[c][k] = PDS_X3_LOAD(pb[(size_t)ch * cstride_b + gb[k]]);                   \
             }                                                                                           \
         }                                                                                               \
         const float* wsrc = A.wpk + (size_t)(chunk_) * 27 * C::KS * wrow + mb0 * 64;                    \
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
                             buf[b_row[r] + ks * 4 * C::CS + (dz * C::YT + dy) * C::RS + j * 16 * S + dx];
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
-                            acc[m][r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf, acc[m][r][j], 0, 0, 0);
+                            PDS_X3_MFMA(acc[m][r][j], af[m], bf);
                     }
                 }
             }

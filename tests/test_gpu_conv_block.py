@@ -1,0 +1,109 @@
+"""GPU (-m gpu): the single-layer entry point pds_conv_block_fwd against an fp64 PyTorch-CPU convolution.
+
+One block of reference network_blocks.py:47-72 (Conv -> LeakyReLU(0.1) -> InstanceNorm with affine parameters) on a
+plain tensor.  The shapes walk every kernel behind the entry point: the Winograd-domain 64-channel kernel
+(conv2d_wino.hip: even widths, partial 64-column tiles, 12 / 64 input channels, several planes and batch entries,
+per-plane and per-volume statistics, bare convolution), the direct MFMA kernel (odd widths, 8 / 16 output channels),
+the 3-D MFMA kernel (stride 1 and 2) and the VALU fallback (channel counts no MFMA tiling covers).
+Tolerance (stated): max-abs <= 2e-5 on the O(1) activations, and on the normalised output scale * raw + shift."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from practicaldeepstereo_nips2018_amd import _lib
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope='module')
+def dev(hip_library):
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def run_block(dev, x, weight, bias, gamma, beta, kd, stride, per_plane):
+    lib = _lib.load()
+    n, cin, d, h, w = x.shape
+    cout = weight.shape[0]
+    od = (d + 1) // 2 if (stride == 2 and kd == 3) else d
+    oh, ow = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+    xg = x.to(dev).contiguous()
+    tensors = [t.to(dev).contiguous() if t is not None else None for t in (weight, bias, gamma, beta)]
+    params = _lib.ConvBlockParams()
+    params.weight, params.bias = tensors[0].data_ptr(), tensors[1].data_ptr()
+    params.gamma = tensors[2].data_ptr() if gamma is not None else None
+    params.beta = tensors[3].data_ptr() if beta is not None else None
+    raw = torch.full((n, cout, od, oh, ow), float('nan'), device=dev)
+    groups = n * cout * (od if per_plane else 1)
+    scale = torch.zeros(groups, device=dev)
+    shift = torch.zeros(groups, device=dev)
+    nbytes = lib.pds_conv_block_workspace_bytes(n, cin, cout, d, h, w, kd, stride, per_plane)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    _lib.check(lib.pds_conv_block_fwd(ctypes.byref(params), _lib.ptr(xg), _lib.ptr(raw), _lib.ptr(scale),
+                                      _lib.ptr(shift), n, cin, cout, d, h, w, kd, stride, per_plane, _lib.ptr(ws),
+                                      ws.numel(), _lib.stream_handle(dev)), 'pds_conv_block_fwd')
+    torch.cuda.synchronize()
+    return raw.cpu(), scale.cpu(), shift.cpu()
+
+
+def reference(x, weight, bias, gamma, beta, kd, stride, per_plane):
+    x, weight, bias = x.double(), weight.double(), bias.double()
+    if kd == 1:
+        n, cin, d, h, w = x.shape
+        planes = x.permute(0, 2, 1, 3, 4).reshape(n * d, cin, h, w)
+        y = F.conv2d(planes, weight, bias, stride=stride, padding=1)
+        y = y.reshape(n, d, -1, y.shape[-2], y.shape[-1]).permute(0, 2, 1, 3, 4)
+    else:
+        y = F.conv3d(x, weight, bias, stride=stride, padding=1)
+    if gamma is None:
+        return y, None
+    raw = F.leaky_relu(y, 0.1)
+    dims = (3, 4) if per_plane else (2, 3, 4)
+    mean = raw.mean(dim=dims, keepdim=True)
+    var = raw.var(dim=dims, unbiased=False, keepdim=True)
+    shape = (1, -1, 1, 1, 1)
+    normed = (raw - mean) / torch.sqrt(var + 1e-5) * gamma.double().view(shape) + beta.double().view(shape)
+    return raw, normed
+
+
+CASES = [
+    # n, cin, cout, d, h, w, kd, stride, per_plane, affine
+    (1, 64, 64, 3, 12, 64, 1, 1, 1, True),     # Winograd kernel, one full tile column
+    (2, 64, 64, 2, 9, 50, 1, 1, 1, True),      # Winograd: batch 2, partial tile, ragged rows
+    (1, 12, 64, 1, 7, 130, 1, 1, 0, True),     # Winograd: 12 input channels (space-to-depth layer), per-volume stats
+    (1, 64, 64, 8, 6, 16, 1, 1, 1, False),     # Winograd: bare convolution, 8 planes (XCD re-mapping active)
+    (1, 64, 64, 2, 8, 33, 1, 1, 1, True),      # odd width: direct MFMA kernel
+    (1, 64, 8, 3, 10, 40, 1, 1, 1, False),     # 8 output channels: direct MFMA kernel, one channel block
+    (2, 64, 16, 1, 5, 24, 1, 1, 1, True),
+    (1, 8, 8, 6, 10, 20, 3, 1, 0, True),       # conv3d MFMA
+    (1, 8, 16, 8, 12, 20, 3, 2, 0, True),      # conv3d MFMA stride 2
+    (1, 6, 6, 4, 6, 10, 3, 1, 0, True),        # channel counts without an MFMA tiling: VALU kernel
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'n%d_%dto%d_d%d_%dx%d_k%d_s%d_pp%d_%s' % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], 'in' if c[9] else 'bare'))
+def test_conv_block_against_fp64(dev, case):
+    n, cin, cout, d, h, w, kd, stride, per_plane, affine = case
+    g = torch.Generator().manual_seed(1000 + cin * 7 + cout * 3 + w)
+    x = torch.randn(n, cin, d, h, w, generator=g)
+    fan_in = cin * 9 * (3 if kd == 3 else 1)
+    wshape = (cout, cin, 3, 3) if kd == 1 else (cout, cin, 3, 3, 3)
+    weight = torch.randn(*wshape, generator=g) / fan_in ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    gamma = torch.rand(cout, generator=g) + 0.5 if affine else None
+    beta = torch.randn(cout, generator=g) * 0.2 if affine else None
+    raw, scale, shift = run_block(dev, x, weight, bias, gamma, beta, kd, stride, per_plane)
+    want_raw, want_normed = reference(x, weight, bias, gamma, beta, kd, stride, per_plane)
+    assert raw.shape == want_raw.shape
+    assert not torch.isnan(raw).any(), 'output positions left unwritten'
+    err = float((raw.double() - want_raw).abs().max())
+    assert err <= TOL, err
+    if affine:
+        groups = (n, cout, raw.shape[2] if per_plane else 1, 1, 1)
+        normed = raw.double() * scale.double().view(groups) + shift.double().view(groups)
+        err_n = float((normed - want_normed).abs().max())
+        assert err_n <= 5 * TOL, err_n
