@@ -807,8 +807,24 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             // stride-1 convolution: dx = conv(dz, flipped weights) on the forward kernels (MFMA where supported)
             float* wf = c.get<float>((size_t)L.out_g.c * L.in_g.c * taps);
             if (!c.plan) c.run(launch_flip_weights(weight, wf, L.out_g.c, L.in_g.c, taps, c.s));
-            PdsConvBlockParams pf{wf, nullptr, nullptr, nullptr};
-            conv_block(c, plain_src(dz), no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);
+            if (L.kd == 1 && L.in_g.c > 64 && L.in_g.c % 64 == 0) {
+                // more than 64 gradient channels (the 4C-channel input of a space-to-depth layer): no MFMA tiling
+                // covers that as one launch, so it is cut into 64-channel blocks per batch entry, each of which
+                // runs on the 64-channel (Winograd) kernel instead of the VALU fallback
+                const size_t vol = (size_t)L.in_g.d * L.in_g.h * L.in_g.w;
+                Geom one = L.out_g;
+                one.n = 1;
+                for (int i = 0; i < L.in_g.n; ++i)
+                    for (int j = 0; j < L.in_g.c / 64; ++j) {
+                        PdsConvBlockParams pf{wf + (size_t)j * 64 * L.out_g.c * taps, nullptr, nullptr, nullptr};
+                        float* block = dx ? dx + ((size_t)i * L.in_g.c + (size_t)j * 64) * vol : nullptr;
+                        conv_block(c, plain_src(dz ? dz + (size_t)i * L.out_g.c * vol : nullptr), no_src(), one, pf, 64,
+                                   1, 1, 0, block);
+                    }
+            } else {
+                PdsConvBlockParams pf{wf, nullptr, nullptr, nullptr};
+                conv_block(c, plain_src(dz), no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);
+            }
         } else if (!c.plan) {
             c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, weight, dx, L.in_g, L.out_g, c.s));
         }
