@@ -142,6 +142,10 @@ size_t bwd_weight_scratch_doubles(int transposed, int kd, const Geom& in, const 
 int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
                       const Geom& in, const Geom& out, int accumulate, double* scratch, hipStream_t s);
 // MFMA weight gradient of the 2-D 3x3 convolutions (wgrad2d_mfma.hip)
+bool wgrad3d_mfma_supported(int transposed, int kd, int stride, const Geom& in, const Geom& out);  // wgrad3d_mfma.hip
+size_t wgrad3d_mfma_scratch_floats(const Geom& in, const Geom& out);
+int launch_wgrad3d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,
+                        int accumulate, float* scratch, hipStream_t s);
 bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, const Geom& in, const Geom& out);
 size_t wgrad2d_mfma_scratch_floats(const Geom& in, const Geom& out);
 int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,

@@ -322,7 +322,7 @@ static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
     const size_t lds_bytes = (size_t)(2 * C::BUF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }

@@ -335,7 +335,7 @@ int launch3(const Args3& A0, hipStream_t s) {
     Args3 A = A0;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }

@@ -144,6 +144,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_f32_kernel(const float* __re
     }
 }
 
+int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, float* dw, int accumulate, hipStream_t s) {
+    unsigned bx = (unsigned)((wcount + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3(bx), dim3(256), 0, s, partial, wcount, parts, dw, accumulate);
+    return check_launch("wgrad_reduce");
+}
+
 bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, const Geom& in, const Geom& out) {
     if (transposed || kd != 1 || stride != 1) return false;
     if (in.c % CG != 0) return false;
