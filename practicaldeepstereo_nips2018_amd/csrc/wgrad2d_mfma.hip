@@ -135,19 +135,37 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
     }
 }
 
+// dw[i] = sum over the workgroup partials, in fp64 and in a fixed order: a workgroup owns 64 consecutive weights,
+// its four waves each walk a quarter of the partials (four independent loads in flight per lane), LDS combines them.
 __global__ __launch_bounds__(256) void wgrad_reduce_f32_kernel(const float* __restrict__ partial, size_t wcount,
                                                                int parts, float* __restrict__ dw, int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < wcount; i += (size_t)gridDim.x * 256) {
-        double s = 0.0;
-        for (int k = 0; k < parts; ++k) s += (double)partial[(size_t)k * wcount + i];
-        dw[i] = (accumulate ? dw[i] : 0.f) + (float)s;
+    __shared__ double red[4][64];
+    const int col = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + col;
+    double s = 0.0;
+    if (i < wcount) {
+        int k = pg;
+        for (; k + 12 < parts; k += 16) {
+            const float v0 = partial[(size_t)k * wcount + i], v1 = partial[(size_t)(k + 4) * wcount + i];
+            const float v2 = partial[(size_t)(k + 8) * wcount + i], v3 = partial[(size_t)(k + 12) * wcount + i];
+            s += (double)v0;
+            s += (double)v1;
+            s += (double)v2;
+            s += (double)v3;
+        }
+        for (; k < parts; k += 4) s += (double)partial[(size_t)k * wcount + i];
+    }
+    red[pg][col] = s;
+    __syncthreads();
+    if (pg == 0 && i < wcount) {
+        const double total = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+        dw[i] = (accumulate ? dw[i] : 0.f) + (float)total;
     }
 }
 
 int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, float* dw, int accumulate, hipStream_t s) {
-    unsigned bx = (unsigned)((wcount + 255) / 256);
-    if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3(bx), dim3(256), 0, s, partial, wcount, parts, dw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3((unsigned)((wcount + 63) / 64)), dim3(256), 0, s, partial, wcount,
+                       parts, dw, accumulate);
     return check_launch("wgrad_reduce");
 }
 
@@ -191,11 +209,8 @@ int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, 
         hipLaunchKernelGGL((wgrad2d_mfma_kernel<4>), grid, dim3(THREADS), 0, s, A);
     else
         hipLaunchKernelGGL((wgrad2d_mfma_kernel<1>), grid, dim3(THREADS), 0, s, A);
-    const size_t wcount = (size_t)out.c * in.c * 9;
-    unsigned bx = (unsigned)((wcount + 255) / 256);
-    if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(wgrad_reduce_f32_kernel, dim3(bx), dim3(256), 0, s, scratch, wcount, wgs, dw, accumulate);
-    return check_launch("wgrad2d_mfma");
+    if (int rc = check_launch("wgrad2d_mfma")) return rc;
+    return launch_wgrad_reduce_f32(scratch, (size_t)out.c * in.c * 9, wgs, dw, accumulate, s);
 }
 
 }  // namespace pds
