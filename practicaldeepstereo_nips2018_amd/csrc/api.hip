@@ -272,9 +272,10 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
     if (kind == 2)
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
-    if (kind == 4) L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout));
+    if (kind == 4)
+        L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
-    if (extra && extra->matching_extras() && kind != 2) {
+    if (extra && extra->matching_extras() && kind != 2 && kind != 4) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
     }

@@ -70,6 +70,8 @@ struct WinoArgs {
     int N, Cin, D, H, W, Cout;
     int lrelu;
     int tiles_x, tiles;
+    size_t w_set_stride;             // floats between the packed weight sets of consecutive planes (0: shared)
+    int bias_set_stride;             // ditto for the bias
 };
 
 __device__ __forceinline__ float row16_sum_w(float v) {
@@ -158,6 +160,8 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
     const float* ps = NORM ? A.a.scale + (A.a.per_plane ? ((size_t)n * A.Cin * A.D + d) : (size_t)n * A.Cin) : nullptr;
     const float* ph = NORM ? A.a.shift + (A.a.per_plane ? ((size_t)n * A.Cin * A.D + d) : (size_t)n * A.Cin) : nullptr;
     const int wlast = W_CHUNK / 4 - 1;
+    const float* wbase = A.wpk + (size_t)d * A.w_set_stride;
+    const float* bias = A.bias ? A.bias + d * A.bias_set_stride : nullptr;
 
     float2 vp[IPT];
     float ve[IPT], vs[IPT], vh[IPT];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
                 vh[k] = hsrc[goff[k]];                                                               \
             }                                                                                        \
         }                                                                                            \
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(A.wpk + (size_t)(chunk_) * W_CHUNK);       \
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wbase + (size_t)(chunk_) * W_CHUNK);       \
         _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
             vw[it] = PDS_X_LOADW(wsrc[min(it * THREADS + tid, wlast)]);                               \
     }
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oc = (half * MBW + m) * 16 + q * 4 + r;
-            const float bv = A.bias ? A.bias[oc] : 0.f;
+            const float bv = bias ? bias[oc] : 0.f;
             float* po = A.out + (((size_t)n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W;
             float s = 0.f, sq = 0.f;
 #pragma unroll
@@ -324,7 +328,8 @@ bool conv2d_wino_eligible(const ConvLayer& L) {
     if (!enabled) return false;
     if (L.kd != 1 || L.stride != 1 || L.out_g.c != 64) return false;
     if (L.in.c % KC != 0 || L.in.c > 256) return false;
-    if (L.b.p || L.l0A || L.side_out || L.plane_weight_sets > 0) return false;
+    if (L.b.p || L.l0A || L.side_out) return false;
+    if (L.plane_weight_sets > 0 && (L.plane_weight_sets != L.in.d || L.plane_weight_sets > 8)) return false;
     if (L.in.w % 2 != 0 || L.in.w < 2) return false;  // rows are read as aligned 8-byte pairs
     if ((size_t)L.in.d * L.in.h * L.in.w * KC >= ((size_t)1 << 31)) return false;
     if (L.in.d > 65535 || L.in.n > 65535) return false;
@@ -338,20 +343,25 @@ size_t conv2d_wino_packed_floats(int cin, int cout) { return (size_t)(cin / KC) 
 int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     if (!L.packed) return set_error(-1, "conv2d_wino: packed weights missing");
     const int total = (int)conv2d_wino_packed_floats(L.in.c, L.out_g.c);
+    const int sets = L.plane_weight_sets > 0 ? L.plane_weight_sets : 1;
     const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
     if (phase != kPackDone) {
-        PackJob j;
-        j.src = L.weight;
-        j.dst = L.packed;
-        j.cout = L.out_g.c;
-        j.cin = L.in.c;
-        j.mblocks = MB;
-        j.kc = KC;
-        j.taps = 12;
-        j.mode = 3;  // F(2,3) filter transform along x
-        j.total = total;
-        if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
-        if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+        PackJob jobs[8];
+        for (int i = 0; i < sets; ++i) {
+            PackJob& j = jobs[i];
+            j.src = L.weight + (size_t)i * L.out_g.c * L.in.c * 9;
+            j.dst = L.packed + (size_t)i * total;
+            j.cout = L.out_g.c;
+            j.cin = L.in.c;
+            j.mblocks = MB;
+            j.kc = KC;
+            j.taps = 12;
+            j.mode = 3;  // F(2,3) filter transform along x
+            j.total = total;
+            if (phase == kPackCollect && !L.sink->push(j)) return set_error(-1, "pack job table full");
+        }
+        if (phase == kPackCollect) return 0;
+        if (int rc = launch_multi_pack(jobs, sets, s)) return rc;
     }
     WinoArgs A;
     A.a = L.a;
@@ -368,6 +378,8 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     A.lrelu = L.lrelu;
     A.tiles_x = (A.W + TWX - 1) / TWX;
     A.tiles = conv2d_wino_tiles(L.out_g);
+    A.w_set_stride = L.plane_weight_sets > 0 ? (size_t)total : 0;
+    A.bias_set_stride = L.plane_weight_sets > 0 ? L.out_g.c : 0;
     const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
     static const int halves = []() {  // PDS_WINO_WAVES=4 selects the 4-wave form (A/B)
         const char* e = getenv("PDS_WINO_WAVES");

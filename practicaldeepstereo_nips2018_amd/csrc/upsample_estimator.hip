@@ -121,15 +121,20 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
                     v[vr][2] = hi2.x;
                     v[vr][3] = hi2.y;
                 }
+                // the 3 x 16 taps of channel c as SGPR operands: explicit s_load_dwordx16 (hipcc turns plain reads of
+                // the weight pointer into vector loads parked in VGPRs, which spills this kernel); the three loads
+                // are issued back to back and share ONE wait (a wait per load left the wave stalled for most of a
+                // plane: 12 scalar-cache round trips against 1.5 k cycles of FMAs)
+                f32x16 wk[3];
+                asm volatile(
+                    "s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&s"(wk[0]), "=&s"(wk[1]), "=&s"(wk[2])
+                    : "s"(A.w), "s"((c * 3 + 0) * 64), "s"((c * 3 + 1) * 64), "s"((c * 3 + 2) * 64)
+                    : "memory");
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
-                    // 16 taps of (c, kd) as SGPR operands: an explicit s_load_dwordx16 (hipcc turns plain reads of
-                    // the weight pointer into vector loads parked in VGPRs, which spills this kernel)
-                    f32x16 wp;
-                    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=s"(wp)
-                                 : "s"(A.w), "s"((c * 3 + kd) * 64)
-                                 : "memory");
+                    const f32x16 wp = wk[kd];
 #pragma unroll
                     for (int py = 0; py < 2; ++py) {
 #pragma unroll
