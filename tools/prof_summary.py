@@ -18,6 +18,18 @@ def main():
         for name, calls, total, avg, pct in con.execute(
                 'select name, total_calls, total_duration, average, percentage from top_kernels'):
             lines.append('%-100s %8d %14.1f %12.1f %7.2f' % (name[:100], calls, total, avg, pct))
+    # the same kernel symbol serves layers of very different size: the launches of the dominant kernel per grid
+    lines.append('#')
+    lines.append('# launches of the 64 -> 64 convolution kernels by grid (threads x, y, z): the hot-path layers are the '
+                 '48-plane ones; bench.py\'s roofline.launch_ms times one of them in isolation')
+    lines.append('%-100s %22s %8s %12s' % ('kernel', 'grid', 'calls', 'avg_us'))
+    for db in dbs:
+        con = sqlite3.connect(db)
+        for name, gx, gy, gz, calls, avg in con.execute(
+                "select name, grid_x, grid_y, grid_z, count(*), avg(end - start) / 1000.0 from kernels "
+                "where name like '%conv2d_wino_kernel%' or name like '%conv2d_mfma_kernel<4%' "
+                "group by name, grid_x, grid_y, grid_z order by avg(end - start) desc"):
+            lines.append('%-100s %22s %8d %12.1f' % (name[:100], '%dx%dx%d' % (gx, gy, gz), calls, avg))
     open(dst, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:30]))
 
