@@ -1,0 +1,73 @@
+"""GPU (-m gpu): the multi-GPU code path with the real kernels, as far as one GPU can exercise it.
+
+Two processes (gloo; both bound to cuda:0 -- the box has one GPU, RCCL needs one device per rank) run
+distributed.ShardedHotPath on a stream of pairs: every rank matches its half of the disparity planes with
+pds_matching_fwd(d_begin, d_count), one all-gather reassembles the signatures, the tail of pair i runs on rank i % 2 on
+a side stream.  Every result must equal the unsharded hot path bit for bit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import practicaldeepstereo_nips2018_amd as pds
+    from practicaldeepstereo_nips2018_amd.distributed import ShardedHotPath, ShardedMatching
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.manual_seed(0)
+        net = pds.PdsNetwork.default(63).eval().to(dev)
+
+        def tail(signatures, shortcut):
+            return net._regularization.forward_with_estimator(signatures, shortcut, net._estimator)
+
+        hot_path = ShardedHotPath(net._matching, tail)
+        ok, outputs = True, []
+        with torch.no_grad():
+            for i in range(4):
+                g = torch.Generator().manual_seed(100 + i)
+                left = torch.randn(1, 64, 32, 64, generator=g).to(dev)
+                right = torch.randn(1, 64, 32, 64, generator=g).to(dev)
+                shortcut = torch.randn(1, 8, 32, 64, generator=g).to(dev)
+                out = hot_path.submit(left, right, shortcut)
+                ok = ok and ((out is not None) == (i % world == rank))
+                outputs.append((out, left, right, shortcut))
+            hot_path.drain()
+            for out, left, right, shortcut in outputs:
+                if out is not None:
+                    ok = ok and torch.equal(out, tail(net._matching(left, right), shortcut))
+            # the plain sharded module (all-gather on every rank) as well
+            _, left, right, _ = outputs[0]
+            ok = ok and torch.equal(ShardedMatching(net._matching)(left, right), net._matching(left, right))
+        torch.cuda.synchronize()
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_hot_path_two_ranks_on_one_gpu(hip_library):
+    assert torch.cuda.is_available()
+    ctx = mp.get_context('spawn')
+    results = ctx.Manager().dict()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(results.get(r) for r in range(2)), dict(results)
