@@ -63,10 +63,14 @@ struct MfmaArgs {
     float* __restrict__ side_out;    // optional: the staged (summed, normalised) input is also written here
 };
 
-template <int MB>
+// KCT: input channels staged per chunk.  4 for the 64-channel-block kernels (keeps 3 workgroups per CU); 8 for the
+// single-block kernels (8 / 16 output channels), whose 45 MFMAs per 4-channel chunk are far shorter than a load round
+// trip: twice the bytes in flight per barrier.
+template <int MB, int KCT = KC>
 struct Cfg {
-    static constexpr int W_CHUNK = 9 * (KC / 4) * MB * 64;      // floats per weight chunk
-    static constexpr int BUF = IN_CHUNK + W_CHUNK;              // floats per LDS buffer
+    static constexpr int IN_CHUNK_T = KCT * CS;
+    static constexpr int W_CHUNK = 9 * (KCT / 4) * MB * 64;     // floats per weight chunk
+    static constexpr int BUF = IN_CHUNK_T + W_CHUNK;            // floats per LDS buffer
     static constexpr int W_ITERS = (W_CHUNK / 4 + THREADS - 1) / THREADS;  // float4 per thread
 };
 
@@ -82,12 +86,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // SRC: 0 = source a;  1 = a + b;  2 = layer-0 terms (A + shifted G);  3 = a + layer-0 terms
-template <int MB, int SRC>
+// PAIR (even widths, SRC 0 / 1): every thread stages ONE aligned pair of columns per channel with an 8-byte load
+// (6 rows x 42 pairs cover columns x0 - 2 .. x0 + 81) instead of two scalar positions: half the load instructions
+// and fully used cache lines.
+template <int MB, int SRC, bool PAIR = false, int KCT = KC>
 __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WAVES : 2) void conv2d_mfma_kernel(const MfmaArgs A) {
     constexpr bool HAS_A = SRC != 2;
     constexpr bool HAS_B = SRC == 1;
     constexpr bool HAS_L0 = SRC >= 2;
-    using C = Cfg<MB>;
+    static_assert(!PAIR || (!HAS_L0 && TW % 2 == 0 && RS >= TW + 4), "pair staging: plain sources, even tiles");
+    using C = Cfg<MB, KCT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 buffers][input chunk | weight chunk]
 
     const int tid = threadIdx.x;
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
     const int y0 = ty * TH, x0 = tx * TW;
     const size_t plane = (size_t)A.H * A.W;
     const size_t cstride = (size_t)A.D * plane;  // channel stride of NCDHW
-    const int nchunks = A.Cin / KC;
+    const int nchunks = A.Cin / KCT;
 
     // ---- staging map: thread -> up to POS positions (row r, column xx) of the (TH+2) x (TW+2) halo tile,
     // the same positions for each of the 8 channels of a chunk.  Loads are unconditional from clamped
@@ -112,14 +120,24 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
     const int disp = A.d_begin + d;
 #pragma unroll
     for (int k = 0; k < POS; ++k) {
-        const int p = min(tid + k * THREADS, NPOS - 1);  // surplus threads duplicate the last position
-        const int r = p / (TW + 2), xx = p % (TW + 2);
+        int r, xx, p;
+        if (PAIR) {  // k = 0 / 1: the two columns of this thread's pair; LDS column = x - (x0 - 2)
+            constexpr int NPAIR = (TH + 2) * ((TW + 4) / 2);
+            static_assert(NPAIR <= THREADS && POS == 2, "one pair per thread");
+            p = min(tid, NPAIR - 1);
+            r = p / ((TW + 4) / 2);
+            xx = 2 * (p % ((TW + 4) / 2)) + k - 1;   // relative to x0 - 1, like the scalar map
+        } else {
+            p = min(tid + k * THREADS, NPOS - 1);  // surplus threads duplicate the last position
+            r = p / (TW + 2);
+            xx = p % (TW + 2);
+        }
         const int y = y0 - 1 + r, x = x0 - 1 + xx;
         inside[k] = y >= 0 && y < A.H && x >= 0 && x < A.W;
         interior[k] = inside[k] && r >= 1 && r <= TH && xx >= 1 && xx <= TW && (tid + k * THREADS) < NPOS;
         const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
-        g_off[k] = yc * A.W + xc;
-        l_off[k] = r * RS + xx;
+        g_off[k] = yc * A.W + (PAIR ? min(max(x - k, 0), A.W - 2) + k : xc);  // pairs stay aligned when clamped
+        l_off[k] = r * RS + xx + (PAIR ? 1 : 0);
         if (HAS_L0) {
             const int u = xc - disp;  // column of the un-shifted right descriptor
             gvalid[k] = u >= -1;
@@ -140,19 +158,32 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
     const float* bias = A.bias ? A.bias + d * A.bias_set_stride : nullptr;
     const int wlast = C::W_CHUNK / 4 - 1;
 
-    float va[HAS_A ? KC : 1][POS], vb[(HAS_B || HAS_L0) ? KC : 1][POS], vg[HAS_L0 ? KC : 1][POS];
+    float va[HAS_A ? KCT : 1][POS], vb[(HAS_B || HAS_L0) ? KCT : 1][POS], vg[HAS_L0 ? KCT : 1][POS];
     f32x4 vw[C::W_ITERS];  // ext-vector type: HIP's float4 struct keeps the array in scratch
 
 #define PDS_FETCH(chunk_)                                                                          \
     {                                                                                              \
-        const float* ca = HAS_A ? pa + (size_t)(chunk_) * KC * cstride : nullptr;                  \
-        const float* cb = HAS_B ? pb + (size_t)(chunk_) * KC * cstride : nullptr;                  \
-        _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                           \
+        const float* ca = HAS_A ? pa + (size_t)(chunk_) * KCT * cstride : nullptr;                  \
+        const float* cb = HAS_B ? pb + (size_t)(chunk_) * KCT * cstride : nullptr;                  \
+        _Pragma("unroll") for (int c = 0; c < KCT; ++c) {                                           \
+            if (PAIR) {                                                                            \
+                if (HAS_A) {                                                                       \
+                    const float2 t = *reinterpret_cast<const float2*>(ca + c * cstride + g_off[0]); \
+                    va[c][0] = t.x;                                                                \
+                    va[c][1] = t.y;                                                                \
+                }                                                                                  \
+                if (HAS_B) {                                                                       \
+                    const float2 t = *reinterpret_cast<const float2*>(cb + c * cstride + g_off[0]); \
+                    vb[c][0] = t.x;                                                                \
+                    vb[c][1] = t.y;                                                                \
+                }                                                                                  \
+                continue;                                                                          \
+            }                                                                                      \
             _Pragma("unroll") for (int k = 0; k < POS; ++k) {                                      \
                 if (HAS_A) va[c][k] = ca[c * cstride + g_off[k]];                                  \
                 if (HAS_B) vb[c][k] = cb[c * cstride + g_off[k]];                                  \
                 if (HAS_L0) {                                                                      \
-                    const int ch = (chunk_) * KC + c;                                              \
+                    const int ch = (chunk_) * KCT + c;                                              \
                     vb[c][k] = pl[(size_t)ch * gplane + la_off[k]];                                \
                     vg[c][k] = gsel[k][(size_t)ch * gplane + gg_off[k]];                           \
                 }                                                                                  \
@@ -165,8 +196,8 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
 
 #define PDS_STASH(chunk_, buf_)                                                                    \
     {                                                                                              \
-        _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                           \
-            const int ch = (chunk_) * KC + c;                                                      \
+        _Pragma("unroll") for (int c = 0; c < KCT; ++c) {                                           \
+            const int ch = (chunk_) * KCT + c;                                                      \
             float sa = 1.f, ha = 0.f, sb = 1.f, hb = 0.f;                                          \
             if (HAS_A && A.a.scale) {                                                              \
                 const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);      \
@@ -192,7 +223,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
                     A.side_out[(((size_t)n * A.Cin + ch) * A.D + d) * plane + g_off[k]] = v;       \
             }                                                                                      \
         }                                                                                          \
-        f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + IN_CHUNK);                                 \
+        f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + C::IN_CHUNK_T);                                 \
         _Pragma("unroll") for (int it = 0; it < C::W_ITERS; ++it)                                  \
             wdst[min(it * THREADS + tid, wlast)] = vw[it];                                         \
     }
@@ -208,7 +239,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
     __syncthreads();
 
     // lane-constant part of the fragment addresses
-    const int b_lane = (lane >> 4) * CS + wave * RS + (lane & 15);
+    const int b_lane = (lane >> 4) * CS + wave * RS + (lane & 15) + (PAIR ? 1 : 0);
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         float* buf = lds + (chunk & 1) * C::BUF;
@@ -216,7 +247,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
         const bool more = chunk + 1 < nchunks;
         if (more) PDS_FETCH(chunk + 1)
         const float* xin = buf + b_lane;
-        const float* win = buf + IN_CHUNK + lane;
+        const float* win = buf + C::IN_CHUNK_T + lane;
 #ifdef PDS_SETPRIO
         __builtin_amdgcn_s_setprio(PDS_SETPRIO);
 #endif
@@ -224,10 +255,10 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-            for (int ks = 0; ks < KC / 4; ++ks) {
+            for (int ks = 0; ks < KCT / 4; ++ks) {
                 float af[MB], bf[NB];
 #pragma unroll
-                for (int m = 0; m < MB; ++m) af[m] = win[((tap * (KC / 4) + ks) * MB + m) * 64];
+                for (int m = 0; m < MB; ++m) af[m] = win[((tap * (KCT / 4) + ks) * MB + m) * 64];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) bf[j] = xin[ks * 4 * CS + dy * RS + j * 16 + dx];
 #pragma unroll
@@ -316,24 +347,34 @@ size_t conv2d_mfma_packed_floats(int cin, int cout) {
     return (size_t)(cin / KC) * 9 * (KC / 4) * mfma_blocks(cout) * 64;
 }
 
-template <int MB, int SRC>
+template <int MB, int SRC, bool PAIR = false, int KCT = KC>
 static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
-    using C = Cfg<MB>;
+    using C = Cfg<MB, KCT>;
     const size_t lds_bytes = (size_t)(2 * C::BUF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC, PAIR, KCT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }
     dim3 grid(A.tiles, A.D, A.N);
-    hipLaunchKernelGGL((conv2d_mfma_kernel<MB, SRC>), grid, dim3(THREADS), lds_bytes, s, A);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<MB, SRC, PAIR, KCT>), grid, dim3(THREADS), lds_bytes, s, A);
     return check_launch("conv2d_mfma");
+}
+
+// 8-channel chunks for the single-block kernels on plain sources (see Cfg): an experiment kept as an opt-in
+static int chunk_depth(const ConvLayer& L) {
+    static const bool deep = []() {  // opt-in (PDS_CONV2D_KC8=1): measured slower on the 64 -> 8 layer (470 vs 400 us)
+        const char* e = getenv("PDS_CONV2D_KC8");
+        return e && e[0] == '1';
+    }();
+    return (deep && mfma_blocks(L.out_g.c) == 1 && !L.l0A && L.plane_weight_sets == 0 && L.in.c % 8 == 0) ? 8 : KC;
 }
 
 int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     if (!L.packed) return set_error(-1, "conv2d_mfma: packed weights missing");
     const int mb = mfma_blocks(L.out_g.c);
+    const int kc = chunk_depth(L);
     const int sets = L.plane_weight_sets > 0 ? L.plane_weight_sets : 1;
     if (L.plane_weight_sets > 0 && L.plane_weight_sets != L.in.d)
         return set_error(-1, "conv2d_mfma: %d weight sets for %d planes", L.plane_weight_sets, L.in.d);
@@ -349,7 +390,7 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
             j.cout = L.out_g.c;
             j.cin = L.in.c;
             j.mblocks = mb;
-            j.kc = KC;
+            j.kc = kc;
             j.taps = 9;
             j.mode = 0;
             j.total = total;
@@ -385,6 +426,19 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     const bool has_b = L.b.p != nullptr, has_l0 = L.l0A != nullptr, has_a = L.a.p != nullptr;
     if (has_l0 && has_b) return set_error(-1, "conv2d_mfma: layer-0 terms and a second source together");
     const int src = has_l0 ? (has_a ? 3 : 2) : (has_b ? 1 : 0);
+    static const bool pairs_enabled = []() {  // opt-in (PDS_CONV2D_PAIRS=1): measured neutral on the 64 -> 8 layer
+        const char* e = getenv("PDS_CONV2D_PAIRS");
+        return e && e[0] == '1';
+    }();
+    const bool pairs = pairs_enabled && !has_l0 && !L.side_out && (A.W % 2) == 0 && A.W >= 2;
+    if (kc == 8) {  // mb == 1, plain sources
+        if (pairs) return src == 1 ? launch_cfg<1, 1, true, 8>(A, s) : launch_cfg<1, 0, true, 8>(A, s);
+        return src == 1 ? launch_cfg<1, 1, false, 8>(A, s) : launch_cfg<1, 0, false, 8>(A, s);
+    }
+    if (pairs) {
+        if (mb == 4) return src == 1 ? launch_cfg<4, 1, true>(A, s) : launch_cfg<4, 0, true>(A, s);
+        return src == 1 ? launch_cfg<1, 1, true>(A, s) : launch_cfg<1, 0, true>(A, s);
+    }
     if (mb == 4) {
         switch (src) {
             case 0: return launch_cfg<4, 0>(A, s);
