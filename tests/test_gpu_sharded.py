@@ -69,5 +69,9 @@ def test_sharded_hot_path_two_ranks_on_one_gpu(hip_library):
         p.start()
     for p in procs:
         p.join(300)
-        assert p.exitcode == 0
+    for p in procs:
+        if p.is_alive():   # a hung rendezvous must not outlive the test
+            p.kill()
+            p.join(10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert all(results.get(r) for r in range(2)), dict(results)
