@@ -64,42 +64,53 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
         const int x0 = seg * TWG;
 
         // ---- stage xhat: 64 channels x 3 rows x 34 columns (x0-1 .. x0+32) -------------------------------
-        for (int e = tid; e < CG * 3 * (TWG + 2); e += THREADS) {
-            const int c = e / (3 * (TWG + 2));
-            const int rem = e - c * 3 * (TWG + 2);
-            const int rr = rem / (TWG + 2), xx = rem - rr * (TWG + 2);
-            const int yy = y - 1 + rr, x = x0 - 1 + xx;
-            const int ch = cg0 + c;
-            float v = 0.f;
-            if (yy >= 0 && yy < A.H && x >= 0 && x < A.W) {
-                const size_t off = ((size_t)(n * A.Cin + ch) * A.D + d) * plane + (size_t)yy * A.W + x;
-                float sa = 1.f, ha = 0.f;
-                if (A.a.scale) {
-                    const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
-                    sa = A.a.scale[g];
-                    ha = A.a.shift[g];
+        // One wave stages one (channel, row) run of 34 contiguous columns per step: the channel, the row and the
+        // InstanceNorm coefficients are wave-uniform (scalar registers), the per-lane work is one load, one fma, one
+        // LDS write.  (The first version walked a flat element index: two divisions and two coefficient loads per
+        // element cost as much issue time as a third of the MFMAs.)
+        {
+            const int xx = min(lane, TWG + 1);        // lanes 0..33 active, the rest shadow lane 33
+            const int x = x0 - 1 + xx;
+            const bool colok = x >= 0 && x < A.W;
+            const int xc = min(max(x, 0), A.W - 1);
+            constexpr int BATCH = 8;                  // (channel, row) runs in flight per wave
+            static_assert((CG * 3) % (4 * BATCH) == 0, "runs split evenly over waves and batches");
+            for (int cr0 = wave * BATCH; cr0 < CG * 3; cr0 += 4 * BATCH) {
+                float va[BATCH], vb[BATCH];
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {     // loads first: unconditional, clamped addresses
+                    const int cr = cr0 + j, c = cr / 3, rr = cr - c * 3;
+                    const int yc = min(max(y - 1 + rr, 0), A.H - 1);
+                    const size_t off = ((size_t)(n * A.Cin + cg0 + c) * A.D + d) * plane + (size_t)yc * A.W + xc;
+                    va[j] = A.a.p[off];
+                    vb[j] = A.b.p ? A.b.p[off] : 0.f;
                 }
-                v = fmaf(sa, A.a.p[off], ha);
-                if (A.b.p) {
-                    float sb = 1.f, hb = 0.f;
-                    if (A.b.scale) {
-                        const int g = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
-                        sb = A.b.scale[g];
-                        hb = A.b.shift[g];
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {
+                    const int cr = cr0 + j, c = cr / 3, rr = cr - c * 3;
+                    const int yy = y - 1 + rr;
+                    const int ch = cg0 + c;
+                    const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                    float v = A.a.scale ? fmaf(A.a.scale[g], va[j], A.a.shift[g]) : va[j];
+                    if (A.b.p) {
+                        const int gb = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                        v += A.b.scale ? fmaf(A.b.scale[gb], vb[j], A.b.shift[gb]) : vb[j];
                     }
-                    v += fmaf(sb, A.b.p[off], hb);
+                    v = (colok && yy >= 0 && yy < A.H) ? v : 0.f;
+                    if (lane < TWG + 2) xl[c * XS + rr * RSX + xx] = v;
                 }
             }
-            xl[c * XS + rr * RSX + xx] = v;
         }
-        // ---- stage dz: (padded) output channels x 32 positions --------------------------------------------
-        for (int e = tid; e < MBW * 16 * TWG; e += THREADS) {
-            const int oc = e / TWG, px = e - oc * TWG;
-            const int x = x0 + px;
-            float v = 0.f;
-            if (oc < A.Cout && x < A.W)
-                v = A.dz[((size_t)(n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W + x];
-            dzl[oc * DS + px] = v;
+        // ---- stage dz: (padded) output channels x 32 positions: a wave stages two channel rows per step ----
+        {
+            const int px = lane & 31, x = x0 + px;
+            for (int o2 = wave; o2 < MBW * 8; o2 += 4) {
+                const int oc = o2 * 2 + (lane >> 5);
+                float v = 0.f;
+                if (oc < A.Cout && x < A.W)
+                    v = A.dz[((size_t)(n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W + x];
+                dzl[oc * DS + px] = v;
+            }
         }
         __syncthreads();
 
