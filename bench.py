@@ -47,7 +47,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-le
 CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
 # HBM bytes per launch of that kernel from the PMC counters (profiles/r01_conv64_wino_pmc.txt); a recorded
 # measurement, not re-collected by this script (counters need rocprofv3 around the process)
-CONV64_HBM_BYTES = 961.5e6
+CONV64_HBM_BYTES = 861.0e6   # FETCH_SIZE 219.3 MB x 2 (the guide's gfx950 correction for wide reads) + WRITE_SIZE 421.9 MB
 # The layer runs in the Winograd domain (csrc/conv2d_wino.hip, F(2,3) along x): 2/3 of the multiplies of the direct
 # form, over 64-column tiles (256 columns computed for 240)
 CONV64_EXECUTED_GFLOP = CONV64_GFLOP * (2.0 / 3.0) * (256.0 / 240.0)
