@@ -57,6 +57,7 @@ struct Args3 {
     int mblocks;                  // ceil(virtual Cout / 16)
     int Creal;                    // real output channels (== Cout for a convolution)
     const unsigned* __restrict__ tapmask;  // [mblocks] 27-bit masks of the taps a channel block uses
+    int xcd_run;                  // tiles per XCD (ceil(tiles / 8)); 0: identity mapping
 };
 
 template <int S, int MB, int TZ, int TY, int NB, int KC>
@@ -98,7 +99,14 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (one L2 each) in launch order; with the
+    // launch index re-mapped every XCD works on a contiguous run of tiles (a slab of z), so the z / y halo planes that
+    // neighbouring tiles share are re-read from the same L2 instead of being fetched through eight of them.
+    int tile = blockIdx.x;
+    if (A.xcd_run > 0) {
+        tile = (int)(blockIdx.x & 7) * A.xcd_run + (int)(blockIdx.x >> 3);
+        if (tile >= A.tiles) return;  // grid.x is padded to a multiple of 8
+    }
     const int mb0 = blockIdx.y * MB;  // first channel block of this workgroup
     const int n = blockIdx.z;
     const int tx = tile % A.tiles_x;
@@ -339,7 +347,12 @@ int launch3(const Args3& A0, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }
-    dim3 grid(A.tiles, (A.mblocks + MB - 1) / MB, A.N);
+    static const bool xcd_map = []() {  // PDS_CONV3D_XCD_MAP=0: launch order = tile order (A/B)
+        const char* e = getenv("PDS_CONV3D_XCD_MAP");
+        return !(e && e[0] == '0');
+    }();
+    A.xcd_run = (xcd_map && A.tiles >= 64) ? (A.tiles + 7) / 8 : 0;
+    dim3 grid(A.xcd_run > 0 ? 8 * A.xcd_run : A.tiles, (A.mblocks + MB - 1) / MB, A.N);
     hipLaunchKernelGGL((conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>), grid, dim3(THREADS), C::LDS_BYTES, s, A);
     return check_launch("conv3d_mfma");
 }
