@@ -5,9 +5,9 @@ Mirrors the factories of reference practical_deep_stereo/network_blocks.py (:19-
 1 = LeakyReLU, 2 = InstanceNorm) and therefore the same state-dict keys, and the same
 construction order so ``torch.manual_seed`` yields the reference's initial weights.
 
-On the hot path these modules are NOT executed by PyTorch: Matching / Regularization hand their
-parameters to the HIP library.  They are ordinary callable torch modules only so the off-path
-Embedding (kept on PyTorch-ROCm by design) can run them.
+These modules are never executed by PyTorch: Embedding, Matching and Regularization hand their
+parameters to the HIP library (libpds_hip.so).  They are torch modules only so that parameters are
+registered, moved and (de)serialised the way the reference's are.
 """
 from torch import nn
 

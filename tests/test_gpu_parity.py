@@ -286,7 +286,7 @@ def test_config1_hot_path_vs_golden(dev):
 
 
 def test_config1_full_network_on_gpu(dev):
-    """The drop-in: PdsNetwork.default with the embedding on PyTorch-ROCm and the HIP hot path."""
+    """The drop-in: PdsNetwork.default end to end on the library (virtual padding, HIP descriptor network, hot path)."""
     g = helpers.golden('g6_config1')
     net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).eval().to(dev)
     left, right = helpers.images(1, 128, 256)
@@ -295,7 +295,8 @@ def test_config1_full_network_on_gpu(dev):
     assert out.shape == (1, 128, 256)
     rep = helpers.disparity_report(out, g['disparity'])
     print('config1 full network (GPU embedding)', rep)
-    assert rep['mae'] <= 5e-3, rep   # the MIOpen embedding perturbs the descriptors by ~1e-6
+    assert rep['mae'] <= 5e-3, rep   # the GPU descriptors differ from the golden (CPU) ones by ~1e-5: a few flips
+    assert rep['mae_noflip'] <= 1e-4 and rep['flips'] <= 2e-4, rep
     net.train()
     with torch.no_grad():
         cost = net(left.to(dev), right.to(dev))
