@@ -120,7 +120,8 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
     const int nchunks = (A.Cin + KC - 1) / KC;
     const unsigned tapmask = MODE != 0 ? A.tapmask[mb0] : 0x7ffffffu;
 
-    int ga[C::POS], gb[C::POS], lo[C::POS];
+    unsigned ga[C::POS], gb[C::POS];   // 32-bit offsets inside one channel (conv3d_mfma_supported bounds the volume)
+    int lo[C::POS];
     bool inside[C::POS];
 #pragma unroll
     for (int k = 0; k < C::POS; ++k) {
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
         const int z = z0 * S - 1 + zz, y = y0 * S - 1 + yy, x = x0 * S - 1 + xx;
         inside[k] = z >= 0 && z < A.Di && y >= 0 && y < A.Hi && x >= 0 && x < A.Wi;
         const int zc = min(max(z, 0), A.Di - 1), yc = min(max(y, 0), A.Hi - 1), xc = min(max(x, 0), A.Wi - 1);
-        ga[k] = (zc * A.Hi + yc) * A.Wi + xc;
-        gb[k] = A.b.bcast_d ? yc * A.Wi + xc : ga[k];
+        ga[k] = (unsigned)((zc * A.Hi + yc) * A.Wi + xc);
+        gb[k] = A.b.bcast_d ? (unsigned)(yc * A.Wi + xc) : ga[k];
         lo[k] = (zz * C::YT + yy) * C::RS + xx;
     }
     const float* pa = A.a.p + (size_t)n * A.Cin * cstride_a;
@@ -143,11 +144,16 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
 
 #define PDS_FETCH3(chunk_)                                                                              \
     {                                                                                                   \
+        /* the second source is tested ONCE per chunk, not per load: straight-line bursts of loads from */ \
+        /* wave-uniform channel pointers plus 32-bit lane offsets                                         */ \
         _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                                \
-            const int ch = min((chunk_) * KC + c, A.Cin - 1);                                           \
-            _Pragma("unroll") for (int k = 0; k < C::POS; ++k) {                                        \
-                va[c][k] = PDS_X3_LOAD(pa[(size_t)ch * cstride_a + ga[k]]);                             \
-                if (hasb) vb[c][k] = PDS_X3_LOAD(pb[(size_t)ch * cstride_b + gb[k]]);                   \
+            const float* ca = pa + (size_t)min((chunk_) * KC + c, A.Cin - 1) * cstride_a;               \
+            _Pragma("unroll") for (int k = 0; k < C::POS; ++k) va[c][k] = PDS_X3_LOAD(ca[ga[k]]);       \
+        }                                                                                               \
+        if (hasb) {                                                                                     \
+            _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                            \
+                const float* cb = pb + (size_t)min((chunk_) * KC + c, A.Cin - 1) * cstride_b;           \
+                _Pragma("unroll") for (int k = 0; k < C::POS; ++k) vb[c][k] = PDS_X3_LOAD(cb[gb[k]]);   \
             }                                                                                           \
         }                                                                                               \
         const float* wsrc = A.wpk + (size_t)(chunk_) * 27 * C::KS * wrow + mb0 * 64;                    \
@@ -173,10 +179,14 @@ __global__ __launch_bounds__(THREADS) void conv3d_mfma_kernel(const Args3 A) {
                 sb = A.b.scale[n * A.Cin + ch];                                                         \
                 hb = A.b.shift[n * A.Cin + ch];                                                         \
             }                                                                                           \
-            _Pragma("unroll") for (int k = 0; k < C::POS; ++k) {                                        \
-                float v = fmaf(sa, va[c][k], ha);                                                       \
-                if (hasb) v += fmaf(sb, vb[c][k], hb);                                                  \
-                (buf_)[c * C::CS + lo[k]] = (inside[k] && chv) ? v : 0.f;                               \
+            if (hasb) {                                                                                 \
+                _Pragma("unroll") for (int k = 0; k < C::POS; ++k) {                                    \
+                    const float v = fmaf(sa, va[c][k], ha) + fmaf(sb, vb[c][k], hb);                    \
+                    (buf_)[c * C::CS + lo[k]] = (inside[k] && chv) ? v : 0.f;                           \
+                }                                                                                       \
+            } else {                                                                                    \
+                _Pragma("unroll") for (int k = 0; k < C::POS; ++k)                                      \
+                    (buf_)[c * C::CS + lo[k]] = (inside[k] && chv) ? fmaf(sa, va[c][k], ha) : 0.f;      \
             }                                                                                           \
         }                                                                                               \
         f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + C::IN_CHUNK);                                   \
