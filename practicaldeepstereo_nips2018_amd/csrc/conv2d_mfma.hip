@@ -42,6 +42,18 @@ constexpr int IN_ITERS = (IN_ELEMS + THREADS - 1) / THREADS;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// timing-decomposition hooks (tools/build_variant.sh): any of them set makes the results wrong
+#ifdef PDS_X2_NOLOAD
+#define PDS_X2_LOAD(v) (float)(tid)
+#else
+#define PDS_X2_LOAD(v) (v)
+#endif
+#ifdef PDS_X2_NOMFMA
+#define PDS_X2_MFMA(c, a, b) (c)[0] += (a) * (b)
+#else
+#define PDS_X2_MFMA(c, a, b) (c) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
 struct MfmaArgs {
     Src a, b;
     const float* __restrict__ wpk;   // packed weights, see pack kernel
@@ -180,8 +192,8 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
                 continue;                                                                          \
             }                                                                                      \
             _Pragma("unroll") for (int k = 0; k < POS; ++k) {                                      \
-                if (HAS_A) va[c][k] = ca[c * cstride + g_off[k]];                                  \
-                if (HAS_B) vb[c][k] = cb[c * cstride + g_off[k]];                                  \
+                if (HAS_A) va[c][k] = PDS_X2_LOAD(ca[c * cstride + g_off[k]]);                     \
+                if (HAS_B) vb[c][k] = PDS_X2_LOAD(cb[c * cstride + g_off[k]]);                     \
                 if (HAS_L0) {                                                                      \
                     const int ch = (chunk_) * KCT + c;                                              \
                     vb[c][k] = pl[(size_t)ch * gplane + la_off[k]];                                \
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[m][j], 0, 0, 0);
+                        PDS_X2_MFMA(acc[m][j], af[m], bf[j]);
             }
         }
 #ifdef PDS_SETPRIO
