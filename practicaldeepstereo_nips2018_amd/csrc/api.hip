@@ -43,6 +43,10 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s);        // conv2d_wino
 bool conv2d_wino_eligible(const ConvLayer& L);
 int conv2d_wino_tiles(const Geom& out_g);
 size_t conv2d_wino_packed_floats(int cin, int cout);
+int launch_conv2d_wino2d(const ConvLayer& L, hipStream_t s);      // conv2d_wino2d.hip
+bool conv2d_wino2d_eligible(const ConvLayer& L);
+int conv2d_wino2d_tiles(const Geom& out_g);
+size_t conv2d_wino2d_packed_floats(int cin, int cout);
 int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma.hip
 bool conv3d_mfma_supported(const ConvLayer& L);
 int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
@@ -268,20 +272,22 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
     // Winograd domain (plain single-source Cin -> 64 layers)
     int kind = 0;
-    if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino_eligible(L) ? 4 : 2;
+    if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino2d_eligible(L) ? 5 : conv2d_wino_eligible(L) ? 4 : 2;
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
     if (kind == 2)
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 4)
         L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
+    if (kind == 5) L.packed = c.get<float>(conv2d_wino2d_packed_floats(in.c, cout));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
-    if (extra && extra->matching_extras() && kind != 2 && kind != 4) {
+    if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 5) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
     }
     auto launch = [&]() {
         return kind == 2 ? launch_conv2d_mfma(L, c.s)
                          : kind == 4 ? launch_conv2d_wino(L, c.s)
+                         : kind == 5 ? launch_conv2d_wino2d(L, c.s)
                                      : kind == 3 ? launch_conv3d_mfma(L, c.s) : launch_conv_direct(L, c.s);
     };
     const bool collecting = c.sink && c.sink->phase == kPackCollect && c.base != nullptr;
@@ -289,7 +295,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     if (norm) {
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
-                                    : kind == 4 ? conv2d_wino_tiles(o.g) : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride) : conv_direct_tiles_for(o.g, stride);
+                                    : kind == 4 ? conv2d_wino_tiles(o.g)
+                                    : kind == 5 ? conv2d_wino2d_tiles(o.g) : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride) : conv_direct_tiles_for(o.g, stride);
         const size_t records = (size_t)o.g.n * o.g.c * (kind == 3 ? 1 : o.g.d) * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
