@@ -4,6 +4,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Pairs arrive as a stream: at N = 1 the tail of pair i (Regularization + SubpixelMap, whose small 3-D layers leave most
+CUs idle) runs on a second HIP stream while Matching of pair i + 1 runs on the first; "value" is that throughput,
+"ms_per_frame" / "sequential" the un-overlapped latency of one pair (--no-pipeline times that mode as value), and
+every pipelined result is checked bit for bit against the sequential one.
+
 A step = one stereo pair through Matching -> Regularization -> SubpixelMap (eval mode) at
 BASELINE.json configs[1]: 960x540 (padded 576x960), D=192 (maximum_disparity 191), fp32, random-init
 weights (seed 0), descriptors of seeded uniform images (SURVEY.md 8c recipe) resident in HBM before
@@ -59,6 +64,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='N = 1: one pair strictly after the other on one stream (latency mode) instead of overlapping '
+                         'the Regularization + estimator tail of pair i with Matching of pair i + 1 on two streams')
     ap.add_argument('--kernel-reps', type=int, default=10)
     ap.add_argument('--graph', action='store_true',
                     help='replay the hot path as one captured HIP graph (N = 1); measured equal to eager launches '
@@ -186,7 +194,14 @@ def main():
     # N > 1: Matching sharded along the disparity axis + one all-gather per pair on every rank; the tail of
     # pair i (Regularization + estimator, not shardable) runs on rank i % N on a side stream instead of being
     # replicated N times (distributed.ShardedHotPath).
-    pipeline = ShardedHotPath(net._matching, tail) if world > 1 else None
+    # N = 1: the same two-stream schedule without the sharding: the tail of pair i overlaps Matching of pair i + 1 (its
+    # small 3-D layers leave most CUs idle).  --no-pipeline (and --graph) time strictly sequential pairs.
+    if world > 1:
+        pipeline = ShardedHotPath(net._matching, tail)
+    elif args.graph or args.no_pipeline:
+        pipeline = None
+    else:
+        pipeline = ShardedHotPath(net._matching, tail, max_pending=2)
 
     def step():
         if pipeline is not None:
@@ -238,6 +253,18 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     replica_elapsed = latency_elapsed = sharded_ok = None
+    if world == 1 and pipeline is not None:
+        # latency of one pair (no overlap across pairs), and a bit-exactness check of the pipelined results
+        with torch.no_grad():
+            for _ in range(2):
+                sequential_result = tail(net._matching(ld_g, rd_g), sc_g)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sequential_result = tail(net._matching(ld_g, rd_g), sc_g)
+            torch.cuda.synchronize(device)
+            latency_elapsed = time.perf_counter() - t0
+        sharded_ok = all(torch.equal(m, sequential_result) for m in mine) and len(mine) == args.steps
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,9 +334,18 @@ def main():
                        'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL) per pair; Regularization + '
                                        'estimator of pair i on rank i %% %d, overlapped with the next pair' % (world, world))
                        if world > 1 else 'single GPU',
-                       'launch': 'hip graph replay' if use_graph else 'eager'},
+                       'launch': 'hip graph replay' if use_graph else
+                                 ('eager, two HIP streams: Regularization + estimator of pair i overlap Matching of pair '
+                                  'i + 1 (ms_per_frame is the un-overlapped latency of one pair)'
+                                  if pipeline is not None and world == 1 else 'eager')},
         }
-        if sharded_ok is not None:
+        if world == 1 and latency_elapsed is not None:
+            line['pipelined_equals_sequential'] = sharded_ok
+            line['sequential'] = {'value': args.steps / latency_elapsed, 'unit': 'pairs/s',
+                                  'ms_per_frame': latency_elapsed / args.steps * 1e3,
+                                  'note': 'one pair strictly after the other on one stream (--no-pipeline times this '
+                                          'mode as value)'}
+        if world > 1 and sharded_ok is not None:
             line['sharded_equals_unsharded'] = sharded_ok
             line['latency_mode'] = {'ms_per_frame': latency_elapsed / args.steps * 1e3,
                                     'note': 'one pair at a time: sharded Matching + all-gather + tail replicated on '

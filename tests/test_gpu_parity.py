@@ -416,3 +416,28 @@ def test_config4_full_batch_runs(dev):
     assert ms.shape == (4, 8, 64, 96, 320) and disparity.shape == (4, 384, 1280)
     assert bool(torch.isfinite(disparity).all())
     assert float(disparity.min()) >= 0.0 and float(disparity.max()) <= 254.0 + 1e-3
+
+
+def test_two_stream_pipeline_is_bit_identical(dev):
+    """bench.py's default N = 1 schedule: distributed.ShardedHotPath without a process group runs the tail of pair i on
+    a side stream while Matching of pair i + 1 runs on the main stream; every result must equal the sequential one."""
+    from practicaldeepstereo_nips2018_amd.distributed import ShardedHotPath
+    net, ld, rd, shortcut = hot_path_inputs(63, 1, 128, 256)
+    net = net.to(dev)
+    reg, est = net._regularization, net._estimator
+
+    def tail(signatures, sc):
+        return reg.forward_with_estimator(signatures, sc, est)
+
+    pairs = []
+    g = torch.Generator().manual_seed(77)
+    for _ in range(5):
+        noise = torch.randn(ld.shape, generator=g) * 0.05
+        pairs.append(((ld + noise).to(dev), (rd - noise).to(dev), shortcut.to(dev)))
+    with torch.no_grad():
+        sequential = [tail(net._matching(a, b), c).clone() for a, b, c in pairs]
+        hot_path = ShardedHotPath(net._matching, tail, max_pending=2)
+        pipelined = [hot_path.submit(a, b, c) for a, b, c in pairs]
+        hot_path.drain()
+    for want, got in zip(sequential, pipelined):
+        assert got is not None and torch.equal(got, want)
