@@ -4,10 +4,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Pairs arrive as a stream: at N = 1 the tail of pair i (Regularization + SubpixelMap, whose small 3-D layers leave most
-CUs idle) runs on a second HIP stream while Matching of pair i + 1 runs on the first; "value" is that throughput,
-"ms_per_frame" / "sequential" the un-overlapped latency of one pair (--no-pipeline times that mode as value), and
-every pipelined result is checked bit for bit against the sequential one.
+Pairs arrive as a stream: at N = 1 whole pairs are dealt round-robin to three HIP streams, so the HBM- and
+latency-bound phases of one pair (factorised first layers, streaming kernels, the small 3-D layers) run beside the
+MFMA-bound kernels of another; "value" is that throughput, "ms_per_frame" / "sequential" the un-overlapped latency of
+one pair (--no-pipeline times that mode as value), and every pipelined result is checked bit for bit against the
+sequential one.
 
 A step = one stereo pair through Matching -> Regularization -> SubpixelMap (eval mode) at
 BASELINE.json configs[1]: 960x540 (padded 576x960), D=192 (maximum_disparity 191), fp32, random-init
@@ -44,7 +45,7 @@ if ROOT not in sys.path:
 
 import practicaldeepstereo_nips2018_amd as pds  # noqa: E402
 from practicaldeepstereo_nips2018_amd import _lib  # noqa: E402
-from practicaldeepstereo_nips2018_amd.distributed import ShardedHotPath, ShardedMatching  # noqa: E402
+from practicaldeepstereo_nips2018_amd.distributed import PairStreams, ShardedHotPath, ShardedMatching  # noqa: E402
 
 HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
@@ -64,9 +65,10 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=3, help='N = 1: HIP streams the pairs are dealt to (round-robin)')
     ap.add_argument('--no-pipeline', action='store_true',
-                    help='N = 1: one pair strictly after the other on one stream (latency mode) instead of overlapping '
-                         'the Regularization + estimator tail of pair i with Matching of pair i + 1 on two streams')
+                    help='N = 1: one pair strictly after the other on one stream (latency mode) instead of dealing whole '
+                         'pairs round-robin to --streams HIP streams')
     ap.add_argument('--kernel-reps', type=int, default=10)
     ap.add_argument('--graph', action='store_true',
                     help='replay the hot path as one captured HIP graph (N = 1); measured equal to eager launches '
@@ -194,14 +196,16 @@ def main():
     # N > 1: Matching sharded along the disparity axis + one all-gather per pair on every rank; the tail of
     # pair i (Regularization + estimator, not shardable) runs on rank i % N on a side stream instead of being
     # replicated N times (distributed.ShardedHotPath).
-    # N = 1: the same two-stream schedule without the sharding: the tail of pair i overlaps Matching of pair i + 1 (its
-    # small 3-D layers leave most CUs idle).  --no-pipeline (and --graph) time strictly sequential pairs.
+    # N = 1: whole pairs are dealt round-robin to a few HIP streams (distributed.PairStreams): the HBM- and latency-bound
+    # phases of one pair run beside the MFMA-bound kernels of another.  --no-pipeline (and --graph) time strictly
+    # sequential pairs.
     if world > 1:
         pipeline = ShardedHotPath(net._matching, tail)
     elif args.graph or args.no_pipeline:
         pipeline = None
     else:
-        pipeline = ShardedHotPath(net._matching, tail, max_pending=2)
+        pipeline = PairStreams(lambda left, right, shortcut: tail(net._matching(left, right), shortcut),
+                               streams=args.streams)
 
     def step():
         if pipeline is not None:
@@ -335,8 +339,8 @@ def main():
                                        'estimator of pair i on rank i %% %d, overlapped with the next pair' % (world, world))
                        if world > 1 else 'single GPU',
                        'launch': 'hip graph replay' if use_graph else
-                                 ('eager, two HIP streams: Regularization + estimator of pair i overlap Matching of pair '
-                                  'i + 1 (ms_per_frame is the un-overlapped latency of one pair)'
+                                 ('eager, whole pairs round-robin over %d HIP streams (ms_per_frame is the un-overlapped '
+                                  'latency of one pair)' % args.streams
                                   if pipeline is not None and world == 1 else 'eager')},
         }
         if world == 1 and latency_elapsed is not None:

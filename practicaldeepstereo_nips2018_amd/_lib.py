@@ -197,16 +197,20 @@ def gradient_buffers(module):
 
 
 class Workspace(object):
-    """Grow-only device scratch buffer reused across calls of one module (same stream => safe)."""
+    """Grow-only device scratch buffers of one module, one per (device, stream): calls on the same stream reuse the
+    buffer (stream order makes that safe), calls on different streams -- two pairs in flight -- never share one."""
 
     def __init__(self):
-        self._buf = None
+        self._buffers = {}
 
     def get(self, nbytes, device):
-        if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
-            self._buf = None
-            self._buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        return self._buf
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        buf = self._buffers.get(key)
+        if buf is None or buf.numel() < nbytes:
+            self._buffers[key] = None
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._buffers[key] = buf
+        return buf
 
 
 def not_differentiable(name):

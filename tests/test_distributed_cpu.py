@@ -145,3 +145,16 @@ def test_single_process_passthrough():
     sharded = pdist.ShardedMatching(CpuShardMatching(3))
     left, right = torch.randn(1, 2, 3, 5), torch.randn(1, 2, 3, 5)
     assert torch.equal(sharded(left, right), oracle.matching(left, right, 3, mock_operation))
+
+
+def test_pair_streams_runs_inline_on_cpu():
+    calls = []
+
+    def hot_path(a, b):
+        calls.append(1)
+        return a + b
+
+    streams = pdist.PairStreams(hot_path, streams=3)
+    outs = [streams.submit(torch.full((2,), float(i)), torch.ones(2)) for i in range(4)]
+    streams.drain()
+    assert len(calls) == 4 and all(torch.equal(o, torch.full((2,), float(i) + 1)) for i, o in enumerate(outs))

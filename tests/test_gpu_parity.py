@@ -418,10 +418,11 @@ def test_config4_full_batch_runs(dev):
     assert float(disparity.min()) >= 0.0 and float(disparity.max()) <= 254.0 + 1e-3
 
 
-def test_two_stream_pipeline_is_bit_identical(dev):
-    """bench.py's default N = 1 schedule: distributed.ShardedHotPath without a process group runs the tail of pair i on
-    a side stream while Matching of pair i + 1 runs on the main stream; every result must equal the sequential one."""
-    from practicaldeepstereo_nips2018_amd.distributed import ShardedHotPath
+def test_stream_pipelines_are_bit_identical(dev):
+    """bench.py's default N = 1 schedule (distributed.PairStreams: whole pairs round-robin over three streams, every
+    module with one workspace per stream) and the tail-only overlap of distributed.ShardedHotPath without a process
+    group: every result must equal the sequential one."""
+    from practicaldeepstereo_nips2018_amd.distributed import PairStreams, ShardedHotPath
     net, ld, rd, shortcut = hot_path_inputs(63, 1, 128, 256)
     net = net.to(dev)
     reg, est = net._regularization, net._estimator
@@ -429,15 +430,21 @@ def test_two_stream_pipeline_is_bit_identical(dev):
     def tail(signatures, sc):
         return reg.forward_with_estimator(signatures, sc, est)
 
+    def whole(a, b, c):
+        return tail(net._matching(a, b), c)
+
     pairs = []
     g = torch.Generator().manual_seed(77)
-    for _ in range(5):
+    for _ in range(7):
         noise = torch.randn(ld.shape, generator=g) * 0.05
         pairs.append(((ld + noise).to(dev), (rd - noise).to(dev), shortcut.to(dev)))
     with torch.no_grad():
-        sequential = [tail(net._matching(a, b), c).clone() for a, b, c in pairs]
+        sequential = [whole(a, b, c).clone() for a, b, c in pairs]
+        streams = PairStreams(whole, streams=3)
+        dealt = [streams.submit(a, b, c) for a, b, c in pairs]
+        streams.drain()
         hot_path = ShardedHotPath(net._matching, tail, max_pending=2)
-        pipelined = [hot_path.submit(a, b, c) for a, b, c in pairs]
+        overlapped = [hot_path.submit(a, b, c) for a, b, c in pairs]
         hot_path.drain()
-    for want, got in zip(sequential, pipelined):
-        assert got is not None and torch.equal(got, want)
+    for want, got, got2 in zip(sequential, dealt, overlapped):
+        assert torch.equal(got, want) and torch.equal(got2, want)
