@@ -200,16 +200,20 @@ class Workspace(object):
     """Grow-only device scratch buffers of one module, one per (device, stream): calls on the same stream reuse the
     buffer (stream order makes that safe), calls on different streams -- two pairs in flight -- never share one."""
 
+    MAX_STREAMS = 8   # buffers kept (least recently used first out): streams come and go in a long-lived process
+
     def __init__(self):
         self._buffers = {}
 
     def get(self, nbytes, device):
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-        buf = self._buffers.get(key)
+        buf = self._buffers.pop(key, None)
         if buf is None or buf.numel() < nbytes:
-            self._buffers[key] = None
+            buf = None
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-            self._buffers[key] = buf
+        self._buffers[key] = buf               # most recently used last
+        while len(self._buffers) > self.MAX_STREAMS:
+            self._buffers.pop(next(iter(self._buffers)))
         return buf
 
 
