@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=3, help='N = 1: HIP streams the pairs are dealt to (round-robin)')
+    ap.add_argument('--sharded-streams', type=int, default=2,
+                    help='N > 1: HIP streams the (sharded) pairs are dealt to on every rank; 1 = main stream + tail stream')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='N = 1: one pair strictly after the other on one stream (latency mode) instead of dealing whole '
                          'pairs round-robin to --streams HIP streams')
@@ -200,7 +202,7 @@ def main():
     # phases of one pair run beside the MFMA-bound kernels of another.  --no-pipeline (and --graph) time strictly
     # sequential pairs.
     if world > 1:
-        pipeline = ShardedHotPath(net._matching, tail)
+        pipeline = ShardedHotPath(net._matching, tail, streams=args.sharded_streams)
     elif args.graph or args.no_pipeline:
         pipeline = None
     else:
@@ -336,7 +338,8 @@ def main():
             'config': {'workload': 'configs[1]: 960x540 pair padded to 576x960, D=192 (48 matching planes, 96 cost '
                                    'planes), batch 1, eval mode, random-init weights seed 0',
                        'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL) per pair; Regularization + '
-                                       'estimator of pair i on rank i %% %d, overlapped with the next pair' % (world, world))
+                                       'estimator of pair i on rank i %% %d; pairs dealt to %d streams per rank' %
+                                       (world, world, args.sharded_streams))
                        if world > 1 else 'single GPU',
                        'launch': 'hip graph replay' if use_graph else
                                  ('eager, whole pairs round-robin over %d HIP streams (ms_per_frame is the un-overlapped '

@@ -86,7 +86,7 @@ class ShardedHotPath(object):
     stream -- has returned) and ``None`` on the other ranks.
     """
 
-    def __init__(self, matching_module, tail, group=None, max_pending=4):
+    def __init__(self, matching_module, tail, group=None, max_pending=4, streams=1):
         self._sharded = ShardedMatching(matching_module, group)
         self._tail = tail
         self._group = group
@@ -94,6 +94,16 @@ class ShardedHotPath(object):
         self._submitted = 0
         self._side = None
         self._pending = []   # completion events of this rank's unfinished tails (GPU only)
+        # streams > 1: whole pairs (this rank's planes, the all-gather and, on the owner, the tail) are dealt
+        # round-robin to that many HIP streams (PairStreams below): the small per-rank shards of one pair leave the
+        # GPU under-used, the next pair fills it.  Collectives stay in program order on every rank (they are issued
+        # by one host thread and funnel through the process group's communication stream).
+        self._lanes = PairStreams(self._whole_pair, streams=streams) if streams > 1 else None
+
+    def _whole_pair(self, index, left_embedding, right_embedding, shortcut_from_left):
+        rank, world = self._world()
+        signatures = self._sharded(left_embedding, right_embedding)
+        return self._tail(signatures, shortcut_from_left) if index % world == rank else None
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -107,6 +117,8 @@ class ShardedHotPath(object):
         rank, world = self._world()
         index = self._submitted
         self._submitted += 1
+        if self._lanes is not None and left_embedding.is_cuda:
+            return self._lanes.submit(index, left_embedding, right_embedding, shortcut_from_left)
         signatures = self._sharded(left_embedding, right_embedding)
         if index % world != rank:
             return None
@@ -134,6 +146,8 @@ class ShardedHotPath(object):
 
     def drain(self):
         """Blocks the main stream (and the host) until every tail submitted on this rank has finished."""
+        if self._lanes is not None:
+            self._lanes.drain()
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
             self._side.synchronize()
