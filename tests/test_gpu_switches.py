@@ -1,0 +1,37 @@
+"""GPU (-m gpu): the alternative kernel paths behind the runtime switches of DESIGN.md 8.1 stay correct.
+
+The switches are read once per process (static initialisers in libpds_hip.so), so every configuration runs the
+single-layer suite (tests/test_gpu_conv_block.py) and the small fused-Matching parity cases in a fresh interpreter."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWITCHES = [
+    {'PDS_WINOGRAD': '0'},          # direct MFMA kernel for the 64-channel layers
+    {'PDS_WINO2D': '1'},            # 2-D Winograd kernel with role-specialised waves
+    {'PDS_WINO_WAVES': '4'},        # 4-wave form of the F(2,3) kernel
+    {'PDS_CONV2D_PAIRS': '1'},      # 8-byte staging in the direct kernel
+    {'PDS_CONV2D_KC8': '1'},        # 8-channel chunks in the single-block direct kernels
+    {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
+    {'PDS_CONV3D_XCD_MAP': '0'},
+]
+
+
+@pytest.mark.parametrize('switch', SWITCHES, ids=lambda s: '_'.join('%s=%s' % kv for kv in s.items()))
+def test_alternative_paths(hip_library, switch):
+    env = dict(os.environ)
+    env.update(switch)
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+           'tests/test_gpu_conv_block.py',
+           'tests/test_gpu_parity.py::test_fused_matching_shapes_vs_oracle',
+           'tests/test_gpu_parity.py::test_fused_matching_golden',
+           'tests/test_gpu_parity.py::test_config1_hot_path_vs_golden',
+           'tests/test_gpu_parity.py::test_regularization_golden']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = out.stdout.decode(errors='replace')[-2000:]
+    assert out.returncode == 0, tail
