@@ -60,14 +60,29 @@ def sources():
 
 
 def build_library(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into libpds_hip.so (cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 into libpds_hip.so (cross-compiles without a GPU): one object per source,
+    compiled in parallel, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
     deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hpp')] + [HEADER_PATH]
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-o', LIB_PATH] + srcs
+    objdir = os.path.join(os.path.dirname(_PKG_DIR), 'build', 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
+        cmd = ['hipcc'] + flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
