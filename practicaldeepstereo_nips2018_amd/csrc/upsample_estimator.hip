@@ -43,10 +43,16 @@ struct FusedArgs {
 
 // WRITE_COST = true: training-mode forward, every finished plane is stored to the cost volume and no
 // estimator state is kept (T is ignored).
-template <int CIN, int T, bool WRITE_COST>
-__global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedArgs A) {
-    __shared__ __attribute__((aligned(16))) float tile[2][CIN][NPOS + 4];
-    const int lane = threadIdx.x;
+// A workgroup is TWO waves on the same input tile: wave PY owns the output rows of parity PY (4 pixels per lane instead
+// of 2 x 4).  One wave per tile left a single wave per SIMD on the chip (1080 tiles on 1024 SIMDs): nothing hid the
+// LDS / scalar-load latencies of the sweep.
+constexpr int UTHREADS = 128;
+constexpr int UPOS = (NPOS + UTHREADS - 1) / UTHREADS;   // 2 staged positions per thread and channel
+
+template <int CIN, int T, bool WRITE_COST, int PY>
+__device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)[CIN][NPOS + 4]) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int r = lane >> 4, cp = lane & 15;
     const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
     const int b = blockIdx.z;
@@ -54,11 +60,11 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
     const size_t cstride = (size_t)A.D * plane;
     const float* src = A.in + (size_t)b * CIN * cstride;
 
-    int goff[POS], loff[POS];
-    bool inside[POS];
+    int goff[UPOS], loff[UPOS];
+    bool inside[UPOS];
 #pragma unroll
-    for (int k = 0; k < POS; ++k) {
-        const int p = min(lane + k * 64, NPOS - 1);
+    for (int k = 0; k < UPOS; ++k) {
+        const int p = min(tid + k * UTHREADS, NPOS - 1);
         const int rr = p / HC, cc = p % HC;
         const int y = i0 - 1 + rr, x = j0 - 1 + cc;
         inside[k] = y >= 0 && y < A.Hi && x >= 0 && x < A.Wi;
@@ -73,21 +79,21 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
     }
     const float bias = A.bias ? A.bias[0] : 0.f;
 
-    float st[CIN][POS];
+    float st[CIN][UPOS];
 #define PDS_FETCHP(p_)                                                             \
-    _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < POS; ++k) \
+    _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < UPOS; ++k) \
         st[c][k] = src[c * cstride + (size_t)(p_) * plane + goff[k]];
 #define PDS_STASHP(buf_)                                                           \
-    _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < POS; ++k) \
+    _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < UPOS; ++k) \
         tile[buf_][c][loff[k]] = inside[k] ? fmaf(sc[c], st[c][k], sh[c]) : 0.f;
 
-    // estimator state for the 2 x 4 pixels of this lane: a delayed window win[0..2T] of the last finished
-    // planes (win[2T] newest).  When the centre win[T] (plane k - T) beats the running maximum, its T
+    // estimator state for the 4 pixels of this lane (output row 2 i + PY): a delayed window win[0..2T] of the last
+    // finished planes (win[2T] newest).  When the centre win[T] (plane k - T) beats the running maximum, its T
     // neighbours on either side are captured from the window -- static register indices only.
-    float best[8], win[8][2 * T + 1], bprev[8][T], bnext[8][T];
-    int bi[8];
+    float best[4], win[4][2 * T + 1], bprev[4][T], bnext[4][T];
+    int bi[4];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
+    for (int o = 0; o < 4; ++o) {
         best[o] = -INFINITY;
         bi[o] = 0;
 #pragma unroll
@@ -95,10 +101,10 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
 #pragma unroll
         for (int t = 0; t < 2 * T + 1; ++t) win[o][t] = -INFINITY;
     }
-    // accumulators: [0] -> output plane p-1, [1] -> p, [2] -> p+1 ; pixel index o = py * 4 + q
-    float acc[3][8];
+    // accumulators: [0] -> output plane p-1, [1] -> p, [2] -> p+1 ; pixel index q (four consecutive output columns)
+    float acc[3][4];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[0][o] = acc[1][o] = acc[2][o] = bias;
+    for (int o = 0; o < 4; ++o) acc[0][o] = acc[1][o] = acc[2][o] = bias;
 
     PDS_FETCHP(0)
     PDS_STASHP(0)
@@ -111,20 +117,21 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
             if (p + 1 < A.D) PDS_FETCHP(p + 1)
 #pragma nounroll
             for (int c = 0; c < CIN; ++c) {  // not unrolled: keeps only 3 x 16 weight SGPRs live
-                float v[3][4];
+                // the two halo rows this output-row parity uses: vr = 1 (tap kh = 1 / 2) and vr = 0 / 2 (kh = 3 / 0)
+                float v[2][4];
 #pragma unroll
-                for (int vr = 0; vr < 3; ++vr) {
+                for (int a = 0; a < 2; ++a) {
+                    const int vr = (a == 0) ? 1 : (PY == 0 ? 0 : 2);
                     const float2 lo2 = *reinterpret_cast<const float2*>(&tile[cur][c][lbase + vr * HC]);
                     const float2 hi2 = *reinterpret_cast<const float2*>(&tile[cur][c][lbase + vr * HC + 2]);
-                    v[vr][0] = lo2.x;
-                    v[vr][1] = lo2.y;
-                    v[vr][2] = hi2.x;
-                    v[vr][3] = hi2.y;
+                    v[a][0] = lo2.x;
+                    v[a][1] = lo2.y;
+                    v[a][2] = hi2.x;
+                    v[a][3] = hi2.y;
                 }
                 // the 3 x 16 taps of channel c as SGPR operands: explicit s_load_dwordx16 (hipcc turns plain reads of
                 // the weight pointer into vector loads parked in VGPRs, which spills this kernel); the three loads
-                // are issued back to back and share ONE wait (a wait per load left the wave stalled for most of a
-                // plane: 12 scalar-cache round trips against 1.5 k cycles of FMAs)
+                // are issued back to back and share one wait
                 f32x16 wk[3];
                 asm volatile(
                     "s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\t"
@@ -136,20 +143,16 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
                 for (int kd = 0; kd < 3; ++kd) {
                     const f32x16 wp = wk[kd];
 #pragma unroll
-                    for (int py = 0; py < 2; ++py) {
+                    for (int a = 0; a < 2; ++a) {
+                        const int kh = (PY == 0) ? (a == 0 ? 1 : 3) : (a == 0 ? 2 : 0);
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            const int vr = (a == 0) ? 1 : (py == 0 ? 0 : 2);
-                            const int kh = (py == 0) ? (a == 0 ? 1 : 3) : (a == 0 ? 2 : 0);
+                        for (int q = 0; q < 4; ++q) {
+                            const int px = q & 1, jc = 1 + (q >> 1);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int px = q & 1, jc = 1 + (q >> 1);
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) {
-                                    const int vc = (e == 0) ? jc : (px == 0 ? jc - 1 : jc + 1);
-                                    const int kw = (px == 0) ? (e == 0 ? 1 : 3) : (e == 0 ? 2 : 0);
-                                    acc[kd][py * 4 + q] = fmaf(wp[kh * 4 + kw], v[vr][vc], acc[kd][py * 4 + q]);
-                                }
+                            for (int e = 0; e < 2; ++e) {
+                                const int vc = (e == 0) ? jc : (px == 0 ? jc - 1 : jc + 1);
+                                const int kw = (px == 0) ? (e == 0 ? 1 : 3) : (e == 0 ? 2 : 0);
+                                acc[kd][q] = fmaf(wp[kh * 4 + kw], v[a][vc], acc[kd][q]);
                             }
                         }
                     }
@@ -163,16 +166,12 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
                 const int i = i0 + r, j = j0 + 2 * cp;
                 if (i < A.Hi && j < A.Wi) {
                     const int Wo = 2 * A.Wi;
-                    float* dst0 = A.cost + (((size_t)b * A.D + (p - 1)) * 2 * A.Hi + 2 * i) * Wo + 2 * j;
-                    float* dst1 = dst0 + Wo;
+                    float* dst = A.cost + (((size_t)b * A.D + (p - 1)) * 2 * A.Hi + 2 * i + PY) * Wo + 2 * j;
                     if (j + 1 < A.Wi) {
-                        *reinterpret_cast<float4*>(dst0) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-                        *reinterpret_cast<float4*>(dst1) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
                     } else {
-                        dst0[0] = acc[0][0];
-                        dst0[1] = acc[0][1];
-                        dst1[0] = acc[0][4];
-                        dst1[1] = acc[0][5];
+                        dst[0] = acc[0][0];
+                        dst[1] = acc[0][1];
                     }
                 }
             }
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
             const int k = p - 1;          // plane entering the window (a real plane while k < D)
             const int centre = k - T;     // plane now at the centre of the window
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
+            for (int o = 0; o < 4; ++o) {
 #pragma unroll
                 for (int t = 0; t < 2 * T; ++t) win[o][t] = win[o][t + 1];
                 win[o][2 * T] = k < A.D ? acc[0][o] : -INFINITY;
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
             }
         }
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < 4; ++o) {
             acc[0][o] = acc[1][o];
             acc[1][o] = acc[2][o];
             acc[2][o] = bias;
@@ -208,9 +207,9 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
     // soft-arg-max around the best plane (estimator.py:84-91)
     const int planes = A.D;
     const int i = i0 + r, j = j0 + 2 * cp;
-    float res[8];
+    float res[4];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
+    for (int o = 0; o < 4; ++o) {
         float den = 1.f;
         float num = A.step * (float)bi[o];
 #pragma unroll
@@ -230,18 +229,23 @@ __global__ __launch_bounds__(64) void upsample_full_subpixel_kernel(const FusedA
     }
     if (i < A.Hi && j < A.Wi) {
         const int Wo = 2 * A.Wi;
-        float* dst0 = A.disp + ((size_t)b * 2 * A.Hi + 2 * i) * Wo + 2 * j;
-        float* dst1 = dst0 + Wo;
+        float* dst = A.disp + ((size_t)b * 2 * A.Hi + 2 * i + PY) * Wo + 2 * j;
         if (j + 1 < A.Wi) {
-            *reinterpret_cast<float4*>(dst0) = make_float4(res[0], res[1], res[2], res[3]);
-            *reinterpret_cast<float4*>(dst1) = make_float4(res[4], res[5], res[6], res[7]);
+            *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
         } else {
-            dst0[0] = res[0];
-            dst0[1] = res[1];
-            dst1[0] = res[4];
-            dst1[1] = res[5];
+            dst[0] = res[0];
+            dst[1] = res[1];
         }
     }
+}
+
+template <int CIN, int T, bool WRITE_COST>
+__global__ __launch_bounds__(UTHREADS) void upsample_full_subpixel_kernel(const FusedArgs A) {
+    __shared__ __attribute__((aligned(16))) float tile[2][CIN][NPOS + 4];
+    if ((threadIdx.x >> 6) == 0)
+        upsample_sweep<CIN, T, WRITE_COST, 0>(A, tile);
+    else
+        upsample_sweep<CIN, T, WRITE_COST, 1>(A, tile);
 }
 
 bool upsample_estimator_supported(int cin, int lo, int hi) {
@@ -270,11 +274,11 @@ int launch_upsample_estimator(const float* in, const float* scale, const float* 
     if (cin != 4) return set_error(-1, "upsample_estimator: unsupported channel count %d", cin);
     A.cost = nullptr;
     if (t <= 1)
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, false>), grid, dim3(64), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, false>), grid, dim3(UTHREADS), 0, s, A);
     else if (t <= 2)
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2, false>), grid, dim3(64), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2, false>), grid, dim3(UTHREADS), 0, s, A);
     else
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4, false>), grid, dim3(64), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4, false>), grid, dim3(UTHREADS), 0, s, A);
     return check_launch("upsample_full_subpixel");
 }
 
@@ -299,7 +303,7 @@ int launch_upsample_full(const float* in, const float* scale, const float* shift
     A.hi = 0;
     A.step = 0.f;
     dim3 grid((wi + TC - 1) / TC, (hi_ + TR - 1) / TR, batch);
-    hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, true>), grid, dim3(64), 0, s, A);
+    hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, true>), grid, dim3(UTHREADS), 0, s, A);
     return check_launch("upsample_full");
 }
 
