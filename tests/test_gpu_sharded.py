@@ -50,6 +50,14 @@ def worker(rank, world, port, results):
             for out, left, right, shortcut in outputs:
                 if out is not None:
                     ok = ok and torch.equal(out, tail(net._matching(left, right), shortcut))
+            # the same stream of pairs dealt to two HIP streams per rank (bench.py's N > 1 default)
+            lanes = ShardedHotPath(net._matching, tail, streams=2)
+            dealt = [lanes.submit(left, right, shortcut) for _, left, right, shortcut in outputs]
+            lanes.drain()
+            for i, (got, (want, _, _, _)) in enumerate(zip(dealt, outputs)):
+                ok = ok and ((got is not None) == (i % world == rank))
+                if got is not None:
+                    ok = ok and torch.equal(got, want)
             # the plain sharded module (all-gather on every rank) as well
             _, left, right, _ = outputs[0]
             ok = ok and torch.equal(ShardedMatching(net._matching)(left, right), net._matching(left, right))
