@@ -51,6 +51,9 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma
 bool conv3d_mfma_supported(const ConvLayer& L);
 int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
 size_t conv3d_mfma_packed_floats(const Geom& out_g, int cin, int stride);
+int launch_conv3d_t8(const ConvLayer& L, hipStream_t s);          // conv3d_t8.hip (8 -> 8 channels, stride 1)
+bool conv3d_t8_supported(const ConvLayer& L);
+int conv3d_t8_records(const Geom& out_g);
 int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s);
 bool deconv3d_mfma_supported(const DeconvLayer& L);
 int deconv3d_mfma_tiles(const Geom& in_g);
@@ -273,6 +276,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     // Winograd domain (plain single-source Cin -> 64 layers)
     int kind = 0;
     if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino2d_eligible(L) ? 5 : conv2d_wino_eligible(L) ? 4 : 2;
+    else if (allow_mfma && conv3d_t8_supported(L)) kind = 6;   // persistent z-Toeplitz kernel, no weight packing
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
     if (kind == 2)
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
@@ -288,16 +292,20 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         return kind == 2 ? launch_conv2d_mfma(L, c.s)
                          : kind == 4 ? launch_conv2d_wino(L, c.s)
                          : kind == 5 ? launch_conv2d_wino2d(L, c.s)
-                                     : kind == 3 ? launch_conv3d_mfma(L, c.s) : launch_conv_direct(L, c.s);
+                                     : kind == 3 ? launch_conv3d_mfma(L, c.s)
+                                                 : kind == 6 ? launch_conv3d_t8(L, c.s) : launch_conv_direct(L, c.s);
     };
     const bool collecting = c.sink && c.sink->phase == kPackCollect && c.base != nullptr;
-    if (collecting && kind != 0) c.run(launch());  // registers the pack job(s) only
+    if (collecting && kind != 0 && kind != 6) c.run(launch());  // registers the pack job(s) only
     if (norm) {
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
                                     : kind == 4 ? conv2d_wino_tiles(o.g)
-                                    : kind == 5 ? conv2d_wino2d_tiles(o.g) : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride) : conv_direct_tiles_for(o.g, stride);
-        const size_t records = (size_t)o.g.n * o.g.c * (kind == 3 ? 1 : o.g.d) * tiles;
+                                    : kind == 5 ? conv2d_wino2d_tiles(o.g)
+                                    : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride)
+                                    : kind == 6 ? conv3d_t8_records(o.g) : conv_direct_tiles_for(o.g, stride);
+        const bool volume_records = kind == 3 || kind == 6;   // [(n, c)][record] instead of [(n, c, d)][tile]
+        const size_t records = (size_t)o.g.n * o.g.c * (volume_records ? 1 : o.g.d) * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
         o.scale = scale_out ? scale_out : c.get<float>(groups);
@@ -306,7 +314,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         o.rstd = c.get<float>(groups);
         if (!c.plan) {
             c.run(launch());
-            const int per_group = kind == 3 ? tiles : tiles * (per_plane ? 1 : o.g.d);
+            const int per_group = volume_records ? tiles : tiles * (per_plane ? 1 : o.g.d);
             const double count = (double)o.g.h * o.g.w * (per_plane ? 1 : o.g.d);
             c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
                                      per_plane ? o.g.d : 1, o.scale, o.shift, o.mean, o.rstd, c.s));

@@ -27,15 +27,9 @@ def shard_range(number_of_planes, rank, world_size):
     return rank * per_rank, per_rank
 
 
-def gather_planes(local_planes, group=None):
-    """All-gathers [batch, C, D_local, h, w] shards along dim 2 in rank order.
-
-    One collective: all_gather_into_tensor into a rank-major staging buffer, then one strided
-    copy into the [batch, C, D, h, w] layout Regularization consumes."""
-    world_size = dist.get_world_size(group)
-    if world_size == 1:
-        return local_planes
+def _gather_planes_raw(local_planes, group):
     local_planes = local_planes.contiguous()
+    world_size = dist.get_world_size(group)
     batch, channels, d_local, h, w = local_planes.shape
     # flat buffers: every backend (RCCL and gloo) accepts "output = world_size x input" along dim 0
     staged = local_planes.new_empty(world_size * local_planes.numel())
@@ -44,24 +38,121 @@ def gather_planes(local_planes, group=None):
     return staged.permute(1, 2, 0, 3, 4, 5).reshape(batch, channels, world_size * d_local, h, w)
 
 
+class _GatherPlanes(torch.autograd.Function):
+    """Differentiable all-gather along the disparity axis.  What follows the gather (Regularization, the loss) is
+    REPLICATED on every rank, so every rank holds the same upstream gradient and the adjoint of the gather is the
+    rank's own slice of it -- no collective in backward (the cross-rank sums happen where the replicated region is
+    entered: ``_ReplicatedInput`` for the descriptors, gradient hooks for the wrapped module's parameters)."""
+
+    @staticmethod
+    def forward(ctx, local_planes, group):
+        ctx.group = group
+        ctx.d_local = local_planes.shape[2]
+        return _gather_planes_raw(local_planes, group)
+
+    @staticmethod
+    def backward(ctx, grad_gathered):
+        begin = dist.get_rank(ctx.group) * ctx.d_local
+        return grad_gathered[:, :, begin:begin + ctx.d_local].contiguous(), None
+
+
+class _ReplicatedInput(torch.autograd.Function):
+    """Identity on the way into the sharded region; in backward the per-rank partial gradients (each rank saw only
+    its disparity planes) are summed over the ranks, so whatever produced the input -- the descriptor network --
+    receives the full gradient on every rank."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        grad = grad.contiguous()
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=ctx.group)
+        return grad, None
+
+
+def gather_planes(local_planes, group=None):
+    """All-gathers [batch, C, D_local, h, w] shards along dim 2 in rank order.
+
+    One collective: all_gather_into_tensor into a rank-major staging buffer, then one strided
+    copy into the [batch, C, D, h, w] layout Regularization consumes.  Differentiable: the
+    gradient of a shard is the matching slice of the (replicated) gradient of the gathered tensor."""
+    world_size = dist.get_world_size(group)
+    if world_size == 1:
+        return local_planes
+    if torch.is_grad_enabled() and local_planes.requires_grad:
+        return _GatherPlanes.apply(local_planes, group)
+    return _gather_planes_raw(local_planes, group)
+
+
 class ShardedMatching(nn.Module):
     """Wraps a ``Matching`` module so that each rank evaluates its slice of the disparity range and
     the full set of matching signatures is reassembled with one all-gather.  Same call signature
-    and result as the wrapped module (matching.py:34-63)."""
+    and result as the wrapped module (matching.py:34-63).
+
+    Training: the region after the gather is replicated, so with gradients enabled (i) the gather's
+    adjoint hands every rank its own slice, (ii) the gradients of the two descriptor inputs are summed
+    over the ranks on the way out and (iii) the wrapped module's parameter gradients -- partial sums
+    over the rank's planes -- are all-reduced by gradient hooks, all in autograd order, identical on
+    every rank.  After ``backward()`` every rank holds the full gradients of the unsharded network.
+
+    State dict: the wrapper adds no level to the key path (``net._matching = ShardedMatching(net._matching)``
+    keeps the reference's ``_matching._operation...`` keys), so reference checkpoints load into, and
+    are saved from, a wrapped network unchanged."""
 
     def __init__(self, matching_module, group=None):
         super(ShardedMatching, self).__init__()
         self._matching = matching_module
         self._group = group
+        self._hooked = False
+        self._register_state_dict_hook(self._strip_wrapper_prefix)
+        self._register_load_state_dict_pre_hook(self._add_wrapper_prefix)
+
+    @staticmethod
+    def _strip_wrapper_prefix(module, state_dict, prefix, local_metadata):
+        inner = prefix + '_matching.'
+        for key in [k for k in state_dict if k.startswith(inner)]:
+            state_dict[prefix + key[len(inner):]] = state_dict.pop(key)
+        return state_dict
+
+    @staticmethod
+    def _add_wrapper_prefix(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        inner = prefix + '_matching.'
+        for key in [k for k in state_dict if k.startswith(prefix) and not k.startswith(inner)]:
+            state_dict[inner + key[len(prefix):]] = state_dict.pop(key)
 
     def set_maximum_disparity(self, maximum_disparity):
         self._matching.set_maximum_disparity(maximum_disparity)
+
+    def _hook_parameter_gradients(self):
+        if self._hooked:
+            return
+        group = self._group
+
+        def reduce_over_ranks(grad):
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+                return grad
+            grad = grad.contiguous().clone()
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+            return grad
+        for p in self._matching.parameters():
+            p.register_hook(reduce_over_ranks)
+        self._hooked = True
 
     def forward(self, left_embedding, right_embedding):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self._group) == 1:
             return self._matching(left_embedding, right_embedding)
         planes = self._matching._maximum_disparity + 1
         shard = shard_range(planes, dist.get_rank(self._group), dist.get_world_size(self._group))
+        if torch.is_grad_enabled():
+            if left_embedding.requires_grad:
+                left_embedding = _ReplicatedInput.apply(left_embedding, self._group)
+            if right_embedding.requires_grad:
+                right_embedding = _ReplicatedInput.apply(right_embedding, self._group)
+            if any(p.requires_grad for p in self._matching.parameters()):
+                self._hook_parameter_gradients()
         self._matching.set_disparity_shard(shard)
         try:
             local = self._matching(left_embedding, right_embedding)
