@@ -58,6 +58,9 @@ int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s);
 bool deconv3d_mfma_supported(const DeconvLayer& L);
 int deconv3d_mfma_tiles(const Geom& in_g);
 size_t deconv3d_mfma_packed_floats(const Geom& in_g, int cout, int kd);
+int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s);    // deconv3d_cell.hip (dense cell form, k4 s2)
+bool deconv3d_cell_supported(const DeconvLayer& L);
+int deconv3d_cell_records(const Geom& in_g, int cout);
 bool upsample_estimator_supported(int cin, int lo, int hi);       // upsample_estimator.hip
 int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w,
                               const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
@@ -354,11 +357,16 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
     L.partials = nullptr;
     L.packed = nullptr;
     L.sink = c.sink;
-    const bool mfma = deconv3d_mfma_supported(L);
+    const bool cell = deconv3d_cell_supported(L);   // persistent dense-cell kernel: no weight packing
+    const bool mfma = !cell && deconv3d_mfma_supported(L);
     if (mfma) L.packed = c.get<float>(deconv3d_mfma_packed_floats(in, cout, kd));
     if (mfma && c.sink && c.sink->phase == kPackCollect && c.base != nullptr) c.run(launch_deconv3d_mfma(L, c.s));
-    // partial records per (n, c): direct kernel [d][tile]; MFMA kernel [tile][parity class]
-    const int per_group = mfma ? deconv3d_mfma_tiles(in) * (kd == 4 ? 8 : 4) : deconv_direct_tiles(o.g) * o.g.d;
+    auto launch = [&]() {
+        return cell ? launch_deconv3d_cell(L, c.s) : mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s);
+    };
+    // partial records per (n, c): cell kernel [workgroup]; MFMA kernel [tile][parity class]; direct kernel [d][tile]
+    const int per_group = cell ? deconv3d_cell_records(in, cout)
+                               : mfma ? deconv3d_mfma_tiles(in) * (kd == 4 ? 8 : 4) : deconv_direct_tiles(o.g) * o.g.d;
     if (norm) {
         const size_t records = (size_t)o.g.n * o.g.c * per_group;
         L.partials = c.get<double>(records * 2);
@@ -368,12 +376,12 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
         o.mean = c.get<float>(groups);
         o.rstd = c.get<float>(groups);
         if (!c.plan) {
-            c.run(mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s));
+            c.run(launch());
             c.run(launch_in_finalize(L.partials, groups, per_group, (double)o.g.volume(), P.gamma, P.beta,
                                      o.g.c, 1, o.scale, o.shift, o.mean, o.rstd, c.s));
         }
     } else if (!c.plan) {
-        c.run(mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s));
+        c.run(launch());
     }
     tape_layer(c, 1, kd, kd == 4 ? 2 : 1, a, b, in, o, &P, norm);
     return o;
