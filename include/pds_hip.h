@@ -16,6 +16,11 @@
  *    calls are re-entrant and hipGraph-capturable.
  *  - return value 0 = enqueued; non-zero = error (negative: bad argument, positive:
  *    hipError_t).  pds_last_error() gives a thread-local message.  Nothing throws.
+ *  - `weights_resident` (the forward entry points that re-lay weights out): pass 0 unless this
+ *    very workspace was last used by the same entry point with the same shapes and the same
+ *    parameter VALUES; then 1 skips the weight re-layout launches (the packed weights a module
+ *    owns are immutable between optimizer steps).  The Python mirror tracks this
+ *    through the parameters' version counters.
  *  - argument validation that the reference does in Python (the ValueErrors of
  *    estimator.py:34-41, network.py:28-31) stays in the Python mirror.
  */
@@ -29,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDS_ABI_VERSION 1
+#define PDS_ABI_VERSION 2
 
 typedef void* pds_stream_t; /* hipStream_t */
 
@@ -95,7 +100,8 @@ size_t pds_matching_workspace_bytes(const PdsMatchingParams* params, int batch, 
 int pds_matching_fwd(const PdsMatchingParams* params,
                      const float* left, const float* right, float* signatures,
                      int batch, int h, int w, int d_begin, int d_count,
-                     void* workspace, size_t workspace_bytes, pds_stream_t stream);
+                     void* workspace, size_t workspace_bytes, int weights_resident,
+                     pds_stream_t stream);
 
 /* MatchingOperation.forward on an already concatenated tensor [n, 2*features, h, w]
  * -> [n, sig, h, w]                          reference matching.py:97-112 */
@@ -124,7 +130,8 @@ size_t pds_regularization_workspace_bytes(const PdsRegularizationParams* params,
 int pds_regularization_fwd(const PdsRegularizationParams* params,
                            const float* signatures, const float* left_shortcut, float* cost,
                            int batch, int d, int h, int w,
-                           void* workspace, size_t workspace_bytes, pds_stream_t stream);
+                           void* workspace, size_t workspace_bytes, int weights_resident,
+                           pds_stream_t stream);
 
 /* Eval-mode fusion of Regularization's last layer with SubpixelMap (network.py:50-51):
  * the full-resolution cost volume is never written.  disparities [batch, 4*h, 4*w]. */
@@ -133,7 +140,7 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params,
                                         float* disparities,
                                         int batch, int d, int h, int w,
                                         int half_support_window, int disparity_step,
-                                        void* workspace, size_t workspace_bytes,
+                                        void* workspace, size_t workspace_bytes, int weights_resident,
                                         pds_stream_t stream);
 
 /* ContractionBlock3d.forward                reference regularization.py:28-31
@@ -209,7 +216,7 @@ size_t pds_embedding_workspace_bytes(const PdsEmbeddingParams* params, int batch
                                      int pad_left);
 int pds_embedding_fwd(const PdsEmbeddingParams* params, const float* image, float* descriptor, float* shortcut,
                       int batch, int h, int w, int pad_top, int pad_left, void* workspace, size_t workspace_bytes,
-                      pds_stream_t stream);
+                      int weights_resident, pds_stream_t stream);
 /* backward (pds_trainer.py:40-46): needs the untouched forward workspace and the descriptor the forward call
  * returned; grad_descriptor is used as scratch (the shortcut branch's contribution is added to it in place) */
 size_t pds_embedding_bwd_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,

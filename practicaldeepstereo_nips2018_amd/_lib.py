@@ -59,22 +59,39 @@ def sources():
     return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hip'))
 
 
+BUILD_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+
+def _source_digest():
+    """sha256 over the compiler flags and every source / header the library is built from."""
+    import hashlib
+    h = hashlib.sha256(' '.join(BUILD_FLAGS).encode())
+    deps = sources() + sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hpp')) + [HEADER_PATH]
+    for path in deps:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into libpds_hip.so (cross-compiles without a GPU): one object per source,
-    compiled in parallel, then one link."""
+    compiled in parallel, then one link.  The library is rebuilt when the digest of flags + sources recorded next to
+    it differs from the tree's (a shipped .so with a stale or missing stamp is rebuilt, not trusted), or on ``force``."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hpp')] + [HEADER_PATH]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+    stamp = LIB_PATH + '.sha256'
+    digest = _source_digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return LIB_PATH
     objdir = os.path.join(os.path.dirname(_PKG_DIR), 'build', 'obj')
     os.makedirs(objdir, exist_ok=True)
-    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
-        cmd = ['hipcc'] + flags + ['-c', src, '-o', obj]
+        cmd = ['hipcc'] + BUILD_FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)
@@ -86,6 +103,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
+    with open(stamp, 'w') as f:
+        f.write(digest + '\n')
     return LIB_PATH
 
 
@@ -101,15 +120,15 @@ SIGNATURES = {
     'pds_shift_concat_fwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_matching_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
     'pds_matching_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I,
-                              _VP, _SZ, _VP]),
+                              _VP, _SZ, _I, _VP]),
     'pds_matching_operation_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I]),
     'pds_matching_operation_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _I, _I, _I,
                                         _VP, _SZ, _VP]),
     'pds_regularization_workspace_bytes': (_SZ, [ctypes.POINTER(RegularizationParams), _I, _I, _I, _I]),
     'pds_regularization_fwd': (_I, [ctypes.POINTER(RegularizationParams), _VP, _VP, _VP,
-                                    _I, _I, _I, _I, _VP, _SZ, _VP]),
+                                    _I, _I, _I, _I, _VP, _SZ, _I, _VP]),
     'pds_regularization_subpixel_map_fwd': (_I, [ctypes.POINTER(RegularizationParams), _VP, _VP, _VP,
-                                                 _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+                                                 _I, _I, _I, _I, _I, _I, _VP, _SZ, _I, _VP]),
     'pds_conv_block_workspace_bytes': (_SZ, [_I] * 9),
     'pds_conv_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _VP,
                                 _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
@@ -126,7 +145,8 @@ SIGNATURES = {
     'pds_expansion_block_bwd': (_I, [ctypes.POINTER(ConvBlockParams)] * 4 + [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I,
                                      _I, _VP, _SZ, _VP, _SZ, _VP]),
     'pds_embedding_workspace_bytes': (_SZ, [ctypes.POINTER(EmbeddingParams), _I, _I, _I, _I, _I]),
-    'pds_embedding_fwd': (_I, [ctypes.POINTER(EmbeddingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_embedding_fwd': (_I, [ctypes.POINTER(EmbeddingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _I,
+                               _VP]),
     'pds_embedding_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(EmbeddingParams), _I, _I, _I, _I, _I]),
     'pds_embedding_bwd': (_I, [ctypes.POINTER(EmbeddingParams)] * 2 + [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I,
                                _VP, _SZ, _VP, _SZ, _VP]),
@@ -211,25 +231,45 @@ def gradient_buffers(module):
     return grads, (lambda p: grads[id(p)])
 
 
+def parameter_signature(module):
+    """Identity and version of every parameter: equal signatures mean equal parameter VALUES (in-place updates by an
+    optimizer or load_state_dict bump ``_version``; re-assignment changes ``data_ptr``)."""
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
 class Workspace(object):
     """Grow-only device scratch buffers of one module, one per (device, stream): calls on the same stream reuse the
-    buffer (stream order makes that safe), calls on different streams -- two pairs in flight -- never share one."""
+    buffer (stream order makes that safe), calls on different streams -- two pairs in flight -- never share one.
+
+    The buffer also holds the module's re-laid-out weights (the arena of an entry point is deterministic), so it
+    remembers what they were made from: ``get(..., key)`` reports ``resident = True`` when the same buffer last
+    served the same ``key`` (call geometry + parameter signature), which lets the entry point skip its weight
+    re-layout launches (``weights_resident`` of include/pds_hip.h)."""
 
     MAX_STREAMS = 8   # buffers kept (least recently used first out): streams come and go in a long-lived process
 
     def __init__(self):
         self._buffers = {}
+        self._keys = {}
 
-    def get(self, nbytes, device):
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-        buf = self._buffers.pop(key, None)
+    def get(self, nbytes, device, key=None):
+        slot = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        buf = self._buffers.pop(slot, None)
         if buf is None or buf.numel() < nbytes:
             buf = None
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        self._buffers[key] = buf               # most recently used last
+            self._keys.pop(slot, None)
+        self._buffers[slot] = buf               # most recently used last
         while len(self._buffers) > self.MAX_STREAMS:
-            self._buffers.pop(next(iter(self._buffers)))
-        return buf
+            old = next(iter(self._buffers))
+            self._buffers.pop(old)
+            self._keys.pop(old, None)
+        if key is None:
+            self._keys.pop(slot, None)
+            return buf
+        resident = self._keys.get(slot) == key
+        self._keys[slot] = key
+        return buf, resident
 
 
 def not_differentiable(name):

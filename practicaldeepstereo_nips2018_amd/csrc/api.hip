@@ -140,18 +140,25 @@ struct Ctx {
 // Runs a module pipeline in two walks over the same (deterministic) arena: the first only collects the
 // weight-packing jobs of every MFMA layer, which are then executed by ONE launch; the second enqueues the
 // layers with their weights already packed.
+// weights_resident: the caller vouches that this workspace still holds the packed weights (and the weight-derived
+// tensors) a previous call of the same entry point with the same shapes and parameter values left there: the first walk
+// and the packing launch are skipped.
 template <class Pipeline>
-static int run_with_batched_packing(void* workspace, hipStream_t stream, Pipeline&& pipeline) {
+static int run_with_batched_packing(void* workspace, hipStream_t stream, Pipeline&& pipeline,
+                                    bool weights_resident = false) {
     PackJob table[64];
     PackSink sink;
     sink.jobs = table;
     sink.capacity = 64;
-    sink.phase = kPackCollect;
-    Ctx collect{(char*)workspace, 0, true, stream};
-    collect.sink = &sink;
-    pipeline(collect);
-    if (collect.err) return collect.err;
-    if (int rc = launch_multi_pack(table, sink.count, stream)) return rc;
+    if (!weights_resident) {
+        sink.phase = kPackCollect;
+        Ctx collect{(char*)workspace, 0, true, stream};
+        collect.sink = &sink;
+        pipeline(collect);
+        if (collect.err) return collect.err;
+        if (sink.count > 0)
+            if (int rc = launch_multi_pack(table, sink.count, stream)) return rc;
+    }
     sink.phase = kPackDone;
     Ctx run{(char*)workspace, 0, false, stream};
     run.sink = &sink;
@@ -911,7 +918,7 @@ size_t pds_matching_workspace_bytes(const PdsMatchingParams* params, int batch, 
 
 int pds_matching_fwd(const PdsMatchingParams* params, const float* left, const float* right, float* signatures,
                      int batch, int h, int w, int d_begin, int d_count, void* workspace, size_t workspace_bytes,
-                     pds_stream_t stream) {
+                     int weights_resident, pds_stream_t stream) {
     if (int rc = check_matching_params(params)) return rc;
     PDS_REQUIRE(left && right && signatures && workspace, "matching: null pointer");
     PDS_REQUIRE(batch > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0, "matching: bad shape");
@@ -919,7 +926,7 @@ int pds_matching_fwd(const PdsMatchingParams* params, const float* left, const f
     PDS_REQUIRE(workspace_bytes >= need, "matching: workspace too small (%zu < %zu)", workspace_bytes, need);
     return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
         matching_pipeline(c, *params, left, right, signatures, batch, h, w, d_begin, d_count);
-    });
+    }, weights_resident != 0);
 }
 
 size_t pds_matching_operation_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w) {
@@ -977,20 +984,20 @@ size_t pds_regularization_workspace_bytes(const PdsRegularizationParams* params,
 
 int pds_regularization_fwd(const PdsRegularizationParams* params, const float* signatures,
                            const float* left_shortcut, float* cost, int batch, int d, int h, int w, void* workspace,
-                           size_t workspace_bytes, pds_stream_t stream) {
+                           size_t workspace_bytes, int weights_resident, pds_stream_t stream) {
     if (int rc = check_regularization(params, batch, d, h, w)) return rc;
     PDS_REQUIRE(signatures && left_shortcut && cost && workspace, "regularization: null pointer");
     const size_t need = pds_regularization_workspace_bytes(params, batch, d, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "regularization: workspace too small (%zu < %zu)", workspace_bytes, need);
     return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
         regularization_pipeline(c, *params, signatures, left_shortcut, cost, batch, d, h, w);
-    });
+    }, weights_resident != 0);
 }
 
 int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, const float* signatures,
                                         const float* left_shortcut, float* disparities, int batch, int d, int h,
                                         int w, int half_support_window, int disparity_step, void* workspace,
-                                        size_t workspace_bytes, pds_stream_t stream) {
+                                        size_t workspace_bytes, int weights_resident, pds_stream_t stream) {
     if (int rc = check_regularization(params, batch, d, h, w)) return rc;
     PDS_REQUIRE(signatures && left_shortcut && disparities && workspace, "regularization_subpixel_map: null pointer");
     PDS_REQUIRE(disparity_step >= 1 && half_support_window >= 1 && half_support_window % disparity_step == 0,
@@ -1006,7 +1013,7 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
         DT half;
         if (int rc = run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& cc) {
                 half = regularization_trunk(cc, *params, signatures, left_shortcut, batch, d, h, w);
-            }))
+            }, weights_resident != 0))
             return rc;
         return launch_upsample_estimator(half.raw, half.scale, half.shift, params->upsample_full.weight,
                                          params->upsample_full.bias, disparities, batch, half.g.c, half.g.d, half.g.h,
@@ -1015,7 +1022,7 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
     float* cost = c.get<float>((size_t)batch * 2 * d * 4 * h * 4 * w);
     if (int rc = run_with_batched_packing((char*)workspace + c.off, (hipStream_t)stream, [&](Ctx& cc) {
             regularization_pipeline(cc, *params, signatures, left_shortcut, cost, batch, d, h, w);
-        }))
+        }, weights_resident != 0))
         return rc;
     return pds_subpixel_map_fwd(cost, disparities, batch, 2 * d, 4 * h, 4 * w, half_support_window, disparity_step,
                                 stream);
@@ -1348,7 +1355,7 @@ static int check_embedding_blocks(const PdsEmbeddingParams* P) {
 
 int pds_embedding_fwd(const PdsEmbeddingParams* params, const float* image, float* descriptor, float* shortcut,
                       int batch, int h, int w, int pad_top, int pad_left, void* workspace, size_t workspace_bytes,
-                      pds_stream_t stream) {
+                      int weights_resident, pds_stream_t stream) {
     if (int rc = check_embedding(params, batch, h, w, pad_top, pad_left)) return rc;
     PDS_REQUIRE(image && descriptor && shortcut && workspace, "embedding: null pointer");
     if (int rc = check_embedding_blocks(params)) return rc;
@@ -1356,7 +1363,7 @@ int pds_embedding_fwd(const PdsEmbeddingParams* params, const float* image, floa
     PDS_REQUIRE(workspace_bytes >= need, "embedding: workspace too small (%zu < %zu)", workspace_bytes, need);
     return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
         embedding_pipeline(c, *params, image, descriptor, shortcut, batch, h, w, pad_top, pad_left);
-    });
+    }, weights_resident != 0);
 }
 
 static int embedding_backward(bool plan, size_t* bytes, const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads,

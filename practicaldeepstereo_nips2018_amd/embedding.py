@@ -89,12 +89,16 @@ class _EmbeddingFunction(torch.autograd.Function):
                                device=image.device)
         nbytes = lib.pds_embedding_workspace_bytes(ctypes.byref(params), batch, h, w, pad_top, pad_left)
         training = any(ctx.needs_input_grad)
-        ws = (torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device) if training
-              else module._workspace.get(nbytes, image.device))
+        if training:
+            ws, resident = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device), False
+        else:
+            # the workspace keeps the re-laid-out weights: skipped when it last served these shapes and parameter values
+            ws, resident = module._workspace.get(
+                nbytes, image.device, key=((batch, h, w, pad_top, pad_left), _lib.parameter_signature(module)))
         with torch.cuda.device(image.device):
             _lib.check(lib.pds_embedding_fwd(
                 ctypes.byref(params), _lib.ptr(image), _lib.ptr(descriptor), _lib.ptr(shortcut), batch, h, w,
-                pad_top, pad_left, _lib.ptr(ws), ws.numel(), _lib.stream_handle(image.device)),
+                pad_top, pad_left, _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(image.device)),
                 'pds_embedding_fwd')
         del keep
         if training:

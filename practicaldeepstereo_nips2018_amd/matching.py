@@ -238,11 +238,13 @@ class _FusedMatchingFunction(torch.autograd.Function):
         out = torch.empty((batch, operation.number_of_signature_features, count, h, w),
                           dtype=torch.float32, device=left.device)
         nbytes = lib.pds_matching_workspace_bytes(ctypes.byref(params), batch, h, w, count)
-        ws = module._workspace.get(nbytes, left.device)
+        # the workspace keeps the re-laid-out weights: skipped when it last served these shapes and parameter values
+        ws, resident = module._workspace.get(nbytes, left.device,
+                                             key=((batch, h, w, count), _lib.parameter_signature(operation)))
         with torch.cuda.device(left.device):
             _lib.check(lib.pds_matching_fwd(
                 ctypes.byref(params), _lib.ptr(left), _lib.ptr(right), _lib.ptr(out),
-                batch, h, w, begin, count, _lib.ptr(ws), ws.numel(),
+                batch, h, w, begin, count, _lib.ptr(ws), ws.numel(), int(resident),
                 _lib.stream_handle(left.device)), 'pds_matching_fwd')
         del keep
         return out

@@ -242,22 +242,24 @@ class _RegularizationFunction(torch.autograd.Function):
             raise ValueError(lib.pds_last_error().decode())
         training = any(ctx.needs_input_grad) and estimator_window is None
         if training:
-            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ms.device)
+            ws, resident = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ms.device), False
         else:
-            ws = module._workspace.get(nbytes, ms.device)
+            # the workspace keeps the re-laid-out weights: skipped when it last served these shapes and parameter values
+            ws, resident = module._workspace.get(
+                nbytes, ms.device, key=((batch, d, h, w, estimator_window is None), _lib.parameter_signature(module)))
         with torch.cuda.device(ms.device):
             if estimator_window is None:
                 out = torch.empty((batch, 2 * d, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
                 _lib.check(lib.pds_regularization_fwd(
                     ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
-                    batch, d, h, w, _lib.ptr(ws), ws.numel(), _lib.stream_handle(ms.device)),
+                    batch, d, h, w, _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(ms.device)),
                     'pds_regularization_fwd')
             else:
                 out = torch.empty((batch, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
                 _lib.check(lib.pds_regularization_subpixel_map_fwd(
                     ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
                     batch, d, h, w, estimator_window[0], estimator_window[1],
-                    _lib.ptr(ws), ws.numel(), _lib.stream_handle(ms.device)),
+                    _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(ms.device)),
                     'pds_regularization_subpixel_map_fwd')
         if training:
             ctx.module = module

@@ -448,3 +448,33 @@ def test_stream_pipelines_are_bit_identical(dev):
         hot_path.drain()
     for want, got, got2 in zip(sequential, dealt, overlapped):
         assert torch.equal(got, want) and torch.equal(got2, want)
+
+
+# ----------------------------------------------------------------- weights kept in the workspace between calls
+def test_resident_weights_follow_parameter_updates(dev):
+    """The workspaces keep the re-laid-out weights and skip the packing launches while the parameter values are
+    unchanged (weights_resident of include/pds_hip.h); an in-place update (optimizer step, load_state_dict) must be
+    noticed through the parameters' version counters."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(63).eval().to(dev)
+    g = torch.Generator().manual_seed(5)
+    left = torch.randn(1, 64, 32, 64, generator=g).to(dev)
+    right = torch.randn(1, 64, 32, 64, generator=g).to(dev)
+    shortcut = torch.randn(1, 8, 32, 64, generator=g).to(dev)
+
+    def run(n):
+        ms = n._matching(left, right)
+        return ms, n._regularization.forward_with_estimator(ms, shortcut, n._estimator)
+
+    with torch.no_grad():
+        first = run(net)
+        again = run(net)            # second call: packing skipped
+        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+        for p in net.parameters():  # in-place update bumps p._version
+            p.mul_(1.01)
+        updated = run(net)
+        fresh = pds.PdsNetwork.default(63).eval().to(dev)
+        fresh.load_state_dict(net.state_dict())
+        expected = run(fresh)       # a module that has never packed anything
+    assert not torch.equal(updated[0], first[0])
+    assert torch.equal(updated[0], expected[0]) and torch.equal(updated[1], expected[1])
