@@ -72,6 +72,8 @@ def parse():
                     help='N = 1: one pair strictly after the other on one stream (latency mode) instead of dealing whole '
                          'pairs round-robin to --streams HIP streams')
     ap.add_argument('--kernel-reps', type=int, default=10)
+    ap.add_argument('--windows', type=int, default=5,
+                    help='timed windows of --steps steps each; the FIRST is "value", the others give the median / spread')
     ap.add_argument('--graph', action='store_true',
                     help='replay the hot path as one captured HIP graph (N = 1); measured equal to eager launches '
                          'because the GPU is saturated, so eager is the default')
@@ -81,19 +83,27 @@ def parse():
     return ap.parse_args()
 
 
+PAIRS = 4   # distinct stereo pairs the timed steps rotate through
+
+
 def make_inputs(device):
-    """Seed-0 default network, seed-1 images (SURVEY.md 8c recipe).  The descriptor network (the producer of the
-    hot path's inputs, itself on the HIP library) runs once, untimed; the CPU baseline later receives host copies
-    of the very same descriptors, so both sides see bit-identical inputs."""
+    """Seed-0 default network; PAIRS image pairs, seeds 1, 2, ... (pair 0 is the SURVEY.md 8c recipe).  The descriptor
+    network (the producer of the hot path's inputs, itself on the HIP library) runs once per pair, untimed; the CPU
+    baseline later receives host copies of the very same descriptors, so both sides see bit-identical inputs.
+    Returns the network, [(left descriptor, right descriptor, left shortcut)] and [(left image, right image)]."""
     torch.manual_seed(0)
     net = pds.PdsNetwork.default(MAX_DISPARITY).eval().to(device)
-    g = torch.Generator().manual_seed(1)
-    left = (torch.rand(1, 3, HEIGHT, WIDTH, generator=g) * 255).to(device)
-    right = (torch.rand(1, 3, HEIGHT, WIDTH, generator=g) * 255).to(device)
-    with torch.no_grad():
-        ld, shortcut = net._embedding(net._size_adapter.pad(left))
-        rd = net._embedding(net._size_adapter.pad(right))[0]
-    return net, ld, rd, shortcut, (left, right)
+    descriptors, images = [], []
+    for i in range(PAIRS):
+        g = torch.Generator().manual_seed(1 + i)
+        left = (torch.rand(1, 3, HEIGHT, WIDTH, generator=g) * 255).to(device)
+        right = (torch.rand(1, 3, HEIGHT, WIDTH, generator=g) * 255).to(device)
+        with torch.no_grad():
+            ld, shortcut = net._embedding(net._size_adapter.pad(left))
+            rd = net._embedding(net._size_adapter.pad(right))[0]
+        descriptors.append((ld, rd, shortcut))
+        images.append((left, right))
+    return net, descriptors, images
 
 
 def time_dominant_kernel(net, device, reps):
@@ -129,7 +139,7 @@ def time_dominant_kernel(net, device, reps):
     return total / reps
 
 
-def cpu_baseline(net, ld, rd, shortcut, gpu_disparity):
+def cpu_baseline(net, ld, rd, shortcut, gpu_disparity, gpu_signatures=None, gpu_cost=None):
     from oracle import pds_oracle as oracle
     # Threads: the cores this process may actually run on, capped at 32 -- oneDNN's small 3-D
     # convolutions thrash with hundreds of threads (256 threads measured 282 s per pair on the
@@ -147,7 +157,7 @@ def cpu_baseline(net, ld, rd, shortcut, gpu_disparity):
     with torch.no_grad():
         for i in range(8):  # 1 warm-up + best of the rest: ~10-30 s of host time (at least 3 passes, stop after 12 s)
             t0 = time.perf_counter()
-            disparity = oracle.hot_path(params, ld, rd, shortcut, MAX_DISPARITY)
+            signatures, cost, disparity = oracle.hot_path(params, ld, rd, shortcut, MAX_DISPARITY, return_stages=True)
             dt = time.perf_counter() - t0
             passes += 1
             if i > 0 or dt > 15.0:
@@ -157,7 +167,21 @@ def cpu_baseline(net, ld, rd, shortcut, gpu_disparity):
                 break
     delta = (gpu_disparity.double().cpu() - disparity.double()).abs()
     parity = {'disparity_mae': float(delta.mean()), 'disparity_max': float(delta.max()),
-              'flip_fraction': float((delta > 0.5).double().mean()), 'tolerance_mae': 1e-3}
+              'flip_fraction': float((delta > 0.5).double().mean()), 'tolerance_mae': 1e-3,
+              'disparity_mae_without_flips': float(delta[delta <= 0.5].mean())}
+    # stage-wise: an arg-max flip moves one pixel by tens of px, so the disparity MAE alone can hide or
+    # exaggerate a regression; the signatures and the cost volume cannot
+    if gpu_signatures is not None:
+        d = (gpu_signatures.cpu() - signatures).abs()
+        parity['signatures_max'] = float(d.max())
+        parity['signatures_mean'] = float(d.mean())
+        parity['signatures_tolerance_max'] = 2e-5
+    if gpu_cost is not None:
+        d = (gpu_cost.cpu() - cost).abs()
+        parity['cost_max'] = float(d.max())
+        parity['cost_mean'] = float(d.mean())
+        parity['cost_tolerance_max'] = 1e-4
+        parity['cost_tolerance_mean'] = 1e-5
     cpu_name = ''
     try:
         with open('/proc/cpuinfo') as f:
@@ -171,8 +195,28 @@ def cpu_baseline(net, ld, rd, shortcut, gpu_disparity):
     return base, parity
 
 
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def relaunch_under_torchrun(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script ourselves (one per GPU, RCCL),
+    exactly as the documented ``python -m torch.distributed.run`` command line would."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch_under_torchrun(args)   # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -180,6 +224,9 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
     _lib.load()  # fail loudly when the HIP extension is missing
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    if world > 1 and not args.share_device and torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: %d ranks need %d GPUs, this node shows %d (functional check on one GPU: '
+                         '--share-device --backend gloo)' % (world, world, torch.cuda.device_count()))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -190,7 +237,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    net, ld_g, rd_g, sc_g, images = make_inputs(device)
+    net, descriptors, images = make_inputs(device)
+    ld_g, rd_g, sc_g = descriptors[0]
     regularization, estimator = net._regularization, net._estimator
 
     def tail(signatures, shortcut):
@@ -210,10 +258,15 @@ def main():
         pipeline = PairStreams(lambda left, right, shortcut: tail(net._matching(left, right), shortcut),
                                streams=args.streams)
 
+    counter = [0]
+
     def step():
+        # the timed steps rotate through PAIRS distinct stereo pairs
+        ld, rd, sc = descriptors[counter[0] % PAIRS]
+        counter[0] += 1
         if pipeline is not None:
-            return pipeline.submit(ld_g, rd_g, sc_g)
-        return tail(net._matching(ld_g, rd_g), sc_g)
+            return pipeline.submit(ld, rd, sc)
+        return tail(net._matching(ld, rd), sc)
 
     def finish():
         if pipeline is not None:
@@ -237,9 +290,8 @@ def main():
                 with torch.cuda.graph(graph, stream=side):
                     graph_out = step()
             torch.cuda.current_stream(device).wait_stream(side)
-        eager_step = step
-
-        def step():  # noqa: F811
+        def step():  # noqa: F811   (the captured step replays pair 0)
+            counter[0] += 1
             graph.replay()
             return graph_out
 
@@ -252,41 +304,56 @@ def main():
         for _ in range(args.warmup):
             disparity = step()
         finish()
-        barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        mine = []
-        for _ in range(args.steps):
-            disparity = step()
-            if disparity is not None:
-                mine.append(disparity)
-        finish()
-        torch.cuda.synchronize(device)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        counter[0] = 0
+
+        def timed_window():
+            barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            results = []
+            for _ in range(args.steps):
+                first = counter[0] % PAIRS
+                out = step()
+                if out is not None:
+                    results.append((first if not use_graph else 0, out))
+            finish()
+            torch.cuda.synchronize(device)
+            barrier()
+            return time.perf_counter() - t0, results
+        elapsed, mine = timed_window()           # THE timed region: exactly --steps steps
+        disparity = dict(mine).get(0)
+        # further windows of the same length, informational (median / spread of the throughput)
+        windows = [elapsed] + [timed_window()[0] for _ in range(args.windows - 1)]
+
+    def reference_results():
+        """unsharded, sequential hot path of every pair (the bit-exactness reference of the schedules)"""
+        with torch.no_grad():
+            return [tail(net._matching(ld, rd), sc) for ld, rd, sc in descriptors]
     replica_elapsed = latency_elapsed = sharded_ok = None
     if world == 1 and pipeline is not None:
         # latency of one pair (no overlap across pairs), and a bit-exactness check of the pipelined results
         with torch.no_grad():
-            for _ in range(2):
-                sequential_result = tail(net._matching(ld_g, rd_g), sc_g)
+            for i in range(2):
+                tail(net._matching(*descriptors[i % PAIRS][:2]), descriptors[i % PAIRS][2])
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            for _ in range(args.steps):
-                sequential_result = tail(net._matching(ld_g, rd_g), sc_g)
+            for i in range(args.steps):
+                ld, rd, sc = descriptors[i % PAIRS]
+                tail(net._matching(ld, rd), sc)
             torch.cuda.synchronize(device)
             latency_elapsed = time.perf_counter() - t0
-        sharded_ok = all(torch.equal(m, sequential_result) for m in mine) and len(mine) == args.steps
+        expected = reference_results()
+        torch.cuda.synchronize(device)
+        sharded_ok = all(torch.equal(m, expected[i]) for i, m in mine) and len(mine) == args.steps
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # untimed check: every disparity map this rank produced in the timed region equals the unsharded hot path
         # on the same inputs bit for bit (same kernels, same planes)
-        with torch.no_grad():
-            unsharded_result = tail(net._matching(ld_g, rd_g), sc_g)
+        expected = reference_results()
         torch.cuda.synchronize(device)
-        good = all(torch.equal(m, unsharded_result) for m in mine)
+        good = all(torch.equal(m, expected[i]) for i, m in mine)
         flag = torch.tensor([1.0 if good else 0.0, float(len(mine))], device=device, dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
         sharded_ok = bool(flag[0].item() == world) and int(flag[1].item()) == args.steps
@@ -348,9 +415,10 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: 960x540 pair padded to 576x960, D=192 (48 matching planes, 96 cost '
                                    'planes), batch 1, eval mode, random-init weights seed 0',
-                       'parallelism': ('disparity-axis shard x%d + one all-gather (RCCL) per pair; Regularization + '
+                       'parallelism': ('disparity-axis shard x%d + one all-gather (%s) per pair; Regularization + '
                                        'estimator of pair i on rank i %% %d; pairs dealt to %d streams per rank' %
-                                       (world, world, args.sharded_streams))
+                                       (world, 'RCCL' if args.backend == 'nccl' else args.backend, world,
+                                        args.sharded_streams))
                        if world > 1 else 'single GPU',
                        'launch': 'hip graph replay' if use_graph else
                                  ('eager, whole pairs round-robin over %d HIP streams (ms_per_frame is the un-overlapped '
@@ -378,14 +446,22 @@ def main():
             # informational: the whole PdsNetwork.forward (network.py:45-52: pad, descriptor network on both images,
             # hot path, crop), everything on the library; the headline value stays the hot path of the metric
             with torch.no_grad():
-                for _ in range(3):
-                    net(*images)
+                for i in range(3):
+                    net(*images[i % PAIRS])
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    net(*images)
+                for i in range(args.steps):
+                    net(*images[i % PAIRS])
                 torch.cuda.synchronize(device)
             line['full_forward_ms'] = (time.perf_counter() - t0) / args.steps * 1e3
+            # the reference's own time-per-image protocol (trainer.py:141-148; README: 0.62 s per image on the
+            # authors' GPU): host images in, one example at a time, synchronize - time - synchronize around the network
+            from practicaldeepstereo_nips2018_amd.timing import time_per_image
+            host_examples = [{'left': images[i % PAIRS][0].cpu(), 'right': images[i % PAIRS][1].cpu(),
+                              'disparity': (torch.rand(1, HEIGHT, WIDTH) * 190.0)} for i in range(2 + 8)]
+            line['time_per_image'] = time_per_image(net, host_examples, device, warmup=2)
+            line['time_per_image'].pop('mean_absolute_error', None)   # random ground truth: only the protocol counts
+            line['time_per_image'].pop('three_pixels_error', None)
         with torch.no_grad():
             kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)
         achieved = CONV64_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
@@ -405,8 +481,18 @@ def main():
             line['roofline']['algorithm'] = 'direct implicit GEMM (PDS_WINOGRAD=0)'
             line['roofline']['executed_gflop_per_launch'] = CONV64_GFLOP
             line['roofline']['executed_tflops'] = achieved
+        ordered = sorted(args.steps / w for w in windows)
+        line['windows'] = {'count': len(windows), 'median': ordered[len(ordered) // 2], 'min': ordered[0],
+                           'max': ordered[-1], 'unit': 'pairs/s',
+                           'note': 'windows of --steps steps each over %d distinct pairs; "value" is the first' % PAIRS}
         if world == 1 and not args.no_cpu_baseline:
-            base, parity = cpu_baseline(net, ld_g.cpu(), rd_g.cpu(), sc_g.cpu(), disparity)
+            with torch.no_grad():
+                signatures_g = net._matching(ld_g, rd_g)
+                cost_g = regularization(signatures_g, sc_g)
+                if disparity is None:
+                    disparity = tail(signatures_g, sc_g)
+            base, parity = cpu_baseline(net, ld_g.cpu(), rd_g.cpu(), sc_g.cpu(), disparity, signatures_g, cost_g)
+            del cost_g
             line['cpu_baseline'] = base
             line['parity'] = parity
         print(json.dumps(line))

@@ -287,5 +287,20 @@ def hot_path(p, left_descriptor, right_descriptor, shortcut_from_left, maximum_d
     return disparity
 
 
+def network_training_output(p, left_image, right_image, maximum_disparity, embedding_prefix='_embedding',
+                            matching_prefix='_matching', regularization_prefix='_regularization'):
+    """PdsNetwork.forward in TRAINING mode (network.py:38-52): pad both images (size_adapter.py:29-43), descriptor
+    network on each, Matching, Regularization, then -- the estimator being skipped (network.py:50-52) -- the matching
+    cost cropped back to the image (size_adapter.py:45-52).  -> [batch, (max + 1) // 2, H, W]."""
+    left_padded, rows, columns = pad_to_multiple(left_image)
+    right_padded = pad_to_multiple(right_image)[0]
+    left_descriptor, shortcut = embedding(p, embedding_prefix, left_padded)
+    right_descriptor = embedding(p, embedding_prefix, right_padded)[0]
+    n = (maximum_disparity + 1) // 4 - 1
+    ms = matching_with_operation(p, matching_prefix, left_descriptor, right_descriptor, n)
+    cost = regularization(p, regularization_prefix, ms, shortcut)
+    return cost[..., rows:, columns:]
+
+
 def cast_params(p, dtype):
     return {k: v.to(dtype) for k, v in p.items()}

@@ -353,6 +353,66 @@ def g7_config2_statistics():
     REPORT['g7_config2'] = rep
 
 
+def g11_training_step():
+    """SURVEY.md 8c fixture "G9" (the file name g9 was already taken by the descriptor network): ONE training step of
+    the reference -- train-mode PdsNetwork.default(63) on the 128x256 pair of config 1, SubpixelCrossEntropy against a
+    seeded ground truth with an unknown (inf) band, backward (pds_trainer.py:35-46, loss.py:30-78).  Stored: the loss,
+    the norm of the gradient of every parameter tensor, and a sub-sample of dL/dcost."""
+    from practical_deep_stereo import loss as ref_loss
+    torch.manual_seed(0)
+    net = ref_network.PdsNetwork.default(63).train()
+    left, right = images(1, 128, 256)
+    g = torch.Generator().manual_seed(31)
+    gt = torch.rand(1, 128, 256, generator=g) * 62.0
+    gt[:, :, :24] = float('inf')
+    cost = net(left, right)
+    cost.retain_grad()
+    value = ref_loss.SubpixelCrossEntropy()(cost, gt)
+    value.backward()
+    # the oracle's training-mode network + loss reproduce the reference (value, cost volume, every gradient)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    cost_o = oracle.network_training_output(p, left, right, 63)
+    cost_o.retain_grad()
+    value_o = oracle.subpixel_cross_entropy(cost_o, gt)
+    value_o.backward()
+    names = [n for n, _ in net.named_parameters()]
+    grads = {n: q.grad for n, q in net.named_parameters()}
+    # the same step of the reference in fp64: the arbiter.  Weight gradients sum up to millions of sign-cancelling
+    # terms, so two fp32 evaluations that only differ in summation order (the reference loops over the disparities,
+    # the oracle batches them) are a few percent of the largest entry apart in the worst tensors; what a third
+    # implementation can be held to is its distance from fp64 relative to the reference's own.
+    import copy
+    net64 = copy.deepcopy(net).double()
+    net64.zero_grad()
+    cost64 = net64(left.double(), right.double())
+    ref_loss.SubpixelCrossEntropy()(cost64, gt.double()).backward()
+    grads64 = {n: q.grad for n, q in net64.named_parameters()}
+
+    def rel(a, b):
+        return maxdiff(a, b) / (float(b.abs().max()) + 1e-30)
+    oracle_rel = np.array([rel(p[n].grad, grads64[n]) for n in names])
+    reference_rel = np.array([rel(grads[n], grads64[n]) for n in names])
+    rep = {'loss': value.item(), 'loss_oracle_diff': abs(value.item() - value_o.item()),
+           'cost_oracle_max': maxdiff(cost, cost_o), 'dcost_oracle_max': maxdiff(cost.grad, cost_o.grad),
+           'param_grad_reference_fp32_vs_fp64_rel_max': float(reference_rel.max()),
+           'param_grad_oracle_fp32_vs_fp64_rel_max': float(oracle_rel.max())}
+    assert rep['loss_oracle_diff'] <= 1e-6 and rep['cost_oracle_max'] <= 1e-6 and rep['dcost_oracle_max'] <= 1e-9, rep
+    # the oracle is no further from fp64 than the reference is (both are fp32 evaluations of the same formulas);
+    # tensors whose true gradient is zero (the bias in front of the soft-max: 1e-17 in fp64) carry only rounding noise
+    live = np.array([grads64[n].norm().item() > 1e-9 for n in names])
+    rep['param_grad_reference_fp32_vs_fp64_rel_max'] = float(reference_rel[live].max())
+    rep['param_grad_oracle_fp32_vs_fp64_rel_max'] = float(oracle_rel[live].max())
+    assert float(oracle_rel[live].max()) <= max(3.0 * float(reference_rel[live].max()), 1e-4), rep
+    save('g11_training_step', loss=value.detach(), ground_truth=gt,
+         grad_norms=np.array([grads[n].double().norm().item() for n in names]),
+         grad_norms_fp64=np.array([grads64[n].norm().item() for n in names]),
+         grad_abs_max=np.array([grads[n].abs().max().item() for n in names]),
+         grad_reference_vs_fp64_rel=reference_rel,
+         parameter_names=np.array(names), dcost_sub=cost.grad[:, ::4, ::8, ::8].contiguous(),
+         cost_sub=cost.detach()[:, ::4, ::8, ::8].contiguous(), weight_checksum=checksum(net.state_dict()))
+    REPORT['g11_training_step'] = rep
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     if '--only' in sys.argv:  # regenerate one fixture, keep the rest of the report
@@ -373,6 +433,7 @@ if __name__ == '__main__':
     g8_loss()
     g9_embedding()
     g10_errors()
+    g11_training_step()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
     REPORT['torch'] = torch.__version__

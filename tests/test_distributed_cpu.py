@@ -158,3 +158,76 @@ def test_pair_streams_runs_inline_on_cpu():
     outs = [streams.submit(torch.full((2,), float(i)), torch.ones(2)) for i in range(4)]
     streams.drain()
     assert len(calls) == 4 and all(torch.equal(o, torch.full((2,), float(i) + 1)) for i, o in enumerate(outs))
+
+
+class LearnedShardMatching(torch.nn.Module):
+    """Differentiable stand-in with a parameter: operation(x) = conv1x1(x) per plane (SURVEY.md 8e interface)."""
+
+    def __init__(self, maximum_disparity, channels):
+        super().__init__()
+        self._maximum_disparity = maximum_disparity
+        self._shard = None
+        torch.manual_seed(7)
+        self._operation = torch.nn.Conv2d(2 * channels, 3, 1)
+
+    def set_disparity_shard(self, shard):
+        self._shard = shard
+
+    def forward(self, left, right):
+        begin, count = self._shard if self._shard is not None else (0, self._maximum_disparity + 1)
+        planes = [self._operation(torch.cat([left, oracle.shift_right(right, d)], 1)) for d in range(begin, begin + count)]
+        return torch.stack(planes, dim=2)
+
+
+def gradient_worker(rank, world, port, results):
+    """Training through ShardedMatching: after backward every rank holds the gradients of the unsharded network --
+    for the wrapped module's parameters AND for what produced its inputs (the gather used to cut the
+    autograd graph)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(3)
+        left0 = torch.randn(2, 4, 5, 7, generator=g)
+        right0 = torch.randn(2, 4, 5, 7, generator=g)
+        weight = torch.randn(2, 3, 8, 5, 7, generator=g)       # the replicated "tail": loss = sum(weight * signatures)
+        torch.manual_seed(11)                                   # identical "descriptor network" on every rank
+        upstream = torch.nn.Conv2d(4, 4, 1)
+        torch.nn.init.normal_(upstream.weight)
+
+        def run(matching):
+            upstream.zero_grad()
+            matching.zero_grad()
+            left = upstream(left0)
+            right = upstream(right0)
+            loss = (matching(left, right) * weight).sum()
+            loss.backward()
+            return (loss.detach().clone(), upstream.weight.grad.clone(),
+                    [p.grad.clone() for p in matching.parameters()])
+        loss_ref, up_ref, params_ref = run(LearnedShardMatching(7, 4))
+        loss, up, params = run(pdist.ShardedMatching(LearnedShardMatching(7, 4)))
+        ok = torch.allclose(loss, loss_ref, rtol=1e-5)
+        ok = ok and torch.allclose(up, up_ref, rtol=1e-4, atol=1e-5)
+        ok = ok and all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(params, params_ref))
+        # the wrapper adds no level to the state-dict key path (reference checkpoints stay loadable)
+        inner = LearnedShardMatching(7, 4)
+        wrapped = pdist.ShardedMatching(inner)
+        ok = ok and sorted(wrapped.state_dict().keys()) == sorted(inner.state_dict().keys())
+        wrapped.load_state_dict({k: v + 1.0 for k, v in inner.state_dict().items()})
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_matching_is_differentiable():
+    world = 2
+    ctx = mp.get_context('spawn')
+    results = ctx.Manager().dict()
+    port = free_port()
+    procs = [ctx.Process(target=gradient_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(results.get(r) for r in range(world)), dict(results)

@@ -4,6 +4,9 @@ Reference behaviour: pds_trainer.py:40-46 calls loss.backward() through network.
 i.e. through Matching, MatchingOperation and Regularization (the estimator is inference-only, estimator.py:19).
 Tolerance: every gradient tensor within 2e-3 of the fp64 gradient, relative to that tensor's largest entry
 (fp32 accumulation over up to ~1e6 terms on both sides of an InstanceNorm)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -218,3 +221,84 @@ def test_standalone_blocks_backward(dev):
     assert relative_error(out, ref) <= 1e-4
     assert relative_error(xi.grad, gxi) <= REL_TOL and relative_error(sc.grad, gsc) <= REL_TOL
     check_param_grads(exp, '_e', gp)
+
+
+def test_config5_full_size_training_step(dev):
+    """BASELINE configs[4] on one GPU: the reference's training step (pds_trainer.py:35-46: train-mode network ->
+    SubpixelCrossEntropy -> backward; RMSprop lr 1e-2, train_on_flyingthings3d.py:68) at the full 960x540, D=192 size.
+    The loss must equal the oracle's (fp32 on the host), every parameter must receive a finite gradient, and two
+    optimizer steps on the same pair must lower the loss."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(191)
+    left, right = helpers.images(1, 540, 960)
+    g = torch.Generator().manual_seed(21)
+    gt = torch.rand(1, 540, 960, generator=g) * 190.0
+    gt[:, :, :40] = float('inf')          # unknown ground truth band (errors.py / loss.py mask it)
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev).train()
+    criterion = pds.SubpixelCrossEntropy()
+    optimizer = torch.optim.RMSprop(net.parameters(), lr=1e-2)
+    left_g, right_g, gt_g = left.to(dev), right.to(dev), gt.to(dev)
+
+    def step():
+        optimizer.zero_grad()
+        cost = net(left_g, right_g)
+        assert cost.shape == (1, 96, 540, 960)       # training mode returns the cropped cost volume (network.py:50-52)
+        loss = criterion(cost, gt_g)
+        loss.backward()
+        return loss, cost
+
+    loss0, cost0 = step()
+    with torch.no_grad():
+        ref_cost = oracle.network_training_output(params, left, right, 191)
+        ref_loss = oracle.subpixel_cross_entropy(ref_cost, gt)
+    print('config5 loss: gpu %.6f oracle %.6f' % (loss0.item(), ref_loss.item()))
+    assert abs(loss0.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
+    assert helpers.maxdiff(cost0.detach(), ref_cost) <= 1e-4
+    grads = [p.grad for p in net.parameters()]
+    assert all(gr is not None and bool(torch.isfinite(gr).all()) for gr in grads)
+    assert sum(float(gr.abs().sum()) for gr in grads) > 0.0
+    del cost0
+    optimizer.step()
+    loss1, _ = step()
+    optimizer.step()
+    loss2, _ = step()
+    print('config5 losses', loss0.item(), loss1.item(), loss2.item())
+    assert loss2.item() < loss0.item()
+
+
+def test_training_step_against_reference_fixture(dev):
+    """SURVEY.md 8c fixture G9 (tests/golden/g11_training_step.npz, written by make_golden.py from the REFERENCE):
+    one training step of train-mode PdsNetwork.default(63) on the 128x256 pair with SubpixelCrossEntropy -- loss,
+    dL/dcost, and the gradient norm of every parameter tensor.  Weight gradients sum sign-cancelling terms, so the gate
+    per tensor is the distance of its NORM to the reference's fp64 run: within 1e-2 (the reference's own fp32 run is up to
+    1.5e-2 of a tensor's largest entry away from its fp64 run element-wise, pinning_report.json), or three times the
+    reference's own fp32 distance where that is larger."""
+    g = helpers.golden('g11_training_step')
+    names = [str(n) for n in np.load(os.path.join(helpers.GOLDEN, 'g11_training_step.npz'))['parameter_names']]
+    net = helpers.seeded(lambda: pds.PdsNetwork.default(63))
+    assert abs(helpers.checksum(net.state_dict()) - g['weight_checksum'].item()) < 1e-9
+    net = net.to(dev).train()
+    left, right = helpers.images(1, 128, 256)
+    cost = net(left.to(dev), right.to(dev))
+    cost.retain_grad()
+    loss = pds.SubpixelCrossEntropy()(cost, g['ground_truth'].to(dev))
+    loss.backward()
+    assert abs(loss.item() - g['loss'].item()) <= 1e-5 * abs(g['loss'].item())
+    assert helpers.maxdiff(cost.detach()[:, ::4, ::8, ::8], g['cost_sub']) <= 1e-4
+    scale = float(g['dcost_sub'].abs().max())
+    assert helpers.maxdiff(cost.grad[:, ::4, ::8, ::8], g['dcost_sub']) <= 1e-3 * scale
+    assert [n for n, _ in net.named_parameters()] == names
+    norms32, norms64 = g['grad_norms'].double(), g['grad_norms_fp64'].double()
+    worst, failures = 0.0, []
+    for i, (name, p) in enumerate(net.named_parameters()):
+        if norms64[i] < 1e-9:      # true zero gradient (the bias in front of the soft-max): rounding noise only
+            assert float(p.grad.double().norm()) <= 1e-5, name
+            continue
+        mine = abs(float(p.grad.double().norm()) - float(norms64[i])) / float(norms64[i])
+        theirs = abs(float(norms32[i]) - float(norms64[i])) / float(norms64[i])
+        worst = max(worst, mine)
+        if mine > max(1e-2, 3.0 * theirs):
+            failures.append((name, mine, theirs))
+    assert not failures, failures
+    print('training step vs reference fixture: loss %.6f, worst gradient-norm error vs fp64 %.2e' % (loss.item(), worst))

@@ -338,6 +338,22 @@ def test_config2_full_size_vs_oracle_and_golden(dev):
     rep_f = helpers.disparity_report(fused, disp_o)
     print('config2 fused disparity vs oracle', rep_f)
     assert rep_f['flips'] <= 3e-5 and rep_f['mae_noflip'] <= 1e-4 and rep_f['mae'] <= 2e-3, rep_f
+    # BASELINE configs[2] at full size: the 48 planes as 2 / 4 / 8 shards of 24 / 12 / 6 planes (what the ranks of
+    # distributed.ShardedMatching compute, here one after the other on this GPU); the gathered signatures must equal
+    # the unsharded ones bit for bit, hence everything downstream too
+    matching = net._matching
+    with torch.no_grad():
+        for shards in (2, 4, 8):
+            per = 48 // shards
+            parts = []
+            for r in range(shards):
+                matching.set_disparity_shard((r * per, per))
+                parts.append(matching(ld.to(dev), rd.to(dev)))
+            matching.set_disparity_shard(None)
+            gathered = torch.cat(parts, dim=2)
+            assert torch.equal(gathered, ms), shards
+            del parts
+        assert torch.equal(net._regularization.forward_with_estimator(gathered, shortcut.to(dev), net._estimator), fused)
 
 
 def test_config2_fp64_arbiter(dev):
@@ -363,12 +379,18 @@ def test_config4_kitti_shape_batch(dev):
     oracle's host time; checks unpad offsets and batch handling."""
     net, ld, rd, shortcut = hot_path_inputs(255, 2, 375, 1242)
     assert ld.shape == (2, 64, 96, 320)
-    ms, cost, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
+    ms, cost, unfused = run_hot_path(net, dev, ld, rd, shortcut, fuse=False)
     p = {k: v.cpu() for k, v in net.state_dict().items()}
     ms_o, cost_o, disp_o = oracle.hot_path(p, ld, rd, shortcut, 255, return_stages=True)
+    # stage-wise first: flips cannot hide a regression here
     assert helpers.maxdiff(ms, ms_o) <= TOL_SIGNATURES
+    assert helpers.maxdiff(cost, cost_o) <= TOL_COST_MAX
+    assert helpers.meandiff(cost, cost_o) <= TOL_COST_MEAN
+    del cost
+    _, _, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     rep = helpers.disparity_report(disparity, disp_o)
     print('config4 disparity vs oracle', rep)
+    assert rep['flips'] <= 3e-5 and rep['mae_noflip'] <= 1e-4, rep
     assert rep['mae'] <= 2e-3, rep
     out = net._size_adapter.unpad(disparity)
     assert out.shape == (2, 375, 1242)
