@@ -18,6 +18,9 @@
 //   LDS         double-buffered [V of 4 channels: [ic][6 rows][4 positions][32 tiles] | U fragments of the chunk];
 //               the input transform (with the producer's deferred InstanceNorm and the literal zero padding)
 //               is applied while staging; the filter transform is part of the weight packing (pack.hip mode 3).
+//   pipeline    two chunks deep: chunk c + 2 is being loaded, chunk c + 1 is transformed and written to the idle
+//               LDS buffer in the shadow of the MFMAs of chunk c (one basic block per chunk, sched_group_barrier
+//               interleave); one barrier per chunk.
 //   epilogue    output transform, + bias, LeakyReLU(0.1), 8-byte stores, per-(plane, channel) sum / sum of
 //               squares partials in fp64 (one deterministic record per tile), as in conv2d_mfma.hip.
 // Rounding: transforms are additions and one exact halving; measured against the fp64 oracle the layer is as
@@ -152,7 +155,9 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
         const unsigned rowbase = (unsigned)c * (unsigned)cstride + (unsigned)(yc * A.W);
         offp[k] = rowbase + (unsigned)min(x, A.W - 2);
         offe[k] = rowbase + (unsigned)((t == 0 || t == NT - 1) ? min(max(xe, 0), A.W - 1) : min(x, A.W - 2));
-        goff[k] = (unsigned)c * gstride;
+        // (a wave's 64 consecutive items lie in one channel: the offset of its scale / shift is wave-uniform, so these
+        // become scalar loads)
+        goff[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * gstride));
         l_off[k] = c * CS + r * RSV + t;
     }
     const float* pa = A.a.p + ((size_t)n * A.Cin * A.D + d) * plane;
@@ -215,8 +220,14 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
 #pragma unroll
             for (int j = 0; j < NBT; ++j) acc[p][m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline, two chunks deep: while the MFMAs of chunk c run out of one LDS buffer, the registers fetched
+    // during chunk c - 1 (chunk c + 1) are transformed and written to the other buffer IN THEIR SHADOW (the body is one
+    // basic block; sched_group_barrier spreads the riders between the MFMAs), and the global loads of chunk c + 2 are
+    // issued.  Chunks past the end re-stage the last one into the idle buffer instead of branching.
+    const int last_chunk = nchunks - 1;
     PDS_WFETCH(0)
     PDS_WSTASH(lds)
+    PDS_WFETCH(min(1, last_chunk))
     __syncthreads();
 
     const int b_lane = (lane >> 4) * CS + wave * RSV + (lane & 15);
@@ -224,13 +235,10 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         float* buf = lds + (chunk & 1) * BUF;
         float* nxt = lds + ((chunk + 1) & 1) * BUF;
-        const bool more = chunk + 1 < nchunks;
-        if (more) PDS_WFETCH(chunk + 1)
         const float* xin = buf + b_lane;
         const float* win = buf + IN_CHUNK + half * MBW * 64 + lane;
-#ifdef PDS_WINO_SETPRIO
-        __builtin_amdgcn_s_setprio(PDS_WINO_SETPRIO);
-#endif
+        PDS_WSTASH(nxt)                               // chunk + 1, fetched one iteration ago
+        PDS_WFETCH(min(chunk + 2, last_chunk))        // lands during the next iteration
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -247,10 +255,14 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
                         PDS_X_MFMA(acc[p][m][j], af[m], bf[j]);
             }
         }
-#ifdef PDS_WINO_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (more) PDS_WSTASH(nxt)
+#pragma unroll
+        for (int i = 0; i < 12 * MBW * NBT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU (input transform of the next chunk)
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
         __syncthreads();
     }
 #undef PDS_WFETCH
