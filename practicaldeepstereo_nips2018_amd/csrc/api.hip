@@ -58,6 +58,13 @@ int launch_deconv3d_mfma(const DeconvLayer& L, hipStream_t s);
 bool deconv3d_mfma_supported(const DeconvLayer& L);
 int deconv3d_mfma_tiles(const Geom& in_g);
 size_t deconv3d_mfma_packed_floats(const Geom& in_g, int cout, int kd);
+int launch_conv3d_ks(const ConvLayer& L, hipStream_t s);          // conv3d_ks.hip (inner hourglass levels, K split over waves)
+bool conv3d_ks_supported(const ConvLayer& L);
+int conv3d_ks_tiles(const Geom& out_g);
+size_t conv3d_ks_packed_floats(int cin, int vchannels, int taps);
+int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s);
+bool deconv3d_ks_supported(const DeconvLayer& L);
+int deconv3d_ks_tiles(const Geom& in_g, int cout);
 int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s);    // deconv3d_cell.hip (dense cell form, k4 s2)
 bool deconv3d_cell_supported(const DeconvLayer& L);
 int deconv3d_cell_records(const Geom& in_g, int cout);
@@ -287,6 +294,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     int kind = 0;
     if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino2d_eligible(L) ? 5 : conv2d_wino_eligible(L) ? 4 : 2;
     else if (allow_mfma && conv3d_t8_supported(L)) kind = 6;   // persistent z-Toeplitz kernel, no weight packing
+    else if (allow_mfma && conv3d_ks_supported(L)) kind = 7;   // inner levels: K split over the waves
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
     if (kind == 2)
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
@@ -294,6 +302,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 5) L.packed = c.get<float>(conv2d_wino2d_packed_floats(in.c, cout));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
+    if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
     if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 5) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
@@ -303,7 +312,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
                          : kind == 4 ? launch_conv2d_wino(L, c.s)
                          : kind == 5 ? launch_conv2d_wino2d(L, c.s)
                                      : kind == 3 ? launch_conv3d_mfma(L, c.s)
-                                                 : kind == 6 ? launch_conv3d_t8(L, c.s) : launch_conv_direct(L, c.s);
+                                                 : kind == 6 ? launch_conv3d_t8(L, c.s)
+                                                             : kind == 7 ? launch_conv3d_ks(L, c.s) : launch_conv_direct(L, c.s);
     };
     const bool collecting = c.sink && c.sink->phase == kPackCollect && c.base != nullptr;
     if (collecting && kind != 0 && kind != 6) c.run(launch());  // registers the pack job(s) only
@@ -313,8 +323,9 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
                                     : kind == 4 ? conv2d_wino_tiles(o.g)
                                     : kind == 5 ? conv2d_wino2d_tiles(o.g)
                                     : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride)
-                                    : kind == 6 ? conv3d_t8_records(o.g) : conv_direct_tiles_for(o.g, stride);
-        const bool volume_records = kind == 3 || kind == 6;   // [(n, c)][record] instead of [(n, c, d)][tile]
+                                    : kind == 6 ? conv3d_t8_records(o.g)
+                                    : kind == 7 ? conv3d_ks_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
+        const bool volume_records = kind == 3 || kind == 6 || kind == 7;   // [(n, c)][record] instead of [(n, c, d)][tile]
         const size_t records = (size_t)o.g.n * o.g.c * (volume_records ? 1 : o.g.d) * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
@@ -365,15 +376,20 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
     L.packed = nullptr;
     L.sink = c.sink;
     const bool cell = deconv3d_cell_supported(L);   // persistent dense-cell kernel: no weight packing
-    const bool mfma = !cell && deconv3d_mfma_supported(L);
+    const bool ks = !cell && deconv3d_ks_supported(L);   // inner levels: cell form, K split over the waves
+    const bool mfma = !cell && !ks && deconv3d_mfma_supported(L);
     if (mfma) L.packed = c.get<float>(deconv3d_mfma_packed_floats(in, cout, kd));
+    if (ks) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, 8 * cout, 8));
     if (mfma && c.sink && c.sink->phase == kPackCollect && c.base != nullptr) c.run(launch_deconv3d_mfma(L, c.s));
+    if (ks && c.sink && c.sink->phase == kPackCollect && c.base != nullptr) c.run(launch_deconv3d_ks(L, c.s));
     auto launch = [&]() {
-        return cell ? launch_deconv3d_cell(L, c.s) : mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s);
+        return cell ? launch_deconv3d_cell(L, c.s)
+                    : ks ? launch_deconv3d_ks(L, c.s) : mfma ? launch_deconv3d_mfma(L, c.s) : launch_deconv_direct(L, c.s);
     };
-    // partial records per (n, c): cell kernel [workgroup]; MFMA kernel [tile][parity class]; direct kernel [d][tile]
+    // partial records per (n, c): cell kernel [workgroup]; K-split / MFMA kernels [tile][parity class]; direct [d][tile]
     const int per_group = cell ? deconv3d_cell_records(in, cout)
-                               : mfma ? deconv3d_mfma_tiles(in) * (kd == 4 ? 8 : 4) : deconv_direct_tiles(o.g) * o.g.d;
+                               : ks ? deconv3d_ks_tiles(in, cout) * 8
+                                    : mfma ? deconv3d_mfma_tiles(in) * (kd == 4 ? 8 : 4) : deconv_direct_tiles(o.g) * o.g.d;
     if (norm) {
         const size_t records = (size_t)o.g.n * o.g.c * per_group;
         L.partials = c.get<double>(records * 2);

@@ -53,7 +53,8 @@ struct PackJob {
     float* dst = nullptr;        // fragment-ordered weights
     unsigned* mask = nullptr;    // transposed convolutions: per-block tap masks
     int cout = 0, cin = 0, mblocks = 0, kc = 4, taps = 9;
-    int mode = 0;                // 0 conv, 1 transposed k4 s2, 2 transposed k(3,4,4) s(1,2,2), 3 conv 3x3 -> F(2,3) along x, 4 conv 3x3 -> F(2x2,3x3) per-lane order
+    int mode = 0;                // 0 conv, 1 transposed k4 s2, 2 transposed k(3,4,4) s(1,2,2), 3 conv 3x3 -> F(2,3) along x, 4 conv 3x3 -> F(2x2,3x3) per-lane order,
+                                 // 5 transposed k4 s2 in the dense cell form (8 taps)
     int total = 0;               // floats in dst
 };
 int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s);

@@ -1,0 +1,502 @@
+// 3-D convolutions and k4/s2 transposed convolutions of the hourglass's INNER levels -- 16 to 128 channels over
+// volumes of 405 to 207 360 voxels (reference practical_deep_stereo/regularization.py:22-26,48-52 at levels 1-3,
+// network_blocks.py:61-85,106-131) -- on the exact-fp32 MFMA units.
+//
+// These layers are small GEMMs with a long K (Cin x 27 up to 3456) and few output positions: the tile-per-workgroup
+// kernel (conv3d_mfma.hip) walks K in chunks behind a barrier each, one dependent accumulator per wave, a few dozen
+// workgroups in flight -- 30 to 70 us per layer for 0.2 to 1.7 GFLOP.  Here K is SPLIT OVER THE WAVES instead:
+//
+//   workgroup   KSPLIT = 4, 8 or 16 waves share one output tile (one row of 16 NB columns, MBW channel blocks of 16);
+//               wave k convolves input channels [k Cin/KSPLIT, (k+1) Cin/KSPLIT) only -- 4 or 8 of them -- so even the
+//               405-voxel level runs > 1700 waves.  The waves never synchronise while they
+//               accumulate: each stages ITS channels' halo tile into a private LDS region (deferred InstanceNorm of
+//               the producer(s), skip sum and zero padding applied on the way; out-of-volume reads come back as zero
+//               from the buffer range check), then streams its weights.
+//   weights     ALL A fragments of a wave (<= 2 x 27 x MBW) go from global memory (L2-resident, fragment order
+//               [ic/4][tap][block][64 lanes]: 256 contiguous bytes per load) straight into registers, requested before
+//               the staging starts so both latencies overlap; every fragment feeds NB MFMAs.  No LDS copy, no barrier.
+//               (A first version with 4 waves per workgroup and weights streamed tap group by tap group was no
+//               faster than conv3d_mfma.hip: < 2 waves per CU, each serially waiting ~1.3 us per round trip.)
+//   GEMM view   M = 16 output channels per block, N = 16 consecutive output x, K = 4 input channels per
+//               v_mfma_f32_16x16x4_f32; the LDS channel stride is == 16 (mod 32) (stride 1) or odd (stride 2) so the
+//               two k-halves of a 32-lane read group hit disjoint banks.
+//   reduction   the four partial accumulators meet in LDS (one barrier), are summed in a fixed order, and the waves
+//               share the epilogue: bias, LeakyReLU(0.1), store, per-channel statistics -> one record per workgroup.
+//   MODE 2      ConvTranspose3d(k4, s2, p1) in the dense "cell" form of deconv3d_cell.hip: cell c maps its 2x2x2 input
+//               corners to the 2x2x2 outputs 2c + 1 + p through 8 "taps"; virtual channel v = class * Cout + oc.
+#include <atomic>
+
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct KsArgs {
+    Src a, b;
+    const float* __restrict__ wpk;   // [Cin / 4][taps][mblocks][64]
+    const float* __restrict__ bias;
+    float* __restrict__ out;
+    double* __restrict__ partials;
+    int Cin, Di, Hi, Wi;             // input volume
+    int Cout, Do, Ho, Wo;            // REAL output channels and output volume
+    int lrelu;
+    int tiles_x, tiles_y, tiles;
+    int mblocks;                     // blocks of 16 (virtual) channels
+    int cs;                          // LDS floats per input channel (bank-padded)
+};
+
+// MODE 0: conv 3x3x3 stride 1; 1: conv 3x3x3 stride 2; 2: transposed conv k4 s2 p1 (cell form)
+template <int MODE, int TZ, int TY, int NB>
+struct KsGeom {
+    static constexpr int S = MODE == 1 ? 2 : 1;
+    static constexpr int TAPS = MODE == 2 ? 8 : 27;
+    static constexpr int GROUP = MODE == 2 ? 4 : 9;       // taps whose weights are fetched together
+    static constexpr int NGROUPS = TAPS / GROUP;
+    static constexpr int EXT = MODE == 2 ? 2 : 3;         // stencil extent per axis
+    static constexpr int ZT = (TZ - 1) * S + EXT, YT = (TY - 1) * S + EXT, XT = (16 * NB - 1) * S + EXT;
+    static constexpr int NPOS = ZT * YT * XT;
+    static constexpr int CS = S == 1 ? ((NPOS + 15) / 32 * 32 + 16) : (NPOS | 1);
+    static constexpr int R = TZ * TY;
+};
+
+__device__ __forceinline__ float ks_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+}
+
+}  // namespace
+
+// NKS: groups of four input channels per wave (Cin = 4 NKS KSPLIT)
+template <int MODE, int TZ, int TY, int NB, int MBW, int KSPLIT, int NKS>
+__global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) {
+    using G = KsGeom<MODE, TZ, TY, NB>;
+    constexpr int S = G::S, R = G::R, NACC = MBW * R * NB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, mb0 = blockIdx.y * MBW, nb = blockIdx.z;
+    const int tx = tile % A.tiles_x, ty = (tile / A.tiles_x) % A.tiles_y, tz = tile / (A.tiles_x * A.tiles_y);
+    // output (conv) / cell (deconv) origin of the tile and the input coordinate of halo position (0, 0, 0)
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16 * NB;
+    const int iz0 = MODE == 2 ? z0 - 1 : z0 * S - 1, iy0 = MODE == 2 ? y0 - 1 : y0 * S - 1,
+              ix0 = MODE == 2 ? x0 - 1 : x0 * S - 1;
+    constexpr int cq = 4 * NKS;           // input channels of this wave
+    const int c_first = wave * cq;
+    const size_t plane_i = (size_t)A.Hi * A.Wi, cstride = (size_t)A.Di * plane_i;
+    const bool two = A.b.p != nullptr;
+    const size_t cstride_b = (two && A.b.bcast_d) ? plane_i : cstride;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A.a.p + ((size_t)nb * A.Cin + c_first) * cstride), 0, (int)(cq * cstride * sizeof(float)),
+        0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(two ? A.b.p + ((size_t)nb * A.Cin + c_first) * cstride_b : A.a.p), 0,
+        (int)(cq * (two ? cstride_b : cstride) * sizeof(float)), 0x00020000);
+
+    // ---- every A fragment of this wave: requested now, consumed after the staging ------------------------------------
+    const size_t tap_stride = (size_t)A.mblocks * 64;                       // floats between consecutive taps
+    float af[NKS][G::TAPS][MBW];
+    {
+        const float* wl = A.wpk + ((size_t)(c_first >> 2) * G::TAPS) * tap_stride + (size_t)mb0 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < G::TAPS; ++t)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) af[ks][t][m] = wl[((size_t)ks * G::TAPS + t) * tap_stride + m * 64];
+    }
+
+    // ---- stage this wave's channels: private LDS region [cq][CS] ---------------------------------------------------
+    float* mine = lds + (size_t)wave * cq * A.cs;
+    {
+        const float* sa = A.a.scale ? A.a.scale + (size_t)nb * A.Cin + c_first : nullptr;
+        const float* ha = A.a.scale ? A.a.shift + (size_t)nb * A.Cin + c_first : nullptr;
+        const float* sb = (two && A.b.scale) ? A.b.scale + (size_t)nb * A.Cin + c_first : nullptr;
+        const float* hb = (two && A.b.scale) ? A.b.shift + (size_t)nb * A.Cin + c_first : nullptr;
+        // all loads of the wave are issued back to back (a few dozen per lane), then written: one round trip
+        constexpr int PER_LANE = (cq * G::NPOS + 63) / 64;
+        constexpr int total = cq * G::NPOS;
+        float va[PER_LANE], vb[PER_LANE];
+        auto locate = [&](int e, int& c, int& lo, bool& in, unsigned& off, unsigned& offb) {
+            c = e / G::NPOS;
+            const int p = e % G::NPOS;
+            const int xx = p % G::XT, yy = (p / G::XT) % G::YT, zz = p / (G::XT * G::YT);
+            lo = c * A.cs + p;
+            const int z = iz0 + zz, y = iy0 + yy, x = ix0 + xx;
+            in = (unsigned)z < (unsigned)A.Di && (unsigned)y < (unsigned)A.Hi && (unsigned)x < (unsigned)A.Wi;
+            off = in ? (unsigned)(((size_t)c * A.Di + z) * plane_i + (size_t)y * A.Wi + x) * 4u : ~0u;
+            offb = !in ? ~0u : (two && A.b.bcast_d ? (unsigned)((size_t)c * plane_i + (size_t)y * A.Wi + x) * 4u : off);
+        };
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) {
+            int c, lo;
+            bool in;
+            unsigned off, offb;
+            locate(min(lane + 64 * i, total - 1), c, lo, in, off, offb);   // (surplus lanes re-stage the last element)
+            va[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off, 0, 0));
+            if (two) vb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, offb, 0, 0));
+        }
+        float sca[cq], sha[cq], scb[cq], shb[cq];   // wave-uniform InstanceNorm coefficients of the wave's channels
+#pragma unroll
+        for (int c = 0; c < cq; ++c) {
+            sca[c] = sa ? sa[c] : 1.f;
+            sha[c] = sa ? ha[c] : 0.f;
+            scb[c] = sb ? sb[c] : 1.f;
+            shb[c] = sb ? hb[c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) {
+            int c, lo;
+            bool in;
+            unsigned off, offb;
+            locate(min(lane + 64 * i, total - 1), c, lo, in, off, offb);
+            // the channel of element i: cq is 4 or 8, picked with a short select chain on the wave-uniform tables
+            float s1 = sca[0], h1 = sha[0], s2 = scb[0], h2 = shb[0];
+#pragma unroll
+            for (int cc = 1; cc < cq; ++cc) {
+                s1 = c == cc ? sca[cc] : s1;
+                h1 = c == cc ? sha[cc] : h1;
+                s2 = c == cc ? scb[cc] : s2;
+                h2 = c == cc ? shb[cc] : h2;
+            }
+            float v = fmaf(s1, va[i], h1);
+            if (two) v += fmaf(s2, vb[i], h2);
+            mine[lo] = in ? v : 0.f;
+        }
+    }
+
+    // ---- K loop: this wave's NKS groups of four channels, all taps ------------------------------------------------------
+    f32x4 acc[MBW][R][NB];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[m][r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const float* bl = mine + q * A.cs + n16 * S;   // B fragment: channel k = lane >> 4, column n = lane & 15
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int tap = 0; tap < G::TAPS; ++tap) {
+                const int dz = MODE == 2 ? tap >> 2 : tap / 9, dy = MODE == 2 ? (tap >> 1) & 1 : (tap / 3) % 3,
+                          dx = MODE == 2 ? tap & 1 : tap % 3;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int rz = r / TY, ry = r % TY;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float b = bl[ks * 4 * A.cs + ((rz * S + dz) * G::YT + ry * S + dy) * G::XT + j * 16 * S + dx];
+#pragma unroll
+                        for (int m = 0; m < MBW; ++m)
+                            acc[m][r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][tap][m], b, acc[m][r][j], 0, 0, 0);
+                    }
+                }
+            }
+    }
+
+    // ---- the four partial sums meet in LDS; wave w finishes the accumulators with index == w (mod 4) -------------------
+    __syncthreads();                                   // every wave is done with its staging region
+    f32x4* red = reinterpret_cast<f32x4*>(lds);        // [KSPLIT waves][NACC][64 lanes]
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) red[((size_t)wave * NACC + (m * R + r) * NB + j) * 64 + lane] = acc[m][r][j];
+    __syncthreads();
+
+    const size_t plane_o = (size_t)A.Ho * A.Wo, cstride_o = (size_t)A.Do * plane_o;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        A.out + (size_t)nb * A.Cout * cstride_o, 0, (int)(A.Cout * cstride_o * sizeof(float)), 0x00020000);
+    float ssum[MBW][4], ssq[MBW][4];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[m][e] = ssq[m][e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = (m * R + r) * NB + j;
+                if (idx % KSPLIT != wave) continue;    // wave-uniform
+                f32x4 t = red[((size_t)0 * NACC + idx) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < KSPLIT; ++w) t += red[((size_t)w * NACC + idx) * 64 + lane];
+                const int rz = r / TY, ry = r % TY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = (mb0 + m) * 16 + 4 * q + e;      // (virtual) output channel
+                    int oc = v, oz = z0 + rz, oy = y0 + ry, ox = x0 + 16 * j + n16;
+                    bool ok = v < (MODE == 2 ? 8 * A.Cout : A.Cout);
+                    if (MODE == 2) {
+                        const int cls = v / A.Cout;
+                        oc = v - cls * A.Cout;
+                        oz = 2 * (oz - 1) + 1 + ((cls >> 2) & 1);
+                        oy = 2 * (oy - 1) + 1 + ((cls >> 1) & 1);
+                        ox = 2 * (ox - 1) + 1 + (cls & 1);
+                    }
+                    ok = ok && (unsigned)oz < (unsigned)A.Do && (unsigned)oy < (unsigned)A.Ho && (unsigned)ox < (unsigned)A.Wo;
+                    float val = t[e] + ((ok && A.bias) ? A.bias[oc] : 0.f);
+                    if (A.lrelu) val = fmaxf(val, val * kLeakySlope);
+                    const unsigned off = ok ? (unsigned)(((size_t)oc * A.Do + oz) * plane_o + (size_t)oy * A.Wo + ox) * 4u : ~0u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), ro, off, 0, 0);
+                    val = ok ? val : 0.f;
+                    ssum[m][e] += val;
+                    ssq[m][e] = fmaf(val, val, ssq[m][e]);
+                }
+            }
+
+    // ---- statistics: one record per (workgroup, channel [, parity class]) ------------------------------------------------
+    if (A.partials) {
+        __syncthreads();                               // the reduction scratch has been read
+        float* sred = lds;                             // [KSPLIT waves][MBW * 16][2]
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = ks_row16_sum(ssum[m][e]), sq = ks_row16_sum(ssq[m][e]);
+                if (n16 == 15) {
+                    sred[((wave * MBW + m) * 16 + 4 * q + e) * 2 + 0] = s;
+                    sred[((wave * MBW + m) * 16 + 4 * q + e) * 2 + 1] = sq;
+                }
+            }
+        __syncthreads();
+        if (tid < MBW * 16 * 2) {
+            const int c16 = tid >> 1, k = tid & 1;
+            const int v = mb0 * 16 + c16;
+            const int vmax = MODE == 2 ? 8 * A.Cout : A.Cout;
+            if (v < vmax) {
+                double sum = 0.0;
+#pragma unroll
+                for (int w = 0; w < KSPLIT; ++w) sum += (double)sred[((w * MBW * 16) + c16) * 2 + k];
+                if (MODE == 2) {
+                    const int cls = v / A.Cout, oc = v - cls * A.Cout;   // records of one real channel: [tile][class]
+                    A.partials[((((size_t)nb * A.Cout + oc) * A.tiles + tile) * 8 + cls) * 2 + k] = sum;
+                } else {
+                    A.partials[(((size_t)nb * A.Cout + v) * A.tiles + tile) * 2 + k] = sum;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+bool ks_enabled() {
+    static const bool on = []() {  // PDS_CONV3D_KS=0: conv3d_mfma.hip serves these layers (A/B)
+        const char* e = getenv("PDS_CONV3D_KS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+struct KsPlan {
+    int nb;       // 16-column blocks per tile (tiles are single rows)
+    int ksplit;   // waves per workgroup
+    int nks;      // groups of four input channels per wave
+};
+
+// tiles are single rows of 16 / 32 / 64 columns; the waves of a workgroup take 4 (Cin <= 32) or 8 input channels each
+KsPlan ks_plan(int cin, int columns) {
+    KsPlan p;
+    p.nb = columns <= 16 ? 1 : (columns <= 32 ? 2 : 4);
+    p.nks = cin >= 64 ? 2 : 1;
+    p.ksplit = cin / (4 * p.nks);
+    return p;
+}
+
+template <int MODE, int NB, int KSPLIT, int NKS, int MBW_ = 0>
+int launch_ks(KsArgs A, int batch, hipStream_t s) {
+    // two channel blocks per workgroup (every B operand feeds two MFMAs), except where 16 waves x 108 weight registers
+    // would not fit (the 128-channel convolutions take one) and for 16 output channels
+    constexpr int MBW = MBW_ ? MBW_ : ((KSPLIT == 16 && MODE != 2) ? 1 : 2);
+    using G = KsGeom<MODE, 1, 1, NB>;
+    A.cs = G::CS;
+    constexpr int NACC = MBW * NB;
+    const size_t staging = (size_t)A.Cin * G::CS * sizeof(float);
+    const size_t reduce = (size_t)KSPLIT * NACC * 64 * sizeof(f32x4);
+    size_t lds_bytes = staging > reduce ? staging : reduce;
+    if (lds_bytes < 4096) lds_bytes = 4096;
+    if (lds_bytes > 160 * 1024) return set_error(-1, "conv3d_ks: tile does not fit in LDS (%zu bytes)", lds_bytes);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done.load() >> (dev & 31)) & 1u)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        attr_done.fetch_or(1u << (dev & 31));
+    }
+    dim3 grid(A.tiles, A.mblocks / MBW, batch);
+    hipLaunchKernelGGL((conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS>), grid, dim3(64 * KSPLIT), lds_bytes, s, A);
+    return check_launch("conv3d_ks");
+}
+
+template <int MODE, int NB>
+int dispatch_split(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s) {
+    if (p.ksplit == 4 && p.nks == 1 && A.mblocks == 1 && MODE == 0) return launch_ks<0, NB, 4, 1, 1>(A, batch, s);
+    if (p.ksplit == 4 && p.nks == 1) return launch_ks<MODE, NB, 4, 1>(A, batch, s);
+    if (p.ksplit == 8 && p.nks == 1) return launch_ks<MODE, NB, 8, 1>(A, batch, s);
+    if (p.ksplit == 8 && p.nks == 2) return launch_ks<MODE, NB, 8, 2>(A, batch, s);
+    if (p.ksplit == 16 && p.nks == 2) return launch_ks<MODE, NB, 16, 2>(A, batch, s);
+    return set_error(-1, "conv3d_ks: no configuration for %d x %d channels per wave", p.ksplit, p.nks);
+}
+
+template <int MODE>
+int dispatch_ks(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s) {
+    if (p.nb == 1) return dispatch_split<MODE, 1>(p, A, batch, s);
+    if (p.nb == 2) return dispatch_split<MODE, 2>(p, A, batch, s);
+    return dispatch_split<MODE, 4>(p, A, batch, s);
+}
+
+size_t ks_lds_bytes(int mode, const KsPlan& p, int cin) {
+    const int sx = mode == 1 ? 2 : 1, ext = mode == 2 ? 2 : 3;
+    const int npos = ext * ext * ((16 * p.nb - 1) * sx + ext);
+    const int cs = sx == 1 ? ((npos + 15) / 32 * 32 + 16) : (npos | 1);
+    return (size_t)cin * cs * sizeof(float);
+}
+
+bool ks_shape_ok(int mode, int cin, int vchannels, int columns, size_t in_elems, size_t out_elems, int batch) {
+    if (cin != 16 && cin != 32 && cin != 64 && cin != 128) return false;
+    if (vchannels % 32 != 0 && !(vchannels == 16 && mode == 0)) return false;   // two channel blocks per workgroup
+    if (in_elems >= ((size_t)1 << 30) || out_elems >= ((size_t)1 << 30)) return false;   // 32-bit byte offsets
+    if (batch > 65535) return false;
+    return ks_lds_bytes(mode, ks_plan(cin, columns), cin) <= 160 * 1024;
+}
+
+}  // namespace
+
+bool conv3d_ks_supported(const ConvLayer& L) {
+    if (!ks_enabled()) return false;
+    if (L.kd != 3 || L.stat_per_plane) return false;
+    if ((L.a.scale && L.a.per_plane) || (L.b.scale && L.b.per_plane)) return false;
+    static const size_t volume_limit = []() {   // PDS_CONV3D_KS_LIMIT: largest output volume served (experiments)
+        const char* e = getenv("PDS_CONV3D_KS_LIMIT");
+        return e ? (size_t)atol(e) : (size_t)30000;
+    }();
+    // the large 16-channel levels keep the tile-per-workgroup kernel: plenty of tiles there, and K is short
+    if ((size_t)L.out_g.d * L.out_g.h * L.out_g.w > volume_limit) return false;
+    return ks_shape_ok(L.stride == 2 ? 1 : 0, L.in.c, L.out_g.c, L.out_g.w, (size_t)L.in.c * L.in.d * L.in.h * L.in.w,
+                       L.out_g.numel() / (L.out_g.n ? L.out_g.n : 1), L.in.n);
+}
+
+int conv3d_ks_tiles(const Geom& o) {
+    const int nb = o.w <= 16 ? 1 : (o.w <= 32 ? 2 : 4);
+    return ((o.w + 16 * nb - 1) / (16 * nb)) * o.h * o.d;
+}
+
+size_t conv3d_ks_packed_floats(int cin, int vchannels, int taps) { return (size_t)(cin / 4) * taps * vchannels * 4; }
+
+int launch_conv3d_ks(const ConvLayer& L, hipStream_t s) {
+    if (!L.packed) return set_error(-1, "conv3d_ks: packed weights missing");
+    const int mode = L.stride == 2 ? 1 : 0;
+    KsArgs A;
+    A.a = L.a;
+    A.b = L.b;
+    A.wpk = L.packed;
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.Cin = L.in.c;
+    A.Di = L.in.d;
+    A.Hi = L.in.h;
+    A.Wi = L.in.w;
+    A.Cout = L.out_g.c;
+    A.Do = L.out_g.d;
+    A.Ho = L.out_g.h;
+    A.Wo = L.out_g.w;
+    A.lrelu = L.lrelu;
+    A.mblocks = A.Cout / 16;
+    const KsPlan p = ks_plan(A.Cin, A.Wo);
+    A.tiles_x = (A.Wo + 16 * p.nb - 1) / (16 * p.nb);
+    A.tiles_y = A.Ho;
+    A.tiles = conv3d_ks_tiles(L.out_g);
+    {
+        const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+        if (phase != kPackDone) {
+            PackJob j;
+            j.src = L.weight;
+            j.dst = L.packed;
+            j.cout = A.Cout;
+            j.cin = A.Cin;
+            j.mblocks = A.mblocks;
+            j.kc = 4;
+            j.taps = 27;
+            j.mode = 0;
+            j.total = (int)conv3d_ks_packed_floats(A.Cin, A.Cout, 27);
+            if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
+            if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+        }
+    }
+    return mode == 1 ? dispatch_ks<1>(p, A, L.in.n, s) : dispatch_ks<0>(p, A, L.in.n, s);
+}
+
+bool deconv3d_ks_supported(const DeconvLayer& L) {
+    if (!ks_enabled()) return false;
+    if (L.kd != 4 || L.b.p != nullptr) return false;
+    if (L.a.scale && L.a.per_plane) return false;
+    if ((size_t)L.in.d * L.in.h * L.in.w > 30000) return false;
+    return ks_shape_ok(2, L.in.c, 8 * L.out_g.c, L.in.w + 1, (size_t)L.in.c * L.in.d * L.in.h * L.in.w,
+                       L.out_g.numel() / (L.out_g.n ? L.out_g.n : 1), L.in.n);
+}
+
+int deconv3d_ks_tiles(const Geom& in, int cout) {
+    const int cells = in.w + 1, nb = cells <= 16 ? 1 : (cells <= 32 ? 2 : 4);
+    return ((cells + 16 * nb - 1) / (16 * nb)) * (in.h + 1) * (in.d + 1);
+}
+
+int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s) {
+    if (!L.packed) return set_error(-1, "deconv3d_ks: packed weights missing");
+    KsArgs A;
+    A.a = L.a;
+    A.b = no_src();
+    A.wpk = L.packed;
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.Cin = L.in.c;
+    A.Di = L.in.d;
+    A.Hi = L.in.h;
+    A.Wi = L.in.w;
+    A.Cout = L.out_g.c;
+    A.Do = L.out_g.d;
+    A.Ho = L.out_g.h;
+    A.Wo = L.out_g.w;
+    A.lrelu = L.lrelu;
+    A.mblocks = 8 * A.Cout / 16;
+    const KsPlan p = ks_plan(A.Cin, A.Wi + 1);
+    A.tiles_x = (A.Wi + 1 + 16 * p.nb - 1) / (16 * p.nb);
+    A.tiles_y = A.Hi + 1;
+    A.tiles = deconv3d_ks_tiles(L.in, A.Cout);
+    {
+        const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+        if (phase != kPackDone) {
+            PackJob j;
+            j.src = L.weight;
+            j.dst = L.packed;
+            j.cout = A.Cout;
+            j.cin = A.Cin;
+            j.mblocks = A.mblocks;
+            j.kc = 4;
+            j.taps = 8;
+            j.mode = 5;
+            j.total = (int)conv3d_ks_packed_floats(A.Cin, 8 * A.Cout, 8);
+            if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
+            if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+        }
+    }
+    return dispatch_ks<2>(p, A, L.in.n, s);
+}
+
+}  // namespace pds

@@ -7,6 +7,7 @@
 //   deconv (taps 27 on the input grid): virtual channel v = class*Cout + oc, class = output parity;
 //           value = Wt[c][oc][kd][kh][kw] for the transposed-conv tap that parity uses at that input
 //           offset, else 0; plus one 27-bit tap mask per 16-channel block (see conv3d_mfma.hip).
+//   cell   (mode 5, taps 8): the dense per-cell form of the k4 s2 transposed convolution (conv3d_ks.hip).
 #include "common.hpp"
 
 namespace pds {
@@ -86,6 +87,16 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
                 const double g0 = g[0], g1 = g[1], g2 = g[2];
                 const int pos = tap & 3;
                 val = pos == 0 ? g[0] : pos == 3 ? g[2] : (float)(pos == 1 ? 0.5 * (g0 + g1 + g2) : 0.5 * (g0 - g1 + g2));
+            }
+        } else if (J.mode == 5) {
+            // dense "cell" form of the k4 s2 p1 transposed convolution (deconv3d_cell.hip, conv3d_ks.hip): 8 taps =
+            // input corners (zi, yi, xi); virtual channel v = class * Cout + oc, class = (pz, py, px);
+            // weight = Wt[c][oc][2 + pz - 2 zi][2 + py - 2 yi][2 + px - 2 xi]
+            if (v < 8 * J.cout && c < J.cin) {
+                const int cls = v / J.cout, oc = v % J.cout;
+                const int kz = 2 + ((cls >> 2) & 1) - 2 * ((tap >> 2) & 1), ky = 2 + ((cls >> 1) & 1) - 2 * ((tap >> 1) & 1),
+                          kx = 2 + (cls & 1) - 2 * (tap & 1);
+                val = J.src[(((size_t)c * J.cout + oc) * 4 + kz) * 16 + ky * 4 + kx];
             }
         } else if (v < ncls * J.cout && c < J.cin) {
             const int cls = v / J.cout, oc = v % J.cout;

@@ -19,7 +19,7 @@ SWITCHES = [
     {'PDS_CONV2D_KC8': '1'},        # 8-channel chunks in the single-block direct kernels
     {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
     {'PDS_CONV3D_XCD_MAP': '0'},
-    {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0'},   # generic MFMA kernels for the full-resolution hourglass layers
+    {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0', 'PDS_CONV3D_KS': '0'},   # generic MFMA kernels for all hourglass layers
 ]
 
 
