@@ -134,12 +134,16 @@ int pds_regularization_fwd(const PdsRegularizationParams* params,
                            pds_stream_t stream);
 
 /* Eval-mode fusion of Regularization's last layer with SubpixelMap (network.py:50-51):
- * the full-resolution cost volume is never written.  disparities [batch, 4*h, 4*w]. */
+ * the full-resolution cost volume is never written.  SizeAdapter.unpad (size_adapter.py:45-52)
+ * is folded into the store: disparities is the contiguous [batch, 4*h - crop_top,
+ * 4*w - crop_left] image without the rows / columns SizeAdapter.pad added on top / left
+ * (crop 0, 0: the padded size). */
 int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params,
                                         const float* signatures, const float* left_shortcut,
                                         float* disparities,
                                         int batch, int d, int h, int w,
                                         int half_support_window, int disparity_step,
+                                        int crop_top, int crop_left,
                                         void* workspace, size_t workspace_bytes, int weights_resident,
                                         pds_stream_t stream);
 

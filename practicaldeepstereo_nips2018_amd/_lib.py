@@ -128,7 +128,7 @@ SIGNATURES = {
     'pds_regularization_fwd': (_I, [ctypes.POINTER(RegularizationParams), _VP, _VP, _VP,
                                     _I, _I, _I, _I, _VP, _SZ, _I, _VP]),
     'pds_regularization_subpixel_map_fwd': (_I, [ctypes.POINTER(RegularizationParams), _VP, _VP, _VP,
-                                                 _I, _I, _I, _I, _I, _I, _VP, _SZ, _I, _VP]),
+                                                 _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _I, _VP]),
     'pds_conv_block_workspace_bytes': (_SZ, [_I] * 9),
     'pds_conv_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _VP,
                                 _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),

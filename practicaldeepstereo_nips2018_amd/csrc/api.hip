@@ -71,7 +71,7 @@ int deconv3d_cell_records(const Geom& in_g, int cout);
 bool upsample_estimator_supported(int cin, int lo, int hi);       // upsample_estimator.hip
 int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w,
                               const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
-                              int hi, int step, hipStream_t s);
+                              int hi, int step, int crop_top, int crop_left, hipStream_t s);
 
 // ---- backward tape ---------------------------------------------------------------------------------
 // Recorded while a pipeline is (re-)walked over the forward workspace; the arena is deterministic, so the
@@ -1012,12 +1012,15 @@ int pds_regularization_fwd(const PdsRegularizationParams* params, const float* s
 
 int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, const float* signatures,
                                         const float* left_shortcut, float* disparities, int batch, int d, int h,
-                                        int w, int half_support_window, int disparity_step, void* workspace,
-                                        size_t workspace_bytes, int weights_resident, pds_stream_t stream) {
+                                        int w, int half_support_window, int disparity_step, int crop_top,
+                                        int crop_left, void* workspace, size_t workspace_bytes, int weights_resident,
+                                        pds_stream_t stream) {
     if (int rc = check_regularization(params, batch, d, h, w)) return rc;
     PDS_REQUIRE(signatures && left_shortcut && disparities && workspace, "regularization_subpixel_map: null pointer");
     PDS_REQUIRE(disparity_step >= 1 && half_support_window >= 1 && half_support_window % disparity_step == 0,
                 "regularization_subpixel_map: bad window/step");
+    PDS_REQUIRE(crop_top >= 0 && crop_top < 4 * h && crop_left >= 0 && crop_left < 4 * w,
+                "regularization_subpixel_map: bad crop (%d, %d)", crop_top, crop_left);
     const size_t need = pds_regularization_workspace_bytes(params, batch, d, h, w);
     PDS_REQUIRE(workspace_bytes >= need, "regularization_subpixel_map: workspace too small (%zu < %zu)",
                 workspace_bytes, need);
@@ -1033,8 +1036,10 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
             return rc;
         return launch_upsample_estimator(half.raw, half.scale, half.shift, params->upsample_full.weight,
                                          params->upsample_full.bias, disparities, batch, half.g.c, half.g.d, half.g.h,
-                                         half.g.w, lo, hi, disparity_step, (hipStream_t)stream);
+                                         half.g.w, lo, hi, disparity_step, crop_top, crop_left, (hipStream_t)stream);
     }
+    PDS_REQUIRE(crop_top == 0 && crop_left == 0,
+                "regularization_subpixel_map: the crop is only folded into the fused kernel (4 features, window <= 4 taps)");
     float* cost = c.get<float>((size_t)batch * 2 * d * 4 * h * 4 * w);
     if (int rc = run_with_batched_packing((char*)workspace + c.off, (hipStream_t)stream, [&](Ctx& cc) {
             regularization_pipeline(cc, *params, signatures, left_shortcut, cost, batch, d, h, w);

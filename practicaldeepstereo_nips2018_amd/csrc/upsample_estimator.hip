@@ -37,6 +37,7 @@ struct FusedArgs {
     int D, Hi, Wi;
     int lo, hi;                       // tap range of the estimator
     float step;
+    int crop_top, crop_left;          // SizeAdapter.unpad folded into the store: disp is [B, 2Hi - top, 2Wi - left]
 };
 
 }  // namespace
@@ -228,13 +229,20 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
         res[o] = num / den;
     }
     if (i < A.Hi && j < A.Wi) {
-        const int Wo = 2 * A.Wi;
-        float* dst = A.disp + ((size_t)b * 2 * A.Hi + 2 * i + PY) * Wo + 2 * j;
-        if (j + 1 < A.Wi) {
-            *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-        } else {
-            dst[0] = res[0];
-            dst[1] = res[1];
+        // the crop of SizeAdapter.unpad (size_adapter.py:45-52: rows from the top, columns from the left) is part of
+        // the store: the output is the contiguous [B, 2Hi - top, 2Wi - left] image itself
+        const int Wc = 2 * A.Wi - A.crop_left, Hc = 2 * A.Hi - A.crop_top;
+        const int row = 2 * i + PY - A.crop_top, col = 2 * j - A.crop_left;
+        if (row >= 0) {
+            float* dst = A.disp + ((size_t)b * Hc + row) * Wc + col;
+            const int valid = (j + 1 < A.Wi) ? 4 : 2;
+            if (valid == 4 && col >= 0 && ((A.crop_left | Wc) & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < valid && col + o >= 0) dst[o] = res[o];
+            }
         }
     }
 }
@@ -255,8 +263,10 @@ bool upsample_estimator_supported(int cin, int lo, int hi) {
 
 int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w,
                               const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
-                              int hi, int step, hipStream_t s) {
+                              int hi, int step, int crop_top, int crop_left, hipStream_t s) {
     FusedArgs A;
+    A.crop_top = crop_top;
+    A.crop_left = crop_left;
     A.in = in;
     A.scale = scale;
     A.shift = shift;
@@ -302,6 +312,7 @@ int launch_upsample_full(const float* in, const float* scale, const float* shift
     A.lo = 0;
     A.hi = 0;
     A.step = 0.f;
+    A.crop_top = A.crop_left = 0;
     dim3 grid((wi + TC - 1) / TC, (hi_ + TR - 1) / TR, batch);
     hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, true>), grid, dim3(UTHREADS), 0, s, A);
     return check_launch("upsample_full");

@@ -71,6 +71,12 @@ class PdsNetwork(nn.Module):
             signatures, shortcut_from_left = self._signatures(self._size_adapter.pad(left_image),
                                                               self._size_adapter.pad(right_image))
         if not self.training and self._can_fuse():
+            crop = self._size_adapter.padding() if hasattr(self._size_adapter, 'padding') else None
+            if crop is not None and self._regularization.can_fold_crop(self._estimator):
+                # SizeAdapter.unpad (size_adapter.py:45-52) folded into the estimator's store: the result is the
+                # contiguous [batch, H, W] image, not a view of the padded one
+                return self._regularization.forward_with_estimator(signatures, shortcut_from_left, self._estimator,
+                                                                   crop=crop)
             output = self._regularization.forward_with_estimator(signatures, shortcut_from_left,
                                                                  self._estimator)
         else:

@@ -204,6 +204,11 @@ class Regularization(nn.Module):
         params.upsample_full = _lib.conv_block_params(self._upsample_to_fullsize, None, tensor_of)
         return params
 
+    def can_fold_crop(self, estimator):
+        """The fused kernel (4 half-resolution features, at most 4 taps per side) is the one that folds the crop."""
+        taps = -(-estimator._half_support_window // estimator._disparity_step)
+        return self.number_of_features == 8 and 1 <= taps <= 4
+
     def _check_inputs(self, matching_signatures, shortcut_from_left_image):
         ms = _lib.require_gpu_tensor(matching_signatures, 'matching_signatures', 5)
         shortcut = _lib.require_gpu_tensor(shortcut_from_left_image, 'shortcut_from_left_image', 4)
@@ -220,11 +225,13 @@ class Regularization(nn.Module):
         ms, shortcut = self._check_inputs(matching_signatures, shortcut_from_left_image)
         return _RegularizationFunction.apply(self, ms, shortcut, None, *self.parameters())
 
-    def forward_with_estimator(self, matching_signatures, shortcut_from_left_image, estimator):
+    def forward_with_estimator(self, matching_signatures, shortcut_from_left_image, estimator, crop=(0, 0)):
         """Eval-mode fusion used by PdsNetwork: Regularization followed by SubpixelMap without
-        materialising the full-resolution cost volume (network.py:50-51).  -> [batch, 4h, 4w]."""
+        materialising the full-resolution cost volume (network.py:50-51).  ``crop`` = (rows, columns)
+        SizeAdapter.pad added on top / left (size_adapter.py:29-43): the crop of ``unpad`` (:45-52) is folded
+        into the store.  -> contiguous [batch, 4h - rows, 4w - columns]."""
         ms, shortcut = self._check_inputs(matching_signatures, shortcut_from_left_image)
-        window = (estimator._half_support_window, estimator._disparity_step)
+        window = (estimator._half_support_window, estimator._disparity_step, int(crop[0]), int(crop[1]))
         return _RegularizationFunction.apply(self, ms, shortcut, window, *self.parameters())
 
 
@@ -255,10 +262,11 @@ class _RegularizationFunction(torch.autograd.Function):
                     batch, d, h, w, _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(ms.device)),
                     'pds_regularization_fwd')
             else:
-                out = torch.empty((batch, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
+                crop_top, crop_left = estimator_window[2], estimator_window[3]
+                out = torch.empty((batch, 4 * h - crop_top, 4 * w - crop_left), dtype=torch.float32, device=ms.device)
                 _lib.check(lib.pds_regularization_subpixel_map_fwd(
                     ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
-                    batch, d, h, w, estimator_window[0], estimator_window[1],
+                    batch, d, h, w, estimator_window[0], estimator_window[1], crop_top, crop_left,
                     _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(ms.device)),
                     'pds_regularization_subpixel_map_fwd')
         if training:

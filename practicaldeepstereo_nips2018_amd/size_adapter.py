@@ -24,6 +24,10 @@ class SizeAdapter(object):
         self._pixels_pad_to_width = self._padding_for(width)
         return self._pixels_pad_to_height, self._pixels_pad_to_width
 
+    def padding(self):
+        """(rows added on top, columns added on the left) by the last ``pad`` / ``measure``."""
+        return self._pixels_pad_to_height, self._pixels_pad_to_width
+
     def pad(self, network_input):
         self.measure(network_input)
         return F.pad(network_input, (self._pixels_pad_to_width, 0, self._pixels_pad_to_height, 0))

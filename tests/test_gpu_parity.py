@@ -500,3 +500,19 @@ def test_resident_weights_follow_parameter_updates(dev):
         expected = run(fresh)       # a module that has never packed anything
     assert not torch.equal(updated[0], first[0])
     assert torch.equal(updated[0], expected[0]) and torch.equal(updated[1], expected[1])
+
+
+def test_unpad_is_folded_into_the_estimator_store(dev):
+    """SURVEY.md 8 f3, second half (size_adapter.py:45-52): the whole-network eval output is the contiguous cropped
+    image written by the fused kernel, bit-identical to cropping the padded result; odd crops (KITTI: 9 rows, 38
+    columns) take the unaligned store path."""
+    for height, width in ((100, 154), (128, 192), (375 // 3, 1242 // 6)):
+        net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).eval().to(dev)
+        left, right = helpers.images(1, height, width)
+        with torch.no_grad():
+            out = net(left.to(dev), right.to(dev))
+            top, lft = net._size_adapter.padding()
+            signatures, shortcut = net._signatures_from_unpadded(left.to(dev), right.to(dev))
+            padded = net._regularization.forward_with_estimator(signatures, shortcut, net._estimator)
+        assert out.shape == (1, height, width) and out.is_contiguous()
+        assert torch.equal(out, padded[..., top:, lft:]), (height, width)
