@@ -43,6 +43,8 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s);        // conv2d_wino
 bool conv2d_wino_eligible(const ConvLayer& L);
 int conv2d_wino_tiles(const Geom& out_g);
 size_t conv2d_wino_packed_floats(int cin, int cout);
+int launch_conv2d_t8(const ConvLayer& L, hipStream_t s);          // conv2d_t8.hip (64 -> 8 channels, bare)
+bool conv2d_t8_supported(const ConvLayer& L);
 int launch_conv2d_wino2d(const ConvLayer& L, hipStream_t s);      // conv2d_wino2d.hip
 bool conv2d_wino2d_eligible(const ConvLayer& L);
 int conv2d_wino2d_tiles(const Geom& out_g);
@@ -292,7 +294,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
     // Winograd domain (plain single-source Cin -> 64 layers)
     int kind = 0;
-    if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino2d_eligible(L) ? 5 : conv2d_wino_eligible(L) ? 4 : 2;
+    if (allow_mfma && !norm && !c.tape && conv2d_t8_supported(L)) kind = 8;   // persistent y-Toeplitz kernel, no packing
+    else if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino2d_eligible(L) ? 5 : conv2d_wino_eligible(L) ? 4 : 2;
     else if (allow_mfma && conv3d_t8_supported(L)) kind = 6;   // persistent z-Toeplitz kernel, no weight packing
     else if (allow_mfma && conv3d_ks_supported(L)) kind = 7;   // inner levels: K split over the waves
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
@@ -303,7 +306,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     if (kind == 5) L.packed = c.get<float>(conv2d_wino2d_packed_floats(in.c, cout));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
-    if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 5) {
+    if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 5 && kind != 8) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
     }
@@ -313,10 +316,11 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
                          : kind == 5 ? launch_conv2d_wino2d(L, c.s)
                                      : kind == 3 ? launch_conv3d_mfma(L, c.s)
                                                  : kind == 6 ? launch_conv3d_t8(L, c.s)
-                                                             : kind == 7 ? launch_conv3d_ks(L, c.s) : launch_conv_direct(L, c.s);
+                                                             : kind == 7 ? launch_conv3d_ks(L, c.s)
+                                                                         : kind == 8 ? launch_conv2d_t8(L, c.s) : launch_conv_direct(L, c.s);
     };
     const bool collecting = c.sink && c.sink->phase == kPackCollect && c.base != nullptr;
-    if (collecting && kind != 0 && kind != 6) c.run(launch());  // registers the pack job(s) only
+    if (collecting && kind != 0 && kind != 6 && kind != 8) c.run(launch());  // registers the pack job(s) only
     if (norm) {
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)

@@ -20,6 +20,7 @@ SWITCHES = [
     {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
     {'PDS_CONV3D_XCD_MAP': '0'},
     {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0', 'PDS_CONV3D_KS': '0'},   # generic MFMA kernels for all hourglass layers
+    {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
 ]
 
 
