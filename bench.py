@@ -51,9 +51,26 @@ HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 # dense 2*MAC count of one 64->64 3x3 convolution over [1, 64, 48, 144, 240] (122.31 GF)
 CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
-# HBM bytes per launch of that kernel from the PMC counters (profiles/r01_conv64_wino_pmc.txt); a recorded
-# measurement, not re-collected by this script (counters need rocprofv3 around the process)
-CONV64_HBM_BYTES = 861.0e6   # FETCH_SIZE 219.3 MB x 2 (the guide's gfx950 correction for wide reads) + WRITE_SIZE 421.9 MB
+# HBM bytes per launch of that kernel come from the PMC record committed with the round's profiles (rocprofv3 must
+# wrap the process to collect counters, so this script cannot re-collect them): tools/collect_profiles.sh writes the
+# counters, profiles/r02_conv64_pmc.json holds FETCH_SIZE / WRITE_SIZE of this kernel and the guide's gfx950 correction
+CONV64_PMC_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_conv64_pmc.json')
+
+
+def conv64_hbm_traffic():
+    """(bytes per launch, description) from the committed PMC record, or (None, reason) when it is absent."""
+    try:
+        with open(CONV64_PMC_RECORD) as f:
+            rec = json.load(f)
+    except (OSError, ValueError) as e:
+        return None, 'no PMC record: %s' % e
+    nbytes = (rec['FETCH_SIZE_KB'] * rec['fetch_correction'] + rec['WRITE_SIZE_KB']) * 1e3
+    return nbytes, ('rocprofv3 FETCH_SIZE %.1f MB x %g (gfx950 wide-read correction) + WRITE_SIZE %.1f MB, separate '
+                    '--pmc passes, profiles/r02_conv64_pmc.json <- profiles/r02_pmc_all_kernels.txt (algorithmic %.1f MB)'
+                    % (rec['FETCH_SIZE_KB'] / 1e3, rec['fetch_correction'], rec['WRITE_SIZE_KB'] / 1e3,
+                       rec['algorithmic_bytes'] / 1e6))
+
+
 # The layer runs in the Winograd domain (csrc/conv2d_wino.hip, F(2,3) along x): 2/3 of the multiplies of the direct
 # form, over 64-column tiles (256 columns computed for 240)
 CONV64_EXECUTED_GFLOP = CONV64_GFLOP * (2.0 / 3.0) * (256.0 / 240.0)
@@ -465,12 +482,11 @@ def main():
         with torch.no_grad():
             kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)
         achieved = CONV64_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
+        traffic, traffic_source = conv64_hbm_traffic()
         line['roofline'] = {'kernel': 'conv2d 3x3 64->64 (+bias, LeakyReLU, InstanceNorm partials) over 48 planes '
                                       'of 144x240, one launch', 'bound': 'mfma', 'achieved': achieved,
                             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                            'traffic': CONV64_HBM_BYTES, 'traffic_unit': 'bytes per launch',
-                            'traffic_source': 'rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes, see '
-                                              'profiles/r01_conv64_wino_pmc.txt (algorithmic 849e6)',
+                            'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_source,
                             'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP,
                             'algorithm': 'Winograd F(2,3) along x on the fp32 MFMA units: "achieved" counts the '
                                          'ALGORITHMIC flops of the direct convolution; the MFMA pipe executes '
