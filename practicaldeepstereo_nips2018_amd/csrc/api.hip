@@ -249,6 +249,7 @@ struct ConvExtra {
     const float* l0G = nullptr;
     const float* l0G2 = nullptr;
     size_t l0_cstride = 0;
+    int l0_rs = 0;
     int d_begin = 0;
     float* side_out = nullptr;
     int plane_weight_sets = 0;
@@ -287,6 +288,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.l0G = extra->l0G;
         L.l0G2 = extra->l0G2;
         L.l0_cstride = extra->l0_cstride;
+        L.l0_rs = extra->l0_rs;
         L.d_begin = extra->d_begin;
         L.side_out = extra->side_out;
         L.plane_weight_sets = extra->plane_weight_sets;
@@ -458,12 +460,6 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     const size_t wn = (size_t)F * F * 9;
     float* w3 = c.get<float>(3 * wn);       // [3 sets][F][F][3][3]: left half, right half, right half without dx=+1
     float* bias3 = c.get<float>(3 * F);
-    const Geom g3{batch, F, 3, h, w + 1};   // plane 0: left, planes 1-2: right, each padded by one zero column
-    float* x3 = c.get<float>(g3.numel());
-    if (c.before_packing())
-        c.run(launch_split_first_weights(P.first.weight, P.first.bias, w3, w3 + wn, w3 + 2 * wn, bias3, F, F, c.s));
-    if (!c.plan) c.run(launch_l0_stack_inputs(left, right, x3, (size_t)batch * F, h, w, c.s));
-    // A = conv_L(left) + bias, G = conv_R(right), G2 = G without its dx = +1 taps: three planes of y3
     const Geom g{batch, F, d_count, h, w};
     const bool fused = [&]() {
         static const bool enabled = []() {  // PDS_MATCHING_FUSED=0 selects the unfused sequence (A/B, debugging)
@@ -472,12 +468,40 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         }();
         return enabled && fused_matching_supported(P, batch, h, w, d_count);
     }();
+    // Column form (misc.hip): G2 / Ha / Hb / H0 only at the columns that are read, as corrections to G / H; the
+    // convolutions run over two 64-channel planes instead of three (layer 0) and five 128-channel ones (layer 1).
+    // PDS_MATCHING_COLUMNS=0 keeps the whole-plane form.
+    const bool columns = [&]() {
+        static const bool enabled = []() {
+            const char* e = getenv("PDS_MATCHING_COLUMNS");
+            return !(e && e[0] == '0');
+        }();
+        return enabled && fused && P.residual_blocks >= 1 && F % 8 == 0;
+    }();
+    const int l0_planes = columns ? 2 : 3;
+    // plane 0: left, planes 1(-2): right, each behind one zero column -- two in the column form: the width is even
+    // (Winograd kernel) and the output is, after zeroing two columns of A, the input of the layer-1 launch
+    const int l0_pad = columns ? 2 : 1;
+    const int l0_rs = w + l0_pad;
+    const Geom g3{batch, F, l0_planes, h, l0_rs};
+    float* x3 = c.get<float>(g3.numel());
+    float* wcol0 = columns ? c.get<float>(9 * (size_t)F * F) : nullptr;   // [dx][ic][dy][oc] of the right half of conv0
+    float* wcol1 = columns ? c.get<float>(9 * (size_t)F * F) : nullptr;   // ... of the first conv of block 1
+    if (c.before_packing()) {
+        c.run(launch_split_first_weights(P.first.weight, P.first.bias, w3, w3 + wn, w3 + 2 * wn, bias3, F, F, c.s));
+        if (columns) {
+            c.run(launch_column_weights(P.first.weight, 2 * F, F, F, F, wcol0, c.s));
+            c.run(launch_column_weights(P.blocks[0].weight, F, 0, F, F, wcol1, c.s));
+        }
+    }
+    if (!c.plan) c.run(launch_l0_stack_inputs(left, right, x3, (size_t)batch * F, h, w, l0_planes, l0_pad, c.s));
+    // A = conv_L(left) + bias, G = conv_R(right), G2 = G without its dx = +1 taps: the planes of y3
     float* y3;
     if (fused) {
         // one launch, per-plane weight sets
         PdsConvBlockParams p3{w3, bias3, nullptr, nullptr};
         ConvExtra e3;
-        e3.plane_weight_sets = 3;
+        e3.plane_weight_sets = l0_planes;
         y3 = conv_block(c, plain_src(x3), no_src(), g3, p3, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e3).raw;
     } else {
         // generic kernels share one weight set per launch: three launches into the planes of y3
@@ -496,10 +520,20 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
                                         (size_t)batch * F, hipMemcpyDeviceToDevice, c.s));
         }
     }
-    const size_t l0_cstride = (size_t)3 * h * (w + 1);
-    const float* l0A = y3 + 1;                               // column 1 of plane 0
-    const float* l0G = y3 + (size_t)h * (w + 1);             // plane 1
-    const float* l0G2 = y3 + (size_t)2 * h * (w + 1);        // plane 2
+    const size_t l0_cstride = (size_t)l0_planes * h * l0_rs;
+    const float* l0A = y3 + l0_pad;                                      // column of x = 0 in plane 0
+    const float* l0G = y3 + (size_t)h * l0_rs + (l0_pad - 1);            // plane 1; index u + 1 holds G[u]
+    const float* l0G2 = y3 + (size_t)2 * h * l0_rs + (l0_pad - 1);       // plane 2
+    float* g2buf = nullptr;
+    if (columns) {
+        // G2 in a buffer of its own with the channel stride of y3 (its consumers take ONE stride for A, G, G2); only
+        // the columns u = w - 1 - d of the planes of this call are ever written or read
+        g2buf = c.get<float>(g3.numel());
+        if (!c.plan)
+            c.run(launch_l0_column_fix(y3 + (size_t)h * l0_rs, right, wcol0, g2buf + (size_t)h * l0_rs, y3, l0_pad,
+                                       l0_cstride, l0_rs, l0_pad, batch, F, F, h, w, d_begin, d_count, c.s));
+        l0G2 = g2buf + (size_t)h * l0_rs + (l0_pad - 1);
+    }
     if (!fused) {
         float* x0 = c.get<float>(g.numel());
         if (!c.plan) c.run(launch_l0_combine(l0A, l0G, l0G2, l0_cstride, x0, batch, F, h, w, d_begin, d_count, c.s));
@@ -514,6 +548,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     l0.l0G = l0G;
     l0.l0G2 = l0G2;
     l0.l0_cstride = l0_cstride;
+    l0.l0_rs = l0_rs;
     l0.d_begin = d_begin;
     const Src none = no_src();
     if (P.residual_blocks == 0) {
@@ -524,17 +559,41 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     // 5-plane launch with tap-masked weight sets; then LeakyReLU(B + shift_d(H)) + statistics in one streaming pass.
     DT t1;
     {
-        const size_t wn4 = (size_t)kL1Planes * F * 2 * F * 9;
-        float* w4 = c.get<float>(wn4);
-        float* bias4 = c.get<float>(kL1Planes * F);
-        const Geom g4{batch, 2 * F, kL1Planes, h, w + 2};
-        float* x4 = c.get<float>(g4.numel());
-        if (c.before_packing()) c.run(launch_l1_weights(P.blocks[0].weight, P.blocks[0].bias, w4, bias4, F, F, c.s));
-        if (!c.plan) c.run(launch_l1_stack_inputs(y3, x4, batch, F, h, w, c.s));
-        PdsConvBlockParams p4{w4, bias4, nullptr, nullptr};
-        ConvExtra e4;
-        e4.plane_weight_sets = kL1Planes;
-        DT y4 = conv_block(c, plain_src(x4), none, g4, p4, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e4);
+        DT y4;
+        const float* corr = nullptr;
+        const float* corr0 = nullptr;
+        if (columns) {
+            float* w2 = c.get<float>(2 * wn);
+            float* bias2 = c.get<float>(2 * F);
+            const Geom g2{batch, F, 2, h, w + 2};   // == g3: the layer-0 output is the input (A's two left columns zeroed)
+            float* cr = c.get<float>((size_t)batch * F * h * d_count * 2);
+            float* cr0 = c.get<float>((size_t)batch * F * h);
+            if (c.before_packing())
+                c.run(launch_l1_weights2(P.blocks[0].weight, P.blocks[0].bias, w2, bias2, F, F, c.s));
+            if (!c.plan)
+                c.run(launch_l1_column_terms(y3 + (size_t)h * l0_rs, g2buf + (size_t)h * l0_rs, wcol1, cr, cr0,
+                                             l0_cstride, l0_rs, l0_pad, batch, F, F, h, w, d_begin, d_count, c.s));
+            float* x2 = y3;
+            PdsConvBlockParams p2{w2, bias2, nullptr, nullptr};
+            ConvExtra e2;
+            e2.plane_weight_sets = 2;
+            y4 = conv_block(c, plain_src(x2), none, g2, p2, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e2);
+            corr = cr;
+            corr0 = cr0;
+        } else {
+            const size_t wn4 = (size_t)kL1Planes * F * 2 * F * 9;
+            float* w4 = c.get<float>(wn4);
+            float* bias4 = c.get<float>(kL1Planes * F);
+            const Geom g4{batch, 2 * F, kL1Planes, h, w + 2};
+            float* x4 = c.get<float>(g4.numel());
+            if (c.before_packing())
+                c.run(launch_l1_weights(P.blocks[0].weight, P.blocks[0].bias, w4, bias4, F, F, c.s));
+            if (!c.plan) c.run(launch_l1_stack_inputs(y3, x4, batch, F, h, w, c.s));
+            PdsConvBlockParams p4{w4, bias4, nullptr, nullptr};
+            ConvExtra e4;
+            e4.plane_weight_sets = kL1Planes;
+            y4 = conv_block(c, plain_src(x4), none, g4, p4, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e4);
+        }
         t1.g = g;
         t1.per_plane = 1;
         t1.raw = c.get<float>(g.numel());
@@ -546,7 +605,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         t1.mean = c.get<float>(groups);
         t1.rstd = c.get<float>(groups);
         if (!c.plan) {
-            c.run(launch_l1_combine(y4.raw, t1.raw, partials, batch, F, h, w, d_begin, d_count, c.s));
+            c.run(launch_l1_combine(y4.raw, corr, corr0, t1.raw, partials, batch, F, h, w, d_begin, d_count, c.s));
             c.run(launch_in_finalize(partials, groups, tiles, (double)h * w, P.blocks[0].gamma, P.blocks[0].beta, F,
                                      d_count, t1.scale, t1.shift, t1.mean, t1.rstd, c.s));
         }
@@ -558,7 +617,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         return;
     }
     float* cur = c.get<float>(g.numel());
-    if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, d_begin, cur, c.s));
+    if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur, c.s));
     for (int r = 1; r < P.residual_blocks; ++r) {
         t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1);
         t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1);

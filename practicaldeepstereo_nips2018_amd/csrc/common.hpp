@@ -91,11 +91,13 @@ struct ConvLayer {
     float* packed;       // scratch for MFMA-ordered weights (MFMA kernels only)
     // conv2d_mfma only: layer-0 terms added on the fly (x0 = l0A + shift_d(l0G)) and an
     // optional copy of the staged input (the residual sum the NEXT block needs)
-    // all three have row stride w + 1 and channel stride l0_cstride; l0A points at column 1 of its rows
+    // all three have row stride l0_rs and channel stride l0_cstride; l0A points at the column of x = 0 of its rows,
+    // l0G / l0G2 hold G[u] at index u + 1
     const float* l0A = nullptr;
     const float* l0G = nullptr;
     const float* l0G2 = nullptr;
     size_t l0_cstride = 0;
+    int l0_rs = 0;
     int d_begin = 0;
     float* side_out = nullptr;
     // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)
@@ -160,7 +162,7 @@ int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int bat
 int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s);
 // out = norm(a) + (A + shift_d(G)): the first residual sum of the fused Matching path
 int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
-                          size_t l0_cstride, int d_begin, float* out, hipStream_t s);
+                          size_t l0_cstride, int l0_rs, int d_begin, float* out, hipStream_t s);
 
 int launch_subpixel_map(const float* sim, float* disp, int batch, int planes, int height, int width,
                         int taps_lo, int taps_hi, int step, hipStream_t s);
@@ -174,15 +176,27 @@ int launch_shift_concat(const float* left, const float* right, float* out, int b
 int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cstride, float* x0, int batch,
                       int channels, int h, int w, int d_begin, int d_count, hipStream_t s);
 int launch_l0_stack_inputs(const float* left, const float* right, float* out, size_t bc_count, int h, int w,
-                           hipStream_t s);
+                           int planes, int pad, hipStream_t s);
 
 // layer-1 factorisation (misc.hip): planes B, H, Ha, Hb, H0
 constexpr int kL1Planes = 5;
 int launch_l1_stack_inputs(const float* y3, float* x4, int batch, int channels, int h, int w, hipStream_t s);
 int launch_l1_weights(const float* w1, const float* b1, float* w4, float* bias4, int cout, int channels, hipStream_t s);
 int l1_combine_tiles(int h, int w);
-int launch_l1_combine(const float* y4, float* t1, double* partials, int batch, int channels, int h, int w,
-                      int d_begin, int d_count, hipStream_t s);
+int launch_l1_combine(const float* y4, const float* corr, const float* corr0, float* t1, double* partials,
+                      int batch, int channels, int h, int w, int d_begin, int d_count, hipStream_t s);
+// column form (misc.hip): only A, G / B, H are full planes; G2, Ha, Hb, H0 are corrections at the columns that are read
+int launch_column_weights(const float* wt, int cin_total, int cin_off, int channels, int cout, float* out,
+                          hipStream_t s);
+// G / G2: channel stride cstride, row stride rs, G[u] at column u + co; A (same strides): first zero_cols columns zeroed
+int launch_l0_column_fix(const float* G, const float* R, const float* wcol, float* G2, float* A, int zero_cols,
+                         size_t cstride, int rs, int co, int batch, int channels, int cout, int h, int w, int d_begin,
+                         int d_count, hipStream_t s);
+int launch_l1_column_terms(const float* G, const float* G2, const float* wcol, float* corr, float* corr0,
+                           size_t cstride, int rs, int co, int batch, int channels, int cout, int h, int w, int d_begin,
+                           int d_count, hipStream_t s);
+int launch_l1_weights2(const float* w1, const float* b1, float* w2, float* bias2, int cout, int channels,
+                       hipStream_t s);
 
 // small utility: zero-pad one column on the left ([.., w] -> [.., w+1]); split conv0 weights
 int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_t s);

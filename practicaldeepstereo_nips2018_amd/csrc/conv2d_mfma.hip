@@ -64,11 +64,12 @@ struct MfmaArgs {
     int lrelu;
     int tiles_x, tiles;              // tiles per row of tiles, tiles per plane
     // layer-0 terms formed on the fly (SRC 2, 3): x0[c,d,y,x] = A[c,y,x] + G[c,y,x-d] (+ right-edge fix)
-    // all three: row stride W + 1, channel stride l0_cstride
-    const float* __restrict__ l0A;   // conv_L(left) + bias, pointing at column 1 of its rows
+    // all three: row stride l0_rs, channel stride l0_cstride
+    const float* __restrict__ l0A;   // conv_L(left) + bias, pointing at the column of x = 0 of its rows
     const float* __restrict__ l0G;   // conv_R(right), column u + 1 for u = x - d
     const float* __restrict__ l0G2;  // same without the dx = +1 taps (used at x = W-1, d >= 1)
     size_t l0_cstride;
+    int l0_rs;
     int d_begin;                     // disparity of plane 0
     size_t w_set_stride;             // floats between the packed weight sets of consecutive planes (0: shared)
     int bias_set_stride;             // ditto for the bias
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
         if (HAS_L0) {
             const int u = xc - disp;  // column of the un-shifted right descriptor
             gvalid[k] = u >= -1;
-            gg_off[k] = yc * (A.W + 1) + max(u, -1) + 1;
+            gg_off[k] = yc * A.l0_rs + max(u, -1) + 1;
             gsel[k] = ((xc == A.W - 1 && disp >= 1) ? A.l0G2 : A.l0G) + (size_t)n * A.Cin * A.l0_cstride;
         }
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(THREADS, (SRC == 0 || SRC == 2 || MB == 1) ? PDS_WA
     int la_off[HAS_L0 ? POS : 1];
     if (HAS_L0) {
 #pragma unroll
-        for (int k = 0; k < POS; ++k) la_off[k] = (g_off[k] / A.W) * (A.W + 1) + g_off[k] % A.W;
+        for (int k = 0; k < POS; ++k) la_off[k] = (g_off[k] / A.W) * A.l0_rs + g_off[k] % A.W;
     }
     const float* wbase = A.wpk + (size_t)d * A.w_set_stride;
     const float* bias = A.bias ? A.bias + d * A.bias_set_stride : nullptr;
@@ -346,7 +347,7 @@ bool conv2d_mfma_supported(const ConvLayer& L) {
     if (L.in.c % KC != 0 || L.in.c > 256) return false;
     if (mfma_blocks(L.out_g.c) == 0) return false;
     if (L.b.p && L.b.bcast_d) return false;
-    if (L.l0A && L.in.h * (L.in.w + 1) * (size_t)L.in.c >= ((size_t)1 << 31)) return false;
+    if (L.l0A && L.in.h * (L.in.w + 2) * (size_t)L.in.c >= ((size_t)1 << 31)) return false;
     // offsets inside an 8-channel chunk are kept in 32-bit registers
     if ((size_t)KC * L.in.d * L.in.h * L.in.w >= ((size_t)1 << 31)) return false;
     if (L.in.d > 65535 || L.in.n > 65535) return false;
@@ -431,6 +432,7 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     A.l0G = L.l0G;
     A.l0G2 = L.l0G2;
     A.l0_cstride = L.l0_cstride;
+    A.l0_rs = L.l0_rs;
     A.w_set_stride = L.plane_weight_sets > 0 ? (size_t)total : 0;
     A.bias_set_stride = L.plane_weight_sets > 0 ? L.out_g.c : 0;
     A.d_begin = L.d_begin;

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const Src a, const Src
 __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const Geom g, const float* __restrict__ A,
                                                              const float* __restrict__ G,
                                                              const float* __restrict__ G2, size_t l0_cstride,
-                                                             int d_begin, float* __restrict__ out) {
+                                                             int l0_rs, int d_begin, float* __restrict__ out) {
     // grid: x = tile over (y, x/4), y = d, z = n*C + c
     const int nc = blockIdx.z, d = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
     float sa, ha;
     src_coeffs(a, n, g.c, c, g.d, d, sa, ha);
     const float* pa = a.p + ((size_t)nc * g.d + d) * px;
-    const float* pA = A + (size_t)nc * l0_cstride;   // row stride w + 1, already at column 1
+    const float* pA = A + (size_t)nc * l0_cstride;   // row stride l0_rs, already at the column of x = 0
     const float* pG = G + (size_t)nc * l0_cstride;
     const float* pG2 = G2 + (size_t)nc * l0_cstride;
     float* po = out + ((size_t)nc * g.d + d) * px;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
         const int y = q / xq, x0 = (q - y * xq) * 4;
         const size_t i = (size_t)y * g.w + x0;
         float av[4], lv[4], r[4];
-        const size_t ia = (size_t)y * (g.w + 1) + x0;
+        const size_t ia = (size_t)y * l0_rs + x0;
         if (vec) {
             const float4 t = *reinterpret_cast<const float4*>(pa + i);
             av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
             const int u = x - disp;
             float x0v = lv[k];
             if (u >= -1 && x < g.w) {
-                const size_t off = (size_t)y * (g.w + 1) + (u + 1);
+                const size_t off = (size_t)y * l0_rs + (u + 1);
                 x0v += (x == g.w - 1 && disp >= 1) ? pG2[off] : pG[off];
             }
             r[k] = fmaf(sa, av[k], ha) + x0v;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
 __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, const Geom g, const float* __restrict__ A,
                                                                    const float* __restrict__ G,
                                                                    const float* __restrict__ G2, size_t l0_cstride,
-                                                                   int d_begin, float* __restrict__ out) {
+                                                                   int l0_rs, int d_begin, float* __restrict__ out) {
     const int nc = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
     const size_t px = g.plane();
@@ -526,10 +526,10 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
     const bool active = (int)(blockIdx.x * 256 + threadIdx.x) < total;
     const int y = q / xq, xi = q - y * xq, x0 = xi * 4;
     const size_t i = (size_t)y * g.w + x0;
-    const size_t row = (size_t)y * (g.w + 1);
+    const size_t row = (size_t)y * l0_rs;
     const float* pa = a.p + (size_t)nc * g.d * px + i;
     float* po = out + (size_t)nc * g.d * px + i;
-    const float* pA = A + (size_t)nc * l0_cstride + row + x0;   // already at column 1
+    const float* pA = A + (size_t)nc * l0_cstride + row + x0;   // already at the column of x = 0
     const float* pG = G + (size_t)nc * l0_cstride + row;        // column u + 1 holds G[u], u >= -1
     const float* pG2 = G2 + (size_t)nc * l0_cstride + row;
     float lv[4], gw[4];
@@ -577,18 +577,18 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
 }
 
 int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
-                          size_t l0_cstride, int d_begin, float* out, hipStream_t s) {
+                          size_t l0_cstride, int l0_rs, int d_begin, float* out, hipStream_t s) {
     if ((g.w & 3) == 0) {
         const int quads = g.h * (g.w / 4);
         hipLaunchKernelGGL(materialize_l0_sweep_kernel, dim3((quads + 255) / 256, g.n * g.c), dim3(256), 0, s, a, g, A, G,
-                           G2, l0_cstride, d_begin, out);
+                           G2, l0_cstride, l0_rs, d_begin, out);
         return check_launch("materialize_l0");
     }
     const int quads = g.h * ((g.w + 3) / 4);
     unsigned bx = (unsigned)((quads + 255) / 256);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(materialize_l0_kernel, dim3(bx, g.d, g.n * g.c), dim3(256), 0, s, a, g, A, G, G2, l0_cstride,
-                       d_begin, out);
+                       l0_rs, d_begin, out);
     return check_launch("materialize_l0");
 }
 

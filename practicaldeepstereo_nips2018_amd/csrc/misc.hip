@@ -81,30 +81,32 @@ int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cs
     return check_launch("l0_combine");
 }
 
-// Inputs of the three layer-0 convolutions as ONE volume [B*C][3 planes][h][w+1]: plane 0 = left descriptor,
-// planes 1 and 2 = right descriptor, each padded with one zero column on the left.
+// Inputs of the layer-0 convolutions as ONE volume [B*C][planes][h][w+pad]: plane 0 = left descriptor,
+// planes 1 (and 2) = right descriptor, each behind `pad` zero columns on the left.
 __global__ __launch_bounds__(256) void l0_stack_inputs_kernel(const float* __restrict__ left,
                                                               const float* __restrict__ right,
-                                                              float* __restrict__ out, size_t bc_count, int h, int w) {
-    const size_t total = bc_count * 3 * h * (size_t)(w + 1);
+                                                              float* __restrict__ out, size_t bc_count, int h, int w,
+                                                              int planes, int pad) {
+    const int wp = w + pad;
+    const size_t total = bc_count * planes * h * (size_t)wp;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % (w + 1));
-        size_t r = i / (w + 1);
+        const int x = (int)(i % wp);
+        size_t r = i / wp;
         const int y = (int)(r % h);
         r /= h;
-        const int p = (int)(r % 3);
-        const size_t bc = r / 3;
+        const int p = (int)(r % planes);
+        const size_t bc = r / planes;
         const float* src = p == 0 ? left : right;
-        out[i] = x == 0 ? 0.f : src[(bc * h + y) * w + x - 1];
+        out[i] = x < pad ? 0.f : src[(bc * h + y) * w + x - pad];
     }
 }
 
 int launch_l0_stack_inputs(const float* left, const float* right, float* out, size_t bc_count, int h, int w,
-                           hipStream_t s) {
-    const size_t total = bc_count * 3 * h * (size_t)(w + 1);
+                           int planes, int pad, hipStream_t s) {
+    const size_t total = bc_count * planes * h * (size_t)(w + pad);
     unsigned bx = (unsigned)((total + 255) / 256);
     if (bx > 8192) bx = 8192;
-    hipLaunchKernelGGL(l0_stack_inputs_kernel, dim3(bx), dim3(256), 0, s, left, right, out, bc_count, h, w);
+    hipLaunchKernelGGL(l0_stack_inputs_kernel, dim3(bx), dim3(256), 0, s, left, right, out, bc_count, h, w, planes, pad);
     return check_launch("l0_stack_inputs");
 }
 
@@ -227,6 +229,229 @@ __global__ __launch_bounds__(256) void l1_weights_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Column form of the two factorisations (round 2).  G2, Ha, Hb and H0 differ from G / H only through the taps of ONE
+// kernel column, and each is read at ONE column per disparity plane (u = w-1-d, w-2-d) or at x = 0, so instead of
+// whole extra planes (three of the five 128-channel planes of the launch above, one of the three of layer 0):
+//   G2[u]          = G[u]  - sum_{ic,dy} Wr[dy][+1] R[y+dy][u+1]                                   (u = w-1-d, d >= 1)
+//   Ha[u] - H[u]   =  sum W1[dy][+1] D[y+dy][u+1]                       D = G2 - G                 (u = w-2-d)
+//   Hb[u] - H[u]   =  sum W1[dy][0]  D[y+dy][u] - sum W1[dy][+1] G[y+dy][u+1]                      (u = w-1-d)
+//   H0[0] - H[0]   = -sum W1[dy][-1] G[y+dy][-1]
+// (sums over the 64 input channels and the three kernel rows; rows and columns outside the images are zero).  Only
+// A, G (layer 0) and B, H (layer 1) remain full 64-channel planes; the corrections are a few thousand short dot
+// products.  Weight columns are re-laid out as wcol[dx][ic][dy][oc] so that a wave reads them through scalar loads.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void column_weights_kernel(const float* __restrict__ wt, int cin_total, int cin_off,
+                                                             int C, int cout, float* __restrict__ out) {
+    const int total = 3 * C * 3 * cout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int oc = i % cout;
+        const int dy = (i / cout) % 3;
+        const int ic = (i / (3 * cout)) % C;
+        const int dx = i / (3 * cout * C);
+        out[i] = wt[(((size_t)oc * cin_total + cin_off + ic) * 3 + dy) * 3 + dx];
+    }
+}
+
+int launch_column_weights(const float* wt, int cin_total, int cin_off, int channels, int cout, float* out,
+                          hipStream_t s) {
+    const int total = 9 * channels * cout;
+    hipLaunchKernelGGL(column_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, wt, cin_total, cin_off,
+                       channels, cout, out);
+    return check_launch("column_weights");
+}
+
+constexpr int kColOcg = 8;      // output channels per thread
+constexpr int kColSlices = 8;   // the input channels are split over the 8 waves of a workgroup (these kernels are a few
+                                // thousand short dot products: bound by load latency, so spread them as wide as possible)
+
+// G2 at the columns the disparity planes [d_lo, d_lo + count) (all >= 1, <= w) read: u = w - 1 - d.  G / G2: row
+// stride rs, column u + co.  Also zeroes the first `zero_cols` columns of A (same strides): with two padding columns
+// the layer-0 output doubles as the input of the layer-1 launch, which needs literal zeros left of the image.
+// grid: x = items (y, j) / 64, y = batch * cout / kColOcg; 512 threads: wave = slice of input channels, lane = item
+__global__ __launch_bounds__(512) void l0_column_fix_kernel(const float* __restrict__ G, const float* __restrict__ R,
+                                                            const float* __restrict__ wcol, float* __restrict__ G2,
+                                                            float* __restrict__ A, int zero_cols, size_t cstride,
+                                                            int rs, int co, int C, int cout, int h, int w, int d_lo,
+                                                            int count) {
+    __shared__ float red[kColSlices][kColOcg][64];
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int groups = cout / kColOcg;
+    const int b = blockIdx.y / groups, ocg = blockIdx.y % groups;
+    if (blockIdx.x == 0 && zero_cols > 0) {
+        for (int i = threadIdx.x; i < kColOcg * h * zero_cols; i += 512) {
+            const int k = i / (h * zero_cols), r = i % (h * zero_cols);
+            A[(size_t)(b * cout + ocg * kColOcg + k) * cstride + (size_t)(r / zero_cols) * rs + r % zero_cols] = 0.f;
+        }
+    }
+    const int item = blockIdx.x * 64 + lane;
+    const bool live = item < h * count;
+    const int y = live ? item / count : 0, d = d_lo + (live ? item % count : 0);
+    const int xr = w - d;  // column of R under the dropped tap (u + 1), in [0, w-1]
+    float acc[kColOcg];
+#pragma unroll
+    for (int k = 0; k < kColOcg; ++k) acc[k] = 0.f;
+    const float* wc = wcol + (size_t)2 * C * 3 * cout + ocg * kColOcg;  // dx = +1
+    const int per = (C + kColSlices - 1) / kColSlices;
+    const int ic_end = (slice + 1) * per < C ? (slice + 1) * per : C;
+    for (int ic = slice * per; ic < ic_end; ++ic) {
+        const float* r = R + ((size_t)(b * C + ic) * h) * w + xr;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const float v = (live && yy >= 0 && yy < h) ? r[(size_t)yy * w] : 0.f;
+            const float* wk = wc + ((size_t)ic * 3 + dy) * cout;
+#pragma unroll
+            for (int k = 0; k < kColOcg; ++k) acc[k] = fmaf(wk[k], v, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kColOcg; ++k) red[slice][k][lane] = acc[k];
+    __syncthreads();
+    {
+        const int k = threadIdx.x >> 6;  // 8 waves <-> 8 output channels
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < kColSlices; ++sl) v += red[sl][k][lane];
+        if (live) {
+            const size_t off = (size_t)(b * cout + ocg * kColOcg + k) * cstride + (size_t)y * rs + (xr - 1 + co);
+            G2[off] = G[off] - v;
+        }
+    }
+}
+
+int launch_l0_column_fix(const float* G, const float* R, const float* wcol, float* G2, float* A, int zero_cols,
+                         size_t cstride, int rs, int co, int batch, int channels, int cout, int h, int w, int d_begin,
+                         int d_count, hipStream_t s) {
+    static_assert(kColOcg == kColSlices, "the final reduction maps one wave to one output channel");
+    const int d_lo = d_begin > 1 ? d_begin : 1;
+    int d_hi = d_begin + d_count - 1;
+    if (d_hi > w) d_hi = w;
+    int count = d_hi - d_lo + 1;
+    if (count < 0) count = 0;
+    if (count == 0 && zero_cols == 0) return 0;
+    const int bx = count > 0 ? (h * count + 63) / 64 : 1;
+    hipLaunchKernelGGL(l0_column_fix_kernel, dim3(bx, batch * (cout / kColOcg)), dim3(512), 0, s, G, R, wcol, G2, A,
+                       zero_cols, cstride, rs, co, channels, cout, h, w, d_lo, count);
+    return check_launch("l0_column_fix");
+}
+
+// corr [nc][h][d_count][2] = {Ha - H at x = w-2, Hb - H at x = w-1} of disparity plane d (0 where the plane does not
+// read them), corr0 [nc][h] = H0 - H at x = 0 (only when d_begin == 0).  G / G2: row stride rs, column u + co.
+__global__ __launch_bounds__(512) void l1_column_terms_kernel(const float* __restrict__ G,
+                                                              const float* __restrict__ G2,
+                                                              const float* __restrict__ wcol,
+                                                              float* __restrict__ corr, float* __restrict__ corr0,
+                                                              size_t cstride, int rs, int co, int C, int cout, int h,
+                                                              int w, int d_begin, int d_count) {
+    __shared__ float red[kColSlices][2 * kColOcg][64];
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int groups = cout / kColOcg;
+    const int b = blockIdx.y / groups, ocg = blockIdx.y % groups;
+    const int item = blockIdx.x * 64 + lane;
+    const bool live = item < h * d_count;
+    const int y = live ? item / d_count : 0, dl = live ? item % d_count : 0, d = d_begin + dl;
+    const size_t wstep = (size_t)C * 3 * cout;
+    const float* w_m = wcol + ocg * kColOcg;   // dx = -1
+    const float* w_0 = w_m + wstep;            // dx = 0
+    const float* w_p = w_0 + wstep;            // dx = +1
+    const int per = (C + kColSlices - 1) / kColSlices;
+    const int ic_begin = slice * per, ic_end = (slice + 1) * per < C ? (slice + 1) * per : C;
+    float accA[kColOcg], accB[kColOcg];
+#pragma unroll
+    for (int k = 0; k < kColOcg; ++k) accA[k] = accB[k] = 0.f;
+    if (live && d == 0) {
+        for (int ic = ic_begin; ic < ic_end; ++ic) {
+            const float* g = G + (size_t)(b * C + ic) * cstride + (co - 1);   // u = -1
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                const float v = (yy >= 0 && yy < h) ? g[(size_t)yy * rs] : 0.f;
+                const float* wk = w_m + ((size_t)ic * 3 + dy) * cout;
+#pragma unroll
+                for (int k = 0; k < kColOcg; ++k) accA[k] = fmaf(-wk[k], v, accA[k]);
+            }
+        }
+    } else if (live) {
+        // u = w - 1 - d: D[u] lives at storage column u + co (valid for u >= -1, i.e. d <= w), G[u + 1] next to it
+        // (valid for d <= w + 1; d >= 1 keeps it inside the row)
+        const int u = w - 1 - d;
+        const bool has_d = u >= -1, has_g = u + 1 >= -1;
+        for (int ic = ic_begin; ic < ic_end; ++ic) {
+            const size_t base = (size_t)(b * C + ic) * cstride;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                const bool row_ok = yy >= 0 && yy < h;
+                const size_t off = base + (size_t)(row_ok ? yy : 0) * rs + co;
+                const float dv = (row_ok && has_d) ? G2[off + u] - G[off + u] : 0.f;
+                const float gn = (row_ok && has_g) ? G[off + u + 1] : 0.f;
+                const float* wk0 = w_0 + ((size_t)ic * 3 + dy) * cout;
+                const float* wkp = w_p + ((size_t)ic * 3 + dy) * cout;
+#pragma unroll
+                for (int k = 0; k < kColOcg; ++k) {
+                    accA[k] = fmaf(wkp[k], dv, accA[k]);
+                    accB[k] = fmaf(wk0[k], dv, fmaf(-wkp[k], gn, accB[k]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kColOcg; ++k) {
+        red[slice][k][lane] = accA[k];
+        red[slice][kColOcg + k][lane] = accB[k];
+    }
+    __syncthreads();
+    const int k = threadIdx.x >> 6;
+    float va = 0.f, vb = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < kColSlices; ++sl) {
+        va += red[sl][k][lane];
+        vb += red[sl][kColOcg + k][lane];
+    }
+    if (!live) return;
+    const size_t nc = (size_t)(b * cout + ocg * kColOcg + k);
+    if (d == 0) {
+        corr0[nc * h + y] = va;
+        va = vb = 0.f;
+    }
+    const bool a_used = d >= 1 && w >= 2 && d <= w;       // x = w - 2 exists and u = w - 2 - d >= -2
+    const bool b_used = d >= 1 && d <= w + 1;             // u = w - 1 - d >= -2
+    *reinterpret_cast<float2*>(corr + ((nc * h + y) * d_count + dl) * 2) =
+        make_float2(a_used ? va : 0.f, b_used ? vb : 0.f);
+}
+
+int launch_l1_column_terms(const float* G, const float* G2, const float* wcol, float* corr, float* corr0,
+                           size_t cstride, int rs, int co, int batch, int channels, int cout, int h, int w, int d_begin,
+                           int d_count, hipStream_t s) {
+    hipLaunchKernelGGL(l1_column_terms_kernel, dim3((h * d_count + 63) / 64, batch * (cout / kColOcg)), dim3(512), 0,
+                       s, G, G2, wcol, corr, corr0, cstride, rs, co, channels, cout, h, w, d_begin, d_count);
+    return check_launch("l1_column_terms");
+}
+
+// weight sets [2][Cout][C][3][3] = {W1, W1} and bias sets [2][Cout] = {b1, 0} of the two-plane launch (B, H)
+__global__ __launch_bounds__(256) void l1_weights2_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          float* __restrict__ w2, float* __restrict__ bias2, int cout,
+                                                          int C) {
+    const int total = cout * C * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * cout; i += gridDim.x * 256) bias2[i] = i < cout ? b1[i] : 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const float v = w1[i];
+        w2[i] = v;
+        w2[total + i] = v;
+    }
+}
+
+int launch_l1_weights2(const float* w1, const float* b1, float* w2, float* bias2, int cout, int channels,
+                       hipStream_t s) {
+    const int total = cout * channels * 9;
+    hipLaunchKernelGGL(l1_weights2_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w1, b1, w2, bias2, cout,
+                       channels);
+    return check_launch("l1_weights2");
+}
+
 // t1[n,o,d,y,x] = LeakyReLU(B + T_d) and partial sums (records [(n*C+o)*D + d][tile] x {sum, sumsq}).
 // One thread owns four consecutive x of one row for ALL disparity planes: B is loaded once; the four H values of a
 // thread, H[x - d] for its x, form a window that slides by one column per plane, the entering value being the
@@ -242,16 +467,20 @@ __device__ __forceinline__ float l1_row16_sum(float v) {
     return v;  // lane 15 of every 16-lane row holds the row's total
 }
 
-__global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict__ y4, float* __restrict__ t1,
+// COLS: y4 holds only the planes B and H ([n][C][2][h][w+2]); the special columns arrive as corrections to H
+// (l1_column_terms_kernel: corr [nc][h][d_count][2], corr0 [nc][h]).
+template <bool COLS>
+__global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict__ y4, const float* __restrict__ corr,
+                                                         const float* __restrict__ corr0, float* __restrict__ t1,
                                                          double* __restrict__ partials, int C, int h, int w,
                                                          int d_begin, int d_first, int d_launch, int d_count) {
-    // grid: x = tile over (y, x/4), y = n*C + o ; y4 [n][C][5][h][w+2]
+    // grid: x = tile over (y, x/4), y = n*C + o ; y4 [n][C][5 or 2][h][w+2]
     const int nc = blockIdx.y, tile = blockIdx.x, tiles = gridDim.x;
     const int W2 = w + 2;
     const size_t px = (size_t)h * w;
-    const float* Bp = y4 + (size_t)nc * kL1Planes * h * W2;
+    const float* Bp = y4 + (size_t)nc * (COLS ? 2 : kL1Planes) * h * W2;
     const float* Hp = Bp + (size_t)h * W2;
-    const float* Ha = Hp + (size_t)h * W2;
+    const float* Ha = Hp + (size_t)h * W2;   // planes 2..4 exist only without COLS
     const float* Hb = Ha + (size_t)h * W2;
     const float* H0 = Hb + (size_t)h * W2;
     __shared__ float red[kL1MaxPlanes][16][2];   // [plane][wave * 4 + DPP row]
@@ -278,7 +507,19 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
         const int d = d_begin + dl;
         float r[4], s = 0.f, q = 0.f;
         float tk[4] = {hw[0], hw[1], hw[2], hw[3]};
-        if (d == 0) {  // the image border is padding at zero disparity: its own H plane
+        if (COLS) {
+            if (d == 0) {  // the image border is padding at zero disparity: H0 differs from H at x = 0 only
+                if (active && xb == 0) tk[0] += corr0[(size_t)nc * h + y];
+            } else if (active && xb + 4 > w - 2) {
+                // the two right-most columns of the image: Ha / Hb = H + correction
+                const float2 cv = *reinterpret_cast<const float2*>(corr + (((size_t)nc * h + y) * d_count + dl) * 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = xb + k;
+                    if (x >= w - 2 && x < w) tk[k] += x == w - 2 ? cv.x : cv.y;
+                }
+            }
+        } else if (d == 0) {  // the image border is padding at zero disparity: its own H plane
 #pragma unroll
             for (int k = 0; k < 4; ++k) tk[k] = (active && xb + k < w) ? H0[row + xb + k + 2] : 0.f;
         } else {
@@ -359,12 +600,17 @@ int l1_combine_tiles(int h, int w) {
     return (int)((quads + 255) / 256);  // one quad per thread
 }
 
-int launch_l1_combine(const float* y4, float* t1, double* partials, int batch, int channels, int h, int w,
-                      int d_begin, int d_count, hipStream_t s) {
+int launch_l1_combine(const float* y4, const float* corr, const float* corr0, float* t1, double* partials,
+                      int batch, int channels, int h, int w, int d_begin, int d_count, hipStream_t s) {
     for (int first = 0; first < d_count; first += kL1MaxPlanes) {
         const int n = d_count - first < kL1MaxPlanes ? d_count - first : kL1MaxPlanes;
-        hipLaunchKernelGGL(l1_combine_kernel, dim3(l1_combine_tiles(h, w), batch * channels), dim3(256), 0, s, y4, t1,
-                           partials, channels, h, w, d_begin, first, n, d_count);
+        const dim3 grid(l1_combine_tiles(h, w), batch * channels);
+        if (corr)
+            hipLaunchKernelGGL(l1_combine_kernel<true>, grid, dim3(256), 0, s, y4, corr, corr0, t1, partials, channels, h,
+                               w, d_begin, first, n, d_count);
+        else
+            hipLaunchKernelGGL(l1_combine_kernel<false>, grid, dim3(256), 0, s, y4, corr, corr0, t1, partials, channels,
+                               h, w, d_begin, first, n, d_count);
     }
     return check_launch("l1_combine");
 }
