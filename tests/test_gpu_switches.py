@@ -18,6 +18,7 @@ SWITCHES = [
     {'PDS_CONV2D_PAIRS': '1'},      # 8-byte staging in the direct kernel
     {'PDS_CONV2D_KC8': '1'},        # 8-channel chunks in the single-block direct kernels
     {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
+    {'PDS_MATCHING_COLUMNS': '0'},  # whole-plane form of the layer-0 / layer-1 factorisation (3 + 5 planes)
     {'PDS_CONV3D_XCD_MAP': '0'},
     {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0', 'PDS_CONV3D_KS': '0'},   # generic MFMA kernels for all hourglass layers
     {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
