@@ -45,10 +45,6 @@ int conv2d_wino_tiles(const Geom& out_g);
 size_t conv2d_wino_packed_floats(int cin, int cout);
 int launch_conv2d_t8(const ConvLayer& L, hipStream_t s);          // conv2d_t8.hip (64 -> 8 channels, bare)
 bool conv2d_t8_supported(const ConvLayer& L);
-int launch_conv2d_wino2d(const ConvLayer& L, hipStream_t s);      // conv2d_wino2d.hip
-bool conv2d_wino2d_eligible(const ConvLayer& L);
-int conv2d_wino2d_tiles(const Geom& out_g);
-size_t conv2d_wino2d_packed_floats(int cin, int cout);
 int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma.hip
 bool conv3d_mfma_supported(const ConvLayer& L);
 int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
@@ -297,7 +293,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     // Winograd domain (plain single-source Cin -> 64 layers)
     int kind = 0;
     if (allow_mfma && !norm && !c.tape && conv2d_t8_supported(L)) kind = 8;   // persistent y-Toeplitz kernel, no packing
-    else if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino2d_eligible(L) ? 5 : conv2d_wino_eligible(L) ? 4 : 2;
+    else if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino_eligible(L) ? 4 : 2;
     else if (allow_mfma && conv3d_t8_supported(L)) kind = 6;   // persistent z-Toeplitz kernel, no weight packing
     else if (allow_mfma && conv3d_ks_supported(L)) kind = 7;   // inner levels: K split over the waves
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
@@ -305,17 +301,15 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 4)
         L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
-    if (kind == 5) L.packed = c.get<float>(conv2d_wino2d_packed_floats(in.c, cout));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
-    if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 5 && kind != 8) {
+    if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 8) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
     }
     auto launch = [&]() {
         return kind == 2 ? launch_conv2d_mfma(L, c.s)
                          : kind == 4 ? launch_conv2d_wino(L, c.s)
-                         : kind == 5 ? launch_conv2d_wino2d(L, c.s)
                                      : kind == 3 ? launch_conv3d_mfma(L, c.s)
                                                  : kind == 6 ? launch_conv3d_t8(L, c.s)
                                                              : kind == 7 ? launch_conv3d_ks(L, c.s)
@@ -327,7 +321,6 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
                                     : kind == 4 ? conv2d_wino_tiles(o.g)
-                                    : kind == 5 ? conv2d_wino2d_tiles(o.g)
                                     : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride)
                                     : kind == 6 ? conv3d_t8_records(o.g)
                                     : kind == 7 ? conv3d_ks_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
@@ -616,14 +609,20 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
                    &l0);
         return;
     }
-    float* cur = c.get<float>(g.numel());
+    // This walk is inference-only (no tape), so the [B, 64, D', h, w] activations rotate through THREE buffers (the
+    // most that are live at once: a block's input, its first and its second layer) instead of one per layer: t1's
+    // buffer is dead once t2 exists, t2's once the residual sum is formed.
+    float* cur = t1.raw;   // x1 = norm(t2) + x0 overwrites t1
     if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur, c.s));
+    float* spare_a = t2.raw;                        // free from here on
+    float* spare_b = c.get<float>(g.numel());
     for (int r = 1; r < P.residual_blocks; ++r) {
-        t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1);
-        t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1);
+        t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a);
+        t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1, spare_b);
         if (r + 1 < P.residual_blocks) {
-            float* nxt = c.get<float>(g.numel());
+            float* nxt = spare_a;                   // t1 is dead: x_{r+1} = norm(t2) + x_r goes there
             if (!c.plan) c.run(launch_materialize(t2.src(), plain_src(cur), g, nxt, c.s));
+            spare_a = cur;
             cur = nxt;
         }
     }

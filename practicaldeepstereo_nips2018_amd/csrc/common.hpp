@@ -1,6 +1,7 @@
 // Shared declarations of libpds_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
@@ -16,6 +17,17 @@ constexpr double kInEps = 1e-5;      // torch InstanceNorm default eps
 // ---- error reporting across the C ABI ------------------------------------------------
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+
+// Per-function attributes (hipFuncSetAttribute) are per DEVICE: a launcher keeps one bit per device in a
+// function-local static and applies the attribute the first time it runs on each device of the process.
+inline bool first_use_on_device(std::atomic<unsigned>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit);
+    return true;
+}
 
 #define PDS_REQUIRE(cond, ...)                       \
     do {                                             \

@@ -364,11 +364,10 @@ template <int MB, int SRC, bool PAIR = false, int KCT = KC>
 static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
     using C = Cfg<MB, KCT>;
     const size_t lds_bytes = (size_t)(2 * C::BUF) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC, PAIR, KCT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        attr_done = true;
     }
     dim3 grid(A.tiles, A.D, A.N);
     hipLaunchKernelGGL((conv2d_mfma_kernel<MB, SRC, PAIR, KCT>), grid, dim3(THREADS), lds_bytes, s, A);

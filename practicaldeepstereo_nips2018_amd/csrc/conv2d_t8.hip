@@ -311,12 +311,9 @@ template <bool TWO, bool NA, bool NB2>
 int launch_c2t8(const C2Args& A, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)(C2_AFRAGS * 64 + 2 * C2_BUF) * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_done.load() >> (dev & 31)) & 1u)) {
+    if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8_kernel<TWO, NA, NB2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        attr_done.fetch_or(1u << (dev & 31));
     }
     int wgs = 512;
     if (wgs > A.tiles) wgs = (A.tiles + 7) / 8 * 8;

@@ -397,8 +397,8 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
         const char* e = getenv("PDS_WINO_WAVES");
         return (e && e[0] == '4') ? 1 : 2;
     }();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    if (first_use_on_device(attr_done)) {
         const int bytes = (int)(160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -408,7 +408,6 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr_done = true;
     }
     const dim3 grid(A.tiles, A.D, A.N);
     if (halves == 2) {

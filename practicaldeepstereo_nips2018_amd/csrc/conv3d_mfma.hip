@@ -351,11 +351,10 @@ template <int MODE, int S, int MB, int TZ, int TY, int NB, int KC>
 int launch3(const Args3& A0, hipStream_t s) {
     using C = Cfg3<S, MB, TZ, TY, NB, KC>;
     Args3 A = A0;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        attr_done = true;
     }
     static const bool xcd_map = []() {  // PDS_CONV3D_XCD_MAP=0: launch order = tile order (A/B)
         const char* e = getenv("PDS_CONV3D_XCD_MAP");

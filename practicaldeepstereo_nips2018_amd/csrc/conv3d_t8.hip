@@ -376,12 +376,9 @@ int launch_t8(const T8Args& A, int batch, hipStream_t s) {
     using C = T8Cfg<NB>;
     constexpr size_t lds_bytes = (size_t)2 * C::LDS_FLOATS * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_done.load() >> (dev & 31)) & 1u)) {
+    if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_t8_kernel<NB, SRC, EXACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        attr_done.fetch_or(1u << (dev & 31));
     }
     hipLaunchKernelGGL((conv3d_t8_kernel<NB, SRC, EXACT>), dim3(A.records, batch), dim3(T8_THREADS), lds_bytes, s, A);
     return check_launch("conv3d_t8");

@@ -362,12 +362,9 @@ int launch_cell(const CellArgs& A, int batch, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)2 * C::LDS_FLOATS * sizeof(float);
     static_assert(lds_bytes >= (size_t)DC_THREADS * 8 * sizeof(double), "reduction scratch must fit");
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_done.load() >> (dev & 31)) & 1u)) {
+    if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        attr_done.fetch_or(1u << (dev & 31));
     }
     hipLaunchKernelGGL((deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM>), dim3(A.records, batch), dim3(DC_THREADS),
                        lds_bytes, s, A);

@@ -39,31 +39,6 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const int ks_n = J.kc / 4;
     const int ncls = J.mode == 1 ? 8 : (J.mode == 2 ? 4 : 1);  // modes 0 and 3: plain convolutions
     const int kdn = J.mode == 1 ? 4 : 3;
-    if (J.mode == 4) {
-        // F(2x2, 3x3) filter transform U = G g G^T in per-lane fragment order (conv2d_wino2d.hip):
-        // dst[chunk][ocb][lane][position], lane = (k = ic in chunk, i = oc in block)
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
-            const int pos = e & 15, lane = (e >> 4) & 63, ocb = (e >> 10) & 3, chunk = e >> 12;
-            const int v = ocb * 16 + (lane & 15), c = chunk * 4 + (lane >> 4);
-            float val = 0.f;
-            if (v < J.cout && c < J.cin) {
-                const float* g = J.src + ((size_t)v * J.cin + c) * 9;
-                const int py = pos >> 2, px = pos & 3;
-                double rowv[3];  // (G g)[py][b]
-                for (int b = 0; b < 3; ++b) {
-                    const double g0 = g[0 * 3 + b], g1 = g[1 * 3 + b], g2 = g[2 * 3 + b];
-                    rowv[b] = py == 0 ? g0 : py == 3 ? g2 : py == 1 ? 0.5 * (g0 + g1 + g2) : 0.5 * (g0 - g1 + g2);
-                }
-                const double u = px == 0 ? rowv[0]
-                                         : px == 3 ? rowv[2]
-                                                   : px == 1 ? 0.5 * (rowv[0] + rowv[1] + rowv[2])
-                                                             : 0.5 * (rowv[0] - rowv[1] + rowv[2]);
-                val = (float)u;
-            }
-            J.dst[e] = val;
-        }
-        return;
-    }
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
         const int i = r % 16;

@@ -13,7 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
     {'PDS_WINOGRAD': '0'},          # direct MFMA kernel for the 64-channel layers
-    {'PDS_WINO2D': '1'},            # 2-D Winograd kernel with role-specialised waves
     {'PDS_WINO_WAVES': '4'},        # 4-wave form of the F(2,3) kernel
     {'PDS_CONV2D_PAIRS': '1'},      # 8-byte staging in the direct kernel
     {'PDS_CONV2D_KC8': '1'},        # 8-channel chunks in the single-block direct kernels
