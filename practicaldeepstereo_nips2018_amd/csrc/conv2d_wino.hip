@@ -348,7 +348,16 @@ bool conv2d_wino_eligible(const ConvLayer& L) {
     return true;
 }
 
-int conv2d_wino_tiles(const Geom& o) { return ((o.h + TH - 1) / TH) * ((o.w + TWX - 1) / TWX); }
+// conv2d_wino16.hip: the 16 x 16-tile form of this kernel (same packed weights), preferred where it covers the plane
+// with fewer workgroups
+int conv2d_wino16_tiles(int h, int w);
+bool conv2d_wino16_preferred(int h, int w);
+int launch_conv2d_wino16(const ConvLayer& L, size_t w_set_stride, int bias_set_stride, hipStream_t s);
+
+int conv2d_wino_tiles(const Geom& o) {
+    if (conv2d_wino16_preferred(o.h, o.w)) return conv2d_wino16_tiles(o.h, o.w);
+    return ((o.h + TH - 1) / TH) * ((o.w + TWX - 1) / TWX);
+}
 
 size_t conv2d_wino_packed_floats(int cin, int cout) { return (size_t)(cin / KC) * W_CHUNK; }
 
@@ -375,6 +384,9 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
         if (phase == kPackCollect) return 0;
         if (int rc = launch_multi_pack(jobs, sets, s)) return rc;
     }
+    if (conv2d_wino16_preferred(L.in.h, L.in.w))
+        return launch_conv2d_wino16(L, L.plane_weight_sets > 0 ? (size_t)total : 0,
+                                    L.plane_weight_sets > 0 ? L.out_g.c : 0, s);
     WinoArgs A;
     A.a = L.a;
     A.wpk = L.packed;
