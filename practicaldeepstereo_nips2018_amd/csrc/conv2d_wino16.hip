@@ -117,34 +117,37 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino16_kernel(const Wino16A
     const float* wbase = A.wpk + (size_t)d * A.w_set_stride;
     const float* bias = A.bias ? A.bias + d * A.bias_set_stride : nullptr;
 
-    f32x4 vp;
-    float ve = 0.f, vs = 1.f, vh = 0.f;
-    f32x4 vw[W_ITERS];
+    // one register set (SETS = 2 with the request of chunk c + 3 issued two MFMA phases ahead was measured: no
+    // difference, 0.78 ms either way -- the loads are not what the loop waits for)
+    constexpr int SETS = 1;
+    f32x4 vp[SETS];
+    float ve[SETS] = {0.f}, vs[SETS] = {1.f}, vh[SETS] = {0.f};
+    f32x4 vw[SETS][W_ITERS];
 
-#define PDS_W16_FETCH(chunk_)                                                                        \
+#define PDS_W16_FETCH(chunk_, S)                                                                     \
     {                                                                                                \
         const float* src = pa + (size_t)(chunk_) * chunk_stride;          /* uniform */              \
         if (stager) {                                                                                \
-            vp = *reinterpret_cast<const f32x4*>(src + offp);                                        \
-            ve = src[offe];                                                                          \
+            vp[S] = *reinterpret_cast<const f32x4*>(src + offp);                                     \
+            ve[S] = src[offe];                                                                       \
             if (NORM) {                                                                              \
-                vs = ps[(size_t)(chunk_) * KC * gstride + goff];                                     \
-                vh = ph[(size_t)(chunk_) * KC * gstride + goff];                                     \
+                vs[S] = ps[(size_t)(chunk_) * KC * gstride + goff];                                  \
+                vh[S] = ph[(size_t)(chunk_) * KC * gstride + goff];                                  \
             }                                                                                        \
         }                                                                                            \
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(wbase + (size_t)(chunk_) * W_CHUNK);       \
         _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
-            vw[it] = wsrc[min(it * THREADS + tid, wlast)];                                            \
+            vw[S][it] = wsrc[min(it * THREADS + tid, wlast)];                                         \
     }
 
-#define PDS_W16_STASH(buf_)                                                                          \
+#define PDS_W16_STASH(buf_, S)                                                                       \
     {                                                                                                \
         if (stager) {                                                                                \
-            const float a0 = inx ? (NORM ? fmaf(vs, vp[0], vh) : vp[0]) : 0.f;                       \
-            const float a1 = inx ? (NORM ? fmaf(vs, vp[1], vh) : vp[1]) : 0.f;                       \
-            const float a2 = inx ? (NORM ? fmaf(vs, vp[2], vh) : vp[2]) : 0.f;                       \
-            const float a3 = inx ? (NORM ? fmaf(vs, vp[3], vh) : vp[3]) : 0.f;                       \
-            const float de = ine ? (NORM ? fmaf(vs, ve, vh) : ve) : 0.f;                             \
+            const float a0 = inx ? (NORM ? fmaf(vs[S], vp[S][0], vh[S]) : vp[S][0]) : 0.f;           \
+            const float a1 = inx ? (NORM ? fmaf(vs[S], vp[S][1], vh[S]) : vp[S][1]) : 0.f;           \
+            const float a2 = inx ? (NORM ? fmaf(vs[S], vp[S][2], vh[S]) : vp[S][2]) : 0.f;           \
+            const float a3 = inx ? (NORM ? fmaf(vs[S], vp[S][3], vh[S]) : vp[S][3]) : 0.f;           \
+            const float de = ine ? (NORM ? fmaf(vs[S], ve[S], vh[S]) : ve[S]) : 0.f;                 \
             const float up = lane_above(a3), dn = lane_below(a0);                                    \
             const float left = tp == 0 ? de : up;       /* x - 1 */                                  \
             const float right = tp == 3 ? de : dn;      /* x + 4 */                                  \
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino16_kernel(const Wino16A
         }                                                                                            \
         f32x4* wdst = reinterpret_cast<f32x4*>((buf_) + IN_CHUNK);                                   \
         _Pragma("unroll") for (int it = 0; it < W_ITERS; ++it)                                       \
-            wdst[min(it * THREADS + tid, wlast)] = vw[it];                                           \
+            wdst[min(it * THREADS + tid, wlast)] = vw[S][it];                                        \
     }
 
     f32x4 acc[4][MBW][NBT];
@@ -168,42 +171,42 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino16_kernel(const Wino16A
 #pragma unroll
             for (int j = 0; j < NBT; ++j) acc[p][m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // two chunks deep, as conv2d_wino.hip: chunk c + 1 is transformed into the idle buffer and chunk c + 2 is
-    // requested before the MFMAs of chunk c; chunks past the end re-stage the last one instead of branching
+    // Software pipeline, as conv2d_wino.hip: chunk c + 1 (requested one iteration ago) is transformed into the idle
+    // LDS buffer and chunk c + 2 is requested before the MFMAs of chunk c.  Chunks past the end re-stage the last one
+    // instead of branching.
     const int last_chunk = nchunks - 1;
-    PDS_W16_FETCH(0)
-    PDS_W16_STASH(lds)
-    PDS_W16_FETCH(min(1, last_chunk))
-    __syncthreads();
-
     const int nn = lane & 15;
     const int b_lane = (lane >> 4) * CS + (4 * wave + (nn >> 3)) * RSV + (nn & 7);
 
+#define PDS_W16_MFMAS(buf)                                                                           \
+    {                                                                                                \
+        const float* xin = (buf) + b_lane;                                                           \
+        const float* win = (buf) + IN_CHUNK + half * MBW * 64 + lane;                                \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) {                                           \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                          \
+                float af[MBW], bf[NBT];                                                              \
+                _Pragma("unroll") for (int m = 0; m < MBW; ++m) af[m] = win[((dy * 4 + p) * MB + m) * 64]; \
+                _Pragma("unroll") for (int j = 0; j < NBT; ++j) bf[j] = xin[(dy + 2 * j) * RSV + p * PS]; \
+                _Pragma("unroll") for (int m = 0; m < MBW; ++m)                                      \
+                    _Pragma("unroll") for (int j = 0; j < NBT; ++j)                                  \
+                        acc[p][m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[p][m][j], 0, 0, 0); \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    PDS_W16_FETCH(0, 0)
+    PDS_W16_STASH(lds, 0)
+    PDS_W16_FETCH(min(1, last_chunk), 0)
+    __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         float* buf = lds + (chunk & 1) * BUF;
         float* nxt = lds + ((chunk + 1) & 1) * BUF;
-        const float* xin = buf + b_lane;
-        const float* win = buf + IN_CHUNK + half * MBW * 64 + lane;
-        PDS_W16_STASH(nxt)                               // chunk + 1, fetched one iteration ago
-        PDS_W16_FETCH(min(chunk + 2, last_chunk))        // lands during the next iteration
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float af[MBW], bf[NBT];
-#pragma unroll
-                for (int m = 0; m < MBW; ++m) af[m] = win[((dy * 4 + p) * MB + m) * 64];
-#pragma unroll
-                for (int j = 0; j < NBT; ++j) bf[j] = xin[(dy + 2 * j) * RSV + p * PS];
-#pragma unroll
-                for (int m = 0; m < MBW; ++m)
-#pragma unroll
-                    for (int j = 0; j < NBT; ++j)
-                        acc[p][m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[j], acc[p][m][j], 0, 0, 0);
-            }
-        }
+        PDS_W16_STASH(nxt, 0)                               // chunk + 1, fetched one iteration ago
+        PDS_W16_FETCH(min(chunk + 2, last_chunk), 0)        // lands during the next iteration
+        PDS_W16_MFMAS(buf)
         __syncthreads();
     }
+#undef PDS_W16_MFMAS
 #undef PDS_W16_FETCH
 #undef PDS_W16_STASH
 

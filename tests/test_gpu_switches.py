@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {'PDS_WINOGRAD': '0'},          # direct MFMA kernel for the 64-channel layers
     {'PDS_WINO_WAVES': '4'},        # 4-wave form of the F(2,3) kernel
+    {'PDS_WINO_TILE16': '0'},       # wide (4 x 64) Winograd tiles everywhere
     {'PDS_CONV2D_PAIRS': '1'},      # 8-byte staging in the direct kernel
     {'PDS_CONV2D_KC8': '1'},        # 8-channel chunks in the single-block direct kernels
     {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
