@@ -905,6 +905,13 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             float* ws = c.get<float>(wgrad3d_mfma_scratch_floats(L.in_g, L.out_g));
             if (!c.plan)
                 c.run(launch_wgrad3d_mfma(sa, sb, dz, dweight, L.in_g, L.out_g, 0, ws, c.s));
+        } else if (wgrad_up_full_mfma_supported(L.type, L.kd, sb, L.in_g, L.out_g)) {
+            float* ws = c.get<float>(wgrad_up_full_mfma_scratch_floats(L.in_g));
+            if (!c.plan) c.run(launch_wgrad_up_full_mfma(sa, dz, dweight, L.in_g, 0, ws, c.s));
+        } else if (wgrad3d_s2_mfma_supported(L.type, L.kd, L.stride, L.in_g, L.out_g)) {
+            float* ws = c.get<float>(wgrad3d_s2_mfma_scratch_floats(L.type, L.in_g, L.out_g));
+            if (!c.plan)
+                c.run(launch_wgrad3d_s2_mfma(L.type, sa, sb, dz, dweight, L.in_g, L.out_g, 0, ws, c.s));
         } else {
             double* weight_scratch = c.get<double>(bwd_weight_scratch_doubles(L.type, L.kd, L.in_g, L.out_g));
             if (!c.plan)

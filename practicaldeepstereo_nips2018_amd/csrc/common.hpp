@@ -157,6 +157,16 @@ size_t bwd_weight_scratch_doubles(int transposed, int kd, const Geom& in, const 
 int launch_bwd_weight(int transposed, int kd, int stride, const Src& a, const Src& b, const float* dz, float* dw,
                       const Geom& in, const Geom& out, int accumulate, double* scratch, hipStream_t s);
 // MFMA weight gradient of the 2-D 3x3 convolutions (wgrad2d_mfma.hip)
+// wgrad3d_s2_mfma.hip: weight gradient of the full-resolution k(3,4,4) s(1,2,2) transposed convolution (Cout = 1)
+bool wgrad_up_full_mfma_supported(int transposed, int kd, const Src& b, const Geom& in, const Geom& out);
+size_t wgrad_up_full_mfma_scratch_floats(const Geom& in);
+int launch_wgrad_up_full_mfma(const Src& a, const float* dz, float* dw, const Geom& in, int accumulate, float* scratch,
+                              hipStream_t s);
+// wgrad3d_s2_mfma.hip: weight gradients of the stride-2 convolutions (kd 3) and the k4 s2 transposed convolutions
+bool wgrad3d_s2_mfma_supported(int transposed, int kd, int stride, const Geom& in, const Geom& out);
+size_t wgrad3d_s2_mfma_scratch_floats(int transposed, const Geom& in, const Geom& out);
+int launch_wgrad3d_s2_mfma(int transposed, const Src& a, const Src& b, const float* dz, float* dw, const Geom& in,
+                           const Geom& out, int accumulate, float* scratch, hipStream_t s);
 bool wgrad3d_mfma_supported(int transposed, int kd, int stride, const Geom& in, const Geom& out);  // wgrad3d_mfma.hip
 size_t wgrad3d_mfma_scratch_floats(const Geom& in, const Geom& out);
 int launch_wgrad3d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,

@@ -1,0 +1,385 @@
+// Weight gradients of the stride-2 layers of the hourglass on the fp32 MFMA units (reference regularization.py:28-31,
+// 54-57, 88-92 and network_blocks.py:37-44, 61-72 under loss.backward(), pds_trainer.py:40-46):
+//   convolution k3 s2 p1          dW[oc][c][k]  = sum_o dz[oc][o]  * xhat[c][2o - 1 + k]      (K = 3)
+//   transposed convolution k4 s2  dW[c][oc][k]  = sum_i xhat[c][i] * dz[oc][2i - 1 + k]       (K = 4)
+// Both are  R[s][b][k] = sum_p S[s][p] * B[b][2p - 1 + k]  per axis, with a "small-grid" tensor S (dz of the strided
+// convolution / the input of the transposed one) and a "big-grid" tensor B (the convolution's input / the transposed
+// convolution's dz); R is laid out exactly like the PyTorch weight of either layer.
+// GEMM view: M = 16 small-grid channels, N = 16 big-grid channels per tap (K^3 column blocks), K = positions, 4 at a time
+// with v_mfma_f32_16x16x4_f32.
+//   workgroup   one (small block, big block) channel pair (grid.y); the K^3 taps are split over the 4 waves; persistent
+//               over work items with the partial R in registers, ONE partial per workgroup (summed by
+//               wgrad_reduce_f32_kernel, wgrad2d_mfma.hip).
+//   work item   a 32-position x-segment of one (n, z, y) row of the small grid.
+//   LDS         S tile [16 ch][32]; B tile [16 ch][K x K rows][odd columns | even columns]: the stride-2 read
+//               B[2p - 1 + kx] becomes a unit-stride read of the odd (kx = 0, 2) or even (kx = 1, 3) half, so both
+//               fragment reads are bank-conflict free (channel strides == 2 mod 32).  The deferred InstanceNorm, the skip
+//               sum (possibly broadcast along D, regularization.py:115) and the zero padding are applied while staging.
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int TWG = 32;           // small-grid positions per work item
+constexpr int HS = 34;            // floats per parity half of a big row (33 used)
+constexpr int RS = 2 * HS;        // big row stride
+constexpr int DS = 34;            // small row stride, == 2 (mod 32)
+constexpr int BCOLS = 2 * TWG + 2;  // big columns staged per row: 2 x0 - 1 .. 2 x0 + 64
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+struct Cfg {
+    static constexpr int ROWS = K * K;
+    static constexpr int RAW = ROWS * RS;
+    static constexpr int XS = RAW + ((2 - RAW % 32) + 32) % 32;   // channel stride == 2 (mod 32)
+    static constexpr int TAPS = K * K * K;
+    static constexpr int TPW = (TAPS + 3) / 4;                    // taps per wave
+    static_assert(XS % 32 == 2, "bank layout");
+};
+static_assert(DS % 32 == 2, "bank layout");
+
+struct WS2Args {
+    Src a, b;                      // the normalised tensor (the layer's input)
+    const float* __restrict__ dz;  // the plain one (gradient of the layer's raw output)
+    float* __restrict__ partial;   // [workgroup][Cs][Cb][K^3]
+    int N, Cs, Cb;
+    int Ds, Hs, Ws;                // small grid
+    int Db, Hb, Wb;                // big grid
+    int items, segs, sblocks;
+};
+
+// value of the layer's (normalised, summed) input at an in-range position
+__device__ __forceinline__ float xhat_value(const Src& a, const Src& b, int n, int C, int c, int D, int H, int W, int z,
+                                            int y, int x) {
+    const size_t plane = (size_t)H * W, inplane = (size_t)y * W + x;
+    const int g = n * C + c;
+    float sa = 1.f, ha = 0.f;
+    if (a.scale) {
+        sa = a.scale[g];
+        ha = a.shift[g];
+    }
+    float v = fmaf(sa, a.p[((size_t)g * D + z) * plane + inplane], ha);
+    if (b.p) {
+        float sb = 1.f, hb = 0.f;
+        if (b.scale) {
+            sb = b.scale[g];
+            hb = b.shift[g];
+        }
+        v += fmaf(sb, b.p[(b.bcast_d ? (size_t)g : (size_t)g * D + z) * plane + inplane], hb);
+    }
+    return v;
+}
+
+}  // namespace
+
+// SMALL_NORM: the small-grid tensor is the normalised one (transposed convolution); otherwise the big-grid one is
+template <int K, bool SMALL_NORM>
+__global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args A) {
+    using C = Cfg<K>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bl = smem;                 // [16][XS]
+    float* sl = smem + 16 * C::XS;    // [16][DS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sb = blockIdx.y % A.sblocks, bb = blockIdx.y / A.sblocks;
+    const int s0 = sb * 16, b0 = bb * 16;
+    const size_t plane_s = (size_t)A.Hs * A.Ws, vol_s = (size_t)A.Ds * plane_s;
+    const size_t plane_b = (size_t)A.Hb * A.Wb, vol_b = (size_t)A.Db * plane_b;
+
+    // tap -> LDS offset of its B fragment row (wave-uniform): row (kz, ky), parity half and shift of kx
+    int toff[C::TPW];
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+        const int tap = min(wave + 4 * i, C::TAPS - 1);
+        const int rr = tap / K, kx = tap % K;
+        toff[i] = rr * RS + ((kx & 1) ? HS : 0) + ((kx + 1) >> 1) - ((kx & 1) ? 1 : 0);
+    }
+    // kx = 0: odd[j], 1: even[j], 2: odd[j + 1], 3: even[j + 1]   (odd[j] = B[2(x0+j) - 1], even[j] = B[2(x0+j)])
+
+    f32x4 acc[C::TPW];
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // channel rows beyond the tensors' channel counts are zeroed once and never staged (few-channel layers: 8 -> 4)
+    const int nb = min(16, A.Cb - b0), ns = min(16, A.Cs - s0);
+    for (int e = tid; e < 16 * C::XS + 16 * DS; e += THREADS) smem[e] = 0.f;
+    __syncthreads();
+
+    for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
+        int r = item;
+        const int seg = r % A.segs;
+        r /= A.segs;
+        const int y = r % A.Hs;
+        r /= A.Hs;
+        const int z = r % A.Ds;
+        const int n = r / A.Ds;
+        const int x0 = seg * TWG;
+
+        // ---- stage the big tile: 16 channels x K*K rows x 66 columns (2 x0 - 1 .. 2 x0 + 64), split by column parity
+        for (int c = 0; c < nb; ++c) {
+            const int ch = b0 + c;
+            for (int e = tid; e < C::ROWS * BCOLS; e += THREADS) {
+                const int rr = e / BCOLS, xx = e - rr * BCOLS;
+                const int zz = 2 * z - 1 + rr / K, yy = 2 * y - 1 + rr % K, x = 2 * x0 - 1 + xx;
+                float v = 0.f;
+                if (zz >= 0 && zz < A.Db && yy >= 0 && yy < A.Hb && x >= 0 && x < A.Wb) {
+                    if (SMALL_NORM)
+                        v = A.dz[((size_t)(n * A.Cb + ch)) * vol_b + (size_t)zz * plane_b + (size_t)yy * A.Wb + x];
+                    else
+                        v = xhat_value(A.a, A.b, n, A.Cb, ch, A.Db, A.Hb, A.Wb, zz, yy, x);
+                }
+                bl[c * C::XS + rr * RS + (xx & 1) * HS + (xx >> 1)] = v;
+            }
+        }
+        // ---- stage the small tile: 16 channels x 32 positions ------------------------------------------------
+        for (int e = tid; e < ns * TWG; e += THREADS) {
+            const int o = e / TWG, px = e - o * TWG;
+            const int x = x0 + px, ch = s0 + o;
+            float v = 0.f;
+            if (x < A.Ws) {
+                if (SMALL_NORM)
+                    v = xhat_value(A.a, A.b, n, A.Cs, ch, A.Ds, A.Hs, A.Ws, z, y, x);
+                else
+                    v = A.dz[((size_t)(n * A.Cs + ch)) * vol_s + (size_t)z * plane_s + (size_t)y * A.Ws + x];
+            }
+            sl[o * DS + px] = v;
+        }
+        __syncthreads();
+
+        const float* arow = sl + (lane & 15) * DS + (lane >> 4);
+        const float* brow = bl + (lane & 15) * C::XS + (lane >> 4);
+#pragma unroll 2
+        for (int ks = 0; ks < TWG / 4; ++ks) {
+            const float af = arow[ks * 4];
+#pragma unroll
+            for (int i = 0; i < C::TPW; ++i) {
+                if (wave + 4 * i < C::TAPS) {   // wave-uniform
+                    const float bf = brow[toff[i] + ks * 4];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one partial per workgroup: [Cs][Cb][K^3] ------------------------------------------------------------
+    float* dst = A.partial + (size_t)blockIdx.x * A.Cs * A.Cb * C::TAPS;
+    const int bc = b0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < C::TPW; ++i) {
+        const int tap = wave + 4 * i;
+        if (tap >= C::TAPS) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int scn = s0 + 4 * (lane >> 4) + rr;
+            if (scn < A.Cs && bc < A.Cb) dst[((size_t)scn * A.Cb + bc) * C::TAPS + tap] = acc[i][rr];
+        }
+    }
+}
+
+int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, float* dw, int accumulate, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the full-resolution transposed convolution k(3,4,4) s(1,2,2) p1, Cin <= 5 -> Cout = 1 (reference
+// regularization.py:90-92, network_blocks.py:124-131):
+//   dW[c][0][kd][kh][kw] = sum_{oz, iy, ix} xhat[c][oz + 1 - kd][iy][ix] * dz[oz][2 iy - 1 + kh][2 ix - 1 + kw]
+// With one output channel the channel-pair tiling above would use 4 x 1 of a 16 x 16 MFMA block, so the TAPS go on the
+// matrix sides instead: M = (c, kd) (12 of 16 rows for 4 channels), N = (kh, kw) (all 16 columns), K = positions along x:
+// ONE MFMA per four positions yields all 48 taps of all channels.  Every wave works alone (wave-private LDS tiles, no
+// workgroup barrier) on items (n, oz, iy, 32-position x segment) and keeps one partial in registers.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int UF_HS = 36, UF_RS = 2 * UF_HS;   // dz rows: parity halves 36 apart, rows 72 apart: banks 8 kh + 4 (kw & 1) + 0..2
+constexpr int UF_WAVE_FLOATS = 16 * DS + 4 * UF_RS;
+struct UFArgs {
+    Src a;
+    const float* __restrict__ dz;
+    float* __restrict__ partial;   // [wave][Cin][48]
+    int N, Cin, Di, Hi, Wi;        // input grid; output grid is (Di, 2 Hi, 2 Wi)
+    int items, segs;
+};
+}  // namespace
+
+__global__ __launch_bounds__(256) void wgrad_up_full_mfma_kernel(const UFArgs A) {
+    __shared__ __attribute__((aligned(16))) float smem_uf[4 * UF_WAVE_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sl = smem_uf + wave * UF_WAVE_FLOATS;   // [16 rows m = c * 4 + kd][DS]
+    float* bl = sl + 16 * DS;                      // [4 kh][odd | even][UF_HS]
+    const int Ho = 2 * A.Hi, Wo = 2 * A.Wi;
+    const size_t plane_i = (size_t)A.Hi * A.Wi, plane_o = (size_t)Ho * Wo;
+    for (int e = lane; e < UF_WAVE_FLOATS; e += 64) sl[e] = 0.f;   // rows kd = 3 and c >= Cin stay zero
+
+    const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nn = lane & 15;
+    const float* arow = sl + nn * DS + (lane >> 4);
+    const float* brow = bl + (nn >> 2) * UF_RS + (nn & 1) * UF_HS + ((nn & 3) >> 1) + (lane >> 4);
+    for (int item = gwave; item < A.items; item += nwaves) {
+        int r = item;
+        const int seg = r % A.segs;
+        r /= A.segs;
+        const int iy = r % A.Hi;
+        r /= A.Hi;
+        const int oz = r % A.Di;
+        const int n = r / A.Di;
+        const int x0 = seg * TWG;
+        // dz rows 2 iy - 1 .. 2 iy + 2, columns 2 x0 - 1 .. 2 x0 + 64, split by column parity
+        const float* pz = A.dz + ((size_t)n * A.Di + oz) * plane_o;
+        for (int e = lane; e < 4 * BCOLS; e += 64) {
+            const int kh = e / BCOLS, xx = e - kh * BCOLS;
+            const int oy = 2 * iy - 1 + kh, ox = 2 * x0 - 1 + xx;
+            float v = 0.f;
+            if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) v = pz[(size_t)oy * Wo + ox];
+            bl[kh * UF_RS + (xx & 1) * UF_HS + (xx >> 1)] = v;
+        }
+        // xhat rows (c, kd): plane oz + 1 - kd of channel c
+        for (int e = lane; e < A.Cin * 3 * TWG; e += 64) {
+            const int px = e % TWG, ck = e / TWG;
+            const int c = ck / 3, kd = ck - c * 3;
+            const int iz = oz + 1 - kd, ix = x0 + px;
+            float v = 0.f;
+            if (iz >= 0 && iz < A.Di && ix < A.Wi) {
+                const int g = n * A.Cin + c;
+                const float sa = A.a.scale ? A.a.scale[g] : 1.f, ha = A.a.scale ? A.a.shift[g] : 0.f;
+                v = fmaf(sa, A.a.p[((size_t)g * A.Di + iz) * plane_i + (size_t)iy * A.Wi + ix], ha);
+            }
+            sl[(c * 4 + kd) * DS + px] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ks = 0; ks < TWG / 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[ks * 4], brow[ks * 4], acc, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // D[m = 4 * (lane >> 4) + r][n = lane & 15]: m = c * 4 + kd, n = kh * 4 + kw
+    float* dst = A.partial + (size_t)gwave * A.Cin * 48;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int m = 4 * (lane >> 4) + rr;
+        const int c = m >> 2, kd = m & 3;
+        if (c < A.Cin && kd < 3) dst[c * 48 + kd * 16 + nn] = acc[rr];
+    }
+}
+
+static int up_full_workgroups(const Geom& in) {
+    const size_t items = (size_t)in.n * in.d * in.h * ((in.w + TWG - 1) / TWG);
+    size_t wgs = items / 16;
+    if (wgs > 1024) wgs = 1024;
+    return wgs < 1 ? 1 : (int)wgs;
+}
+
+bool wgrad_up_full_mfma_supported(int transposed, int kd, const Src& b, const Geom& in, const Geom& out) {
+    static const bool enabled = []() {
+        const char* e = getenv("PDS_WGRAD3D_S2_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && transposed && kd == 3 && !b.p && in.c <= 4 && out.c == 1 && out.d == in.d && out.h == 2 * in.h &&
+           out.w == 2 * in.w;
+}
+
+size_t wgrad_up_full_mfma_scratch_floats(const Geom& in) { return (size_t)up_full_workgroups(in) * 4 * in.c * 48; }
+
+
+// type: 0 convolution (kd 3, stride 2), 1 transposed convolution (kd 4: k4 s2 p1 on all three axes)
+bool wgrad3d_s2_mfma_supported(int transposed, int kd, int stride, const Geom& in, const Geom& out) {
+    static const bool enabled = []() {  // PDS_WGRAD3D_S2_MFMA=0 selects the VALU kernels (A/B, debugging)
+        const char* e = getenv("PDS_WGRAD3D_S2_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return false;
+    if (transposed) return kd == 4 && out.d == 2 * in.d && out.h == 2 * in.h && out.w == 2 * in.w;
+    return kd == 3 && stride == 2 && out.d == (in.d - 1) / 2 + 1 && out.h == (in.h - 1) / 2 + 1 &&
+           out.w == (in.w - 1) / 2 + 1;
+}
+
+static void s2_roles(int transposed, const Geom& in, const Geom& out, Geom& small, Geom& big) {
+    small = transposed ? in : out;
+    big = transposed ? out : in;
+}
+
+static int wgrad3d_s2_workgroups(const Geom& small, int pairs) {
+    const size_t items = (size_t)small.n * small.d * small.h * ((small.w + TWG - 1) / TWG);
+    size_t wgs = items / 4;                       // >= ~4 items per workgroup so the partial write amortises
+    const size_t cap = (size_t)(2048 / pairs) > 0 ? (size_t)(2048 / pairs) : 1;
+    if (wgs > cap) wgs = cap;
+    return wgs < 1 ? 1 : (int)wgs;
+}
+
+size_t wgrad3d_s2_mfma_scratch_floats(int transposed, const Geom& in, const Geom& out) {
+    Geom small, big;
+    s2_roles(transposed, in, out, small, big);
+    const int pairs = ((small.c + 15) / 16) * ((big.c + 15) / 16);
+    const int taps = transposed ? 64 : 27;
+    return (size_t)wgrad3d_s2_workgroups(small, pairs) * small.c * big.c * taps;
+}
+
+int launch_wgrad3d_s2_mfma(int transposed, const Src& a, const Src& b, const float* dz, float* dw, const Geom& in,
+                           const Geom& out, int accumulate, float* scratch, hipStream_t s) {
+    Geom small, big;
+    s2_roles(transposed, in, out, small, big);
+    WS2Args A;
+    A.a = a;
+    A.b = b;
+    A.dz = dz;
+    A.partial = scratch;
+    A.N = in.n;
+    A.Cs = small.c;
+    A.Cb = big.c;
+    A.Ds = small.d;
+    A.Hs = small.h;
+    A.Ws = small.w;
+    A.Db = big.d;
+    A.Hb = big.h;
+    A.Wb = big.w;
+    A.segs = (small.w + TWG - 1) / TWG;
+    A.items = small.n * small.d * small.h * A.segs;
+    A.sblocks = (small.c + 15) / 16;
+    const int pairs = A.sblocks * ((big.c + 15) / 16);
+    const int wgs = wgrad3d_s2_workgroups(small, pairs);
+    const int taps = transposed ? 64 : 27;
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    if (first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<3, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    }
+    if (transposed) {
+        const size_t lds = (size_t)(16 * Cfg<4>::XS + 16 * DS) * sizeof(float);
+        hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<4, true>), dim3(wgs, pairs), dim3(THREADS), lds, s, A);
+    } else {
+        const size_t lds = (size_t)(16 * Cfg<3>::XS + 16 * DS) * sizeof(float);
+        hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<3, false>), dim3(wgs, pairs), dim3(THREADS), lds, s, A);
+    }
+    if (int rc = check_launch("wgrad3d_s2_mfma")) return rc;
+    return launch_wgrad_reduce_f32(scratch, (size_t)small.c * big.c * taps, wgs, dw, accumulate, s);
+}
+
+int launch_wgrad_up_full_mfma(const Src& a, const float* dz, float* dw, const Geom& in, int accumulate, float* scratch,
+                              hipStream_t s) {
+    UFArgs A;
+    A.a = a;
+    A.dz = dz;
+    A.partial = scratch;
+    A.N = in.n;
+    A.Cin = in.c;
+    A.Di = in.d;
+    A.Hi = in.h;
+    A.Wi = in.w;
+    A.segs = (in.w + TWG - 1) / TWG;
+    A.items = in.n * in.d * in.h * A.segs;
+    const int wgs = up_full_workgroups(in);
+    hipLaunchKernelGGL(wgrad_up_full_mfma_kernel, dim3(wgs), dim3(256), 0, s, A);
+    if (int rc = check_launch("wgrad_up_full_mfma")) return rc;
+    return launch_wgrad_reduce_f32(scratch, (size_t)in.c * 48, wgs * 4, dw, accumulate, s);
+}
+
+}  // namespace pds
