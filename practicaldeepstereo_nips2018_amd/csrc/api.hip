@@ -246,6 +246,7 @@ struct ConvExtra {
     const float* l0G2 = nullptr;
     size_t l0_cstride = 0;
     int l0_rs = 0;
+    int out_batch_channels = 0;   // Winograd kernels only: write a channel slice of a wider tensor
     int d_begin = 0;
     float* side_out = nullptr;
     int plane_weight_sets = 0;
@@ -285,6 +286,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.l0G2 = extra->l0G2;
         L.l0_cstride = extra->l0_cstride;
         L.l0_rs = extra->l0_rs;
+        L.out_batch_channels = extra->out_batch_channels;
         L.d_begin = extra->d_begin;
         L.side_out = extra->side_out;
         L.plane_weight_sets = extra->plane_weight_sets;
@@ -303,6 +305,10 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
+    if (L.out_batch_channels && kind != 4) {
+        c.run(set_error(-1, "conv_block: a channel-slice output needs the Winograd kernel"));
+        return o;
+    }
     if (extra && extra->matching_extras() && kind != 2 && kind != 4 && kind != 8) {
         c.run(set_error(-1, "conv_block: fused Matching extras need the conv2d MFMA kernel"));
         return o;
@@ -932,15 +938,28 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
                 // covers that as one launch, so it is cut into 64-channel blocks per batch entry, each of which
                 // runs on the 64-channel (Winograd) kernel instead of the VALU fallback
                 const size_t vol = (size_t)L.in_g.d * L.in_g.h * L.in_g.w;
-                Geom one = L.out_g;
-                one.n = 1;
-                for (int i = 0; i < L.in_g.n; ++i)
+                if (L.in_g.w % 2 == 0 && L.out_g.c % 4 == 0) {
+                    // Winograd kernels: one launch per 64-channel block over the whole batch, written as a channel
+                    // slice of dx (the planes of the training-mode Matching are batch entries: 96 one-plane launches
+                    // that each filled a quarter of the chip became 2)
                     for (int j = 0; j < L.in_g.c / 64; ++j) {
                         PdsConvBlockParams pf{wf + (size_t)j * 64 * L.out_g.c * taps, nullptr, nullptr, nullptr};
-                        float* block = dx ? dx + ((size_t)i * L.in_g.c + (size_t)j * 64) * vol : nullptr;
-                        conv_block(c, plain_src(dz ? dz + (size_t)i * L.out_g.c * vol : nullptr), no_src(), one, pf, 64,
-                                   1, 1, 0, block);
+                        ConvExtra slice;
+                        slice.out_batch_channels = L.in_g.c;
+                        conv_block(c, plain_src(dz), no_src(), L.out_g, pf, 64, 1, 1, 0,
+                                   dx ? dx + (size_t)j * 64 * vol : nullptr, true, nullptr, nullptr, &slice);
                     }
+                } else {
+                    Geom one = L.out_g;
+                    one.n = 1;
+                    for (int i = 0; i < L.in_g.n; ++i)
+                        for (int j = 0; j < L.in_g.c / 64; ++j) {
+                            PdsConvBlockParams pf{wf + (size_t)j * 64 * L.out_g.c * taps, nullptr, nullptr, nullptr};
+                            float* block = dx ? dx + ((size_t)i * L.in_g.c + (size_t)j * 64) * vol : nullptr;
+                            conv_block(c, plain_src(dz ? dz + (size_t)i * L.out_g.c * vol : nullptr), no_src(), one, pf,
+                                       64, 1, 1, 0, block);
+                        }
+                }
             } else {
                 PdsConvBlockParams pf{wf, nullptr, nullptr, nullptr};
                 conv_block(c, plain_src(dz), no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);

@@ -110,6 +110,9 @@ struct ConvLayer {
     const float* l0G2 = nullptr;
     size_t l0_cstride = 0;
     int l0_rs = 0;
+    // conv2d Winograd kernels only: the output tensor has this many channels per batch entry (0: out_g.c) -- the launch
+    // writes a 64-channel slice of a wider tensor (data gradients of layers with more than 64 input channels)
+    int out_batch_channels = 0;
     int d_begin = 0;
     float* side_out = nullptr;
     // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)

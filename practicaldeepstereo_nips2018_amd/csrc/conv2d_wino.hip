@@ -71,6 +71,7 @@ struct WinoArgs {
     float* __restrict__ out;
     double* __restrict__ partials;
     int N, Cin, D, H, W, Cout;
+    int CoutStride;                  // channels per batch entry of the output tensor (>= Cout)
     int lrelu;
     int tiles_x, tiles;
     size_t w_set_stride;             // floats between the packed weight sets of consecutive planes (0: shared)
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
         for (int r = 0; r < 4; ++r) {
             const int oc = (half * MBW + m) * 16 + q * 4 + r;
             const float bv = bias ? bias[oc] : 0.f;
-            float* po = A.out + (((size_t)n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W;
+            float* po = A.out + (((size_t)n * A.CoutStride + oc) * A.D + d) * plane + (size_t)y * A.W;
             float s = 0.f, sq = 0.f;
 #pragma unroll
             for (int j = 0; j < NBT; ++j) {
@@ -399,6 +400,7 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     A.H = L.in.h;
     A.W = L.in.w;
     A.Cout = L.out_g.c;
+    A.CoutStride = L.out_batch_channels > 0 ? L.out_batch_channels : L.out_g.c;
     A.lrelu = L.lrelu;
     A.tiles_x = (A.W + TWX - 1) / TWX;
     A.tiles = conv2d_wino_tiles(L.out_g);

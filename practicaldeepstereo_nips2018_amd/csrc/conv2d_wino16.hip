@@ -45,6 +45,7 @@ struct Wino16Args {
     float* __restrict__ out;
     double* __restrict__ partials;
     int N, Cin, D, H, W, Cout;
+    int CoutStride;                  // channels per batch entry of the output tensor (>= Cout)
     int lrelu;
     int tiles_x, tiles;
     size_t w_set_stride;             // floats between the packed weight sets of consecutive planes (0: shared)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_wino16_kernel(const Wino16A
         for (int r = 0; r < 4; ++r) {
             const int oc = (half * MBW + m) * 16 + q * 4 + r;
             const float bv = bias ? bias[oc] : 0.f;
-            float* po = A.out + (((size_t)n * A.Cout + oc) * A.D + d) * plane;
+            float* po = A.out + (((size_t)n * A.CoutStride + oc) * A.D + d) * plane;
             float s = 0.f, sq = 0.f;
 #pragma unroll
             for (int j = 0; j < NBT; ++j) {
@@ -289,6 +290,7 @@ int launch_conv2d_wino16(const ConvLayer& L, size_t w_set_stride, int bias_set_s
     A.H = L.in.h;
     A.W = L.in.w;
     A.Cout = L.out_g.c;
+    A.CoutStride = L.out_batch_channels > 0 ? L.out_batch_channels : L.out_g.c;
     A.lrelu = L.lrelu;
     A.tiles_x = (A.W + TWX - 1) / TWX;
     A.tiles = conv2d_wino16_tiles(A.H, A.W);
