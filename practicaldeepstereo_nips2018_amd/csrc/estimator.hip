@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void subpixel_map_kernel(const float* __restri
         for (int t = 0; t < 2 * T + 1; ++t) win[v][t] = -INFINITY;
     }
 
-#pragma unroll 4
+#pragma unroll 8
     for (int k = 0; k < planes + T; ++k) {  // + T flush steps
         float x[VEC];
         if (k < planes) {
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void subpixel_map_kernel(const float* __restri
                 x[1] = q.y;
                 x[2] = q.z;
                 x[3] = q.w;
+            } else if constexpr (VEC == 2) {
+                const float2 q = *reinterpret_cast<const float2*>(src + (size_t)k * plane_px);
+                x[0] = q.x;
+                x[1] = q.y;
             } else {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) x[v] = src[(size_t)k * plane_px + v];
@@ -99,6 +103,8 @@ __global__ __launch_bounds__(256) void subpixel_map_kernel(const float* __restri
     float* dst = disp + b * plane_px + p0;
     if constexpr (VEC == 4) {
         *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2*>(dst) = make_float2(res[0], res[1]);
     } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) dst[v] = res[v];
@@ -137,9 +143,20 @@ __global__ __launch_bounds__(256) void subpixel_map_wide_kernel(const float* __r
 template <int T>
 static void launch_t(const float* sim, float* disp, int batch, int planes, size_t px, int lo, int hi, int step,
                      hipStream_t s) {
-    if (px % 4 == 0) {
+    // pixels per lane: 16-byte loads are the widest, but the sweep is a chain of dependent steps per lane, so what fills
+    // the memory pipes is the number of waves: two pixels per lane (8-byte loads, twice the waves) measured fastest
+    // (PDS_SUBPIXEL_VEC=1|2|4 selects another width for A/B)
+    static const int vec_pref = []() {
+        const char* e = getenv("PDS_SUBPIXEL_VEC");
+        return e ? atoi(e) : 2;
+    }();
+    if (px % 4 == 0 && vec_pref == 4) {
         dim3 grid((unsigned)((px / 4 + 255) / 256), batch);
         hipLaunchKernelGGL((subpixel_map_kernel<T, 4>), grid, dim3(256), 0, s, sim, disp, planes, px, lo, hi,
+                           (float)step);
+    } else if (px % 2 == 0 && vec_pref >= 2) {
+        dim3 grid((unsigned)((px / 2 + 255) / 256), batch);
+        hipLaunchKernelGGL((subpixel_map_kernel<T, 2>), grid, dim3(256), 0, s, sim, disp, planes, px, lo, hi,
                            (float)step);
     } else {
         dim3 grid((unsigned)((px + 255) / 256), batch);

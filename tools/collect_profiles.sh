@@ -4,6 +4,7 @@
 #   kernels_3streams.txt the default bench schedule (three streams)
 #   pmc.txt             PMC counters (separate passes, FETCH_SIZE / WRITE_SIZE apart) of every kernel of the hot path
 #   bench_line.json     the default bench.py line
+#   train_step_kernels.txt  kernel summary of the full-size training step (tools/train_step_bench.py)
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_r02
 rm -rf $OUT; mkdir -p $OUT
@@ -23,5 +24,8 @@ done
 python tools/pmc_summary.py $OUT > $OUT/pmc.txt 2>&1
 python bench.py > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/bench_line.json
-rm -rf $OUT/trace_seq $OUT/trace_pipe $OUT/pmc_[0-9]   # raw databases stay on the box
+python tools/train_step_bench.py > $OUT/train_step.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace_train -- python tools/train_step_bench.py > $OUT/train_prof.log 2>&1
+python tools/prof_summary.py $OUT/trace_train $OUT/train_step_kernels.txt "tools/train_step_bench.py: 3 full-size training steps (960x540, D=192, one GPU, SubpixelCrossEntropy); un-profiled timing: $(tail -1 $OUT/train_step.log)" > /dev/null 2>&1
+rm -rf $OUT/trace_seq $OUT/trace_pipe $OUT/trace_train $OUT/pmc_[0-9]   # raw databases stay on the box
 ls -la $OUT
