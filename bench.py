@@ -71,9 +71,11 @@ def conv64_hbm_traffic():
                        rec['algorithmic_bytes'] / 1e6))
 
 
-# The layer runs in the Winograd domain (csrc/conv2d_wino.hip, F(2,3) along x): 2/3 of the multiplies of the direct
-# form, over 64-column tiles (256 columns computed for 240)
-CONV64_EXECUTED_GFLOP = CONV64_GFLOP * (2.0 / 3.0) * (256.0 / 240.0)
+# The layer runs in the Winograd domain (F(2,3) along x): 2/3 of the multiplies of the direct form.  Default:
+# csrc/conv2d_wino16.hip, 16 x 16-pixel tiles that cover 144 x 240 exactly; PDS_WINO_TILE16=0: csrc/conv2d_wino.hip,
+# 4 x 64 tiles (256 columns computed for 240)
+CONV64_EXECUTED_GFLOP = CONV64_GFLOP * (2.0 / 3.0) * (
+    256.0 / 240.0 if os.environ.get('PDS_WINO_TILE16', '1')[:1] == '0' else 1.0)
 
 
 def parse():
@@ -488,9 +490,9 @@ def main():
                             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                             'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_source,
                             'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP,
-                            'algorithm': 'Winograd F(2,3) along x on the fp32 MFMA units: "achieved" counts the '
-                                         'ALGORITHMIC flops of the direct convolution; the MFMA pipe executes '
-                                         'executed_gflop_per_launch',
+                            'algorithm': 'Winograd F(2,3) along x on the fp32 MFMA units (16x16-pixel tiles): "achieved" '
+                                         'counts the ALGORITHMIC flops of the direct convolution; the MFMA pipe '
+                                         'executes executed_gflop_per_launch',
                             'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
                             'executed_tflops': CONV64_EXECUTED_GFLOP / kernel_ms}
         if os.environ.get('PDS_WINOGRAD', '1')[:1] == '0':
