@@ -275,3 +275,29 @@ class Workspace(object):
 def not_differentiable(name):
     raise NotImplementedError(
         '%s: backward of this entry point is not built yet; run it under torch.no_grad()' % name)
+
+
+def saved_workspace(ctx, name):
+    """The forward workspace a backward needs; a second backward through the same node is refused (the workspace is
+    released after the first one, and the backward kernels use the forward's intermediates in place)."""
+    ws = getattr(ctx, 'forward_workspace', None)
+    if ws is None:
+        raise RuntimeError('%s: backward through this node a second time is not supported (retain_graph / repeated '
+                           'torch.autograd.grad): run the forward again' % name)
+    return ws
+
+
+_warned_eval_with_grad = set()
+
+
+def warn_eval_with_grad(module):
+    """Inference is meant to run under torch.no_grad() (as the reference's trainer.py:232-243 does): with gradients
+    enabled the modules take the training route -- every layer output is kept and the fused inference kernels are
+    skipped -- whatever module.training says.  Said once per module class."""
+    key = type(module).__name__
+    if not module.training and key not in _warned_eval_with_grad:
+        _warned_eval_with_grad.add(key)
+        import warnings
+        warnings.warn('%s is in eval() mode but gradients are enabled: taking the (slower, memory-hungry) training '
+                      'route; wrap inference in torch.no_grad()' % key, stacklevel=3)
+

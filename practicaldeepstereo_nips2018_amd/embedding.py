@@ -63,6 +63,13 @@ class Embedding(nn.Module):
         if x.size(1) != self._embedding_modules[1].conv.in_channels:
             raise ValueError('expected %d image channels, got %d' %
                              (self._embedding_modules[1].conv.in_channels, x.size(1)))
+        if torch.is_grad_enabled():
+            if x.requires_grad:
+                # the reference propagates through the first InstanceNorm to the image; this path does not
+                raise NotImplementedError('Embedding: the gradient with respect to the image is not implemented '
+                                          '(detach the image, or use the reference module for saliency-type uses)')
+            if any(p.requires_grad for p in self.parameters()):
+                _lib.warn_eval_with_grad(self)
         return _EmbeddingFunction.apply(self, x, int(pad_top), int(pad_left), *self.parameters())
 
     def forward(self, image):
@@ -127,7 +134,7 @@ class _EmbeddingFunction(torch.autograd.Function):
         grad_params, keep_grads = module.native_params(tensor_of)
         nbytes = lib.pds_embedding_bwd_workspace_bytes(ctypes.byref(params), batch, h, w, pad_top, pad_left)
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device)
-        fws = ctx.forward_workspace
+        fws = _lib.saved_workspace(ctx, 'embedding')
         with torch.cuda.device(image.device):
             _lib.check(lib.pds_embedding_bwd(
                 ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(image), _lib.ptr(descriptor),

@@ -30,6 +30,9 @@ class SubpixelCrossEntropy(nn.Module):
                              (tuple(gt.shape), tuple(sim.shape)))
         w = None
         if weights is not None:
+            if torch.is_grad_enabled() and weights.requires_grad:
+                raise NotImplementedError('SubpixelCrossEntropy: the gradient with respect to `weights` is not '
+                                          'implemented (pass weights.detach())')
             w = _lib.require_gpu_tensor(weights.detach(), 'weights', 3)
             if w.shape != gt.shape:
                 raise ValueError('weights of shape %s do not match the ground truth %s' %

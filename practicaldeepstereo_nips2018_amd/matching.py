@@ -130,7 +130,7 @@ class _MatchingOperationFunction(torch.autograd.Function):
         grad_x = torch.empty_like(x)
         nbytes = lib.pds_matching_operation_bwd_workspace_bytes(ctypes.byref(params), n, h, w)
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
-        fws = ctx.forward_workspace
+        fws = _lib.saved_workspace(ctx, 'matching')
         with torch.cuda.device(x.device):
             _lib.check(lib.pds_matching_operation_bwd(
                 ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(x), _lib.ptr(grad_out),
@@ -215,6 +215,7 @@ class Matching(nn.Module):
             if not needs_grad:
                 return _FusedMatchingFunction.apply(self, left, right, begin, count,
                                                     *operation.parameters())
+            _lib.warn_eval_with_grad(self)
             # Training: the differentiable route is shift/concat -> MatchingOperation over all planes at once
             # (the statistics of InstanceNorm2d are per image, so planes may be folded into the batch).
             batch = left.size(0)

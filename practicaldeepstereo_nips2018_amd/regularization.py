@@ -84,7 +84,7 @@ class _ContractionFunction(torch.autograd.Function):
         grad_x = torch.empty_like(x)
         ws = torch.empty(max(int(lib.pds_contraction_block_bwd_workspace_bytes(batch, c, d, h, w)), 256),
                          dtype=torch.uint8, device=x.device)
-        fws = ctx.forward_workspace
+        fws = _lib.saved_workspace(ctx, 'regularization')
         with torch.cuda.device(x.device):
             _lib.check(lib.pds_contraction_block_bwd(
                 ctypes.byref(pd), ctypes.byref(ps), ctypes.byref(gd), ctypes.byref(gs), _lib.ptr(x),
@@ -156,7 +156,7 @@ class _ExpansionFunction(torch.autograd.Function):
         grad_x, grad_shortcut = torch.empty_like(x), torch.empty_like(shortcut)
         ws = torch.empty(max(int(lib.pds_expansion_block_bwd_workspace_bytes(batch, c, d, h, w)), 256),
                          dtype=torch.uint8, device=x.device)
-        fws = ctx.forward_workspace
+        fws = _lib.saved_workspace(ctx, 'regularization')
         with torch.cuda.device(x.device):
             _lib.check(lib.pds_expansion_block_bwd(
                 ctypes.byref(pu), ctypes.byref(ps), ctypes.byref(gu), ctypes.byref(gs), _lib.ptr(x),
@@ -293,7 +293,7 @@ class _RegularizationFunction(torch.autograd.Function):
         grad_shortcut = torch.empty_like(shortcut)
         nbytes = lib.pds_regularization_bwd_workspace_bytes(ctypes.byref(params), batch, d, h, w)
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ms.device)
-        fws = ctx.forward_workspace
+        fws = _lib.saved_workspace(ctx, 'regularization')
         with torch.cuda.device(ms.device):
             _lib.check(lib.pds_regularization_bwd(
                 ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(ms), _lib.ptr(shortcut),

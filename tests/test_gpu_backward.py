@@ -302,3 +302,44 @@ def test_training_step_against_reference_fixture(dev):
             failures.append((name, mine, theirs))
     assert not failures, failures
     print('training step vs reference fixture: loss %.6f, worst gradient-norm error vs fp64 %.2e' % (loss.item(), worst))
+
+
+def test_unsupported_autograd_uses_fail_loudly(dev):
+    """A second backward through a node, a gradient for the image and one for the loss weights are refused with
+    a message instead of crashing or silently returning nothing."""
+    op = helpers.seeded(pds.MatchingOperation, seed=3).to(dev)
+    x = torch.randn(1, 128, 8, 12, generator=torch.Generator().manual_seed(0)).to(dev).requires_grad_(True)
+    out = op(x).sum()
+    out.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='second time'):
+        out.backward()
+
+    emb = helpers.seeded(pds.Embedding, seed=1).to(dev)
+    image = (torch.rand(1, 3, 32, 48) * 255).to(dev).requires_grad_(True)
+    with pytest.raises(NotImplementedError, match='image'):
+        emb(image)
+
+    crit = pds.SubpixelCrossEntropy()
+    sim = torch.randn(1, 8, 4, 6, device=dev, requires_grad=True)
+    gt = torch.rand(1, 4, 6, device=dev) * 10
+    weights = torch.ones(1, 4, 6, device=dev, requires_grad=True)
+    with pytest.raises(NotImplementedError, match='weights'):
+        crit(sim, gt, weights)
+    crit(sim, gt, weights.detach()).backward()   # the supported form
+
+
+def test_eval_mode_with_gradients_warns_once(dev):
+    import warnings
+    from practicaldeepstereo_nips2018_amd import _lib
+    _lib._warned_eval_with_grad.discard('Embedding')
+    emb = helpers.seeded(pds.Embedding, seed=1).to(dev).eval()
+    image = (torch.rand(1, 3, 32, 48) * 255).to(dev)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        emb(image)
+        emb(image)
+    assert sum('torch.no_grad' in str(w.message) for w in caught) == 1
+    with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+        warnings.simplefilter('always')
+        emb(image)
+    assert not caught
