@@ -494,11 +494,13 @@ def main():
                                          'counts the ALGORITHMIC flops of the direct convolution; the MFMA pipe '
                                          'executes executed_gflop_per_launch',
                             'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
-                            'executed_tflops': CONV64_EXECUTED_GFLOP / kernel_ms}
+                            'executed_tflops': CONV64_EXECUTED_GFLOP / kernel_ms,
+                            'frac_executed': CONV64_EXECUTED_GFLOP / kernel_ms / FP32_MFMA_PEAK_TFLOPS}
         if os.environ.get('PDS_WINOGRAD', '1')[:1] == '0':
             line['roofline']['algorithm'] = 'direct implicit GEMM (PDS_WINOGRAD=0)'
             line['roofline']['executed_gflop_per_launch'] = CONV64_GFLOP
             line['roofline']['executed_tflops'] = achieved
+            line['roofline']['frac_executed'] = achieved / FP32_MFMA_PEAK_TFLOPS
         ordered = sorted(args.steps / w for w in windows)
         line['windows'] = {'count': len(windows), 'median': ordered[len(ordered) // 2], 'min': ordered[0],
                            'max': ordered[-1], 'unit': 'pairs/s',
