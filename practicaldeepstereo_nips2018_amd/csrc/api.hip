@@ -844,9 +844,16 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             c.run(set_error(-1, "backward: layer %d has no upstream gradient", li));
             return;
         }
-        auto route = [&](int id, const float* grad_in, const Geom& in_g) {
+        // may_adopt: grad_in is an arena buffer nobody else will read or write (a layer's fresh dx): the first
+        // gradient of a tensor then simply BECOMES that buffer instead of being copied into a new one
+        auto route = [&](int id, const float* grad_in, const Geom& in_g, bool may_adopt = false) {
             if (id < 0 || !T.tensors[id].needs_grad) return;
             const TapeTensor& t = T.tensors[id];
+            if (may_adopt && !dhat[id] && !written[id] && !t.bcast_d) {
+                dhat[id] = c.plan && !grad_in ? reinterpret_cast<float*>(8) : const_cast<float*>(grad_in);
+                written[id] = 1;
+                return;
+            }
             if (!dhat[id]) {
                 dhat[id] = c.get<float>(t.bcast_d ? (size_t)t.g.n * t.g.c * t.g.h * t.g.w : t.g.numel());
                 if (!dhat[id]) dhat[id] = reinterpret_cast<float*>(8);  // plan mode: mark as carved
@@ -868,7 +875,7 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             if (!T.tensors[L.a].needs_grad) continue;
             float* dx = c.get<float>(L.in_g.numel());
             if (!c.plan) c.run(launch_depth_to_space(g, L.in_g.n, L.in_g.c, L.in_g.h, L.in_g.w, dx, c.s));
-            route(L.a, dx, L.in_g);
+            route(L.a, dx, L.in_g, true);
             continue;
         }
         const PdsConvBlockParams* gp = M.find(L.P);
@@ -967,8 +974,10 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         } else if (!c.plan) {
             c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, weight, dx, L.in_g, L.out_g, c.s));
         }
-        route(L.a, dx, L.in_g);
-        route(L.b, dx, L.in_g);
+        // dx goes to both sources of a two-source layer: only one of them may adopt the buffer
+        const bool a_takes = L.a >= 0 && T.tensors[L.a].needs_grad && !T.tensors[L.a].bcast_d;
+        route(L.a, dx, L.in_g, true);
+        route(L.b, dx, L.in_g, !a_takes);
     }
 }
 
