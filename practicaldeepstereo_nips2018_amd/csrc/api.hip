@@ -893,7 +893,8 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             float* m2 = c.get<float>(groups);
             if (!c.plan)
                 c.run(launch_in_bwd(g, out.raw, out.g, out.per_plane, out.mean, out.rstd, L.P->gamma, scratch, m1, m2,
-                                    dzb, const_cast<float*>(gp->gamma), const_cast<float*>(gp->beta), 0, c.s));
+                                    dzb, const_cast<float*>(gp->gamma), const_cast<float*>(gp->beta),
+                                    const_cast<float*>(gp->bias), 0, c.s));   // (the bias gradient comes with it)
             dz = dzb;
         }
         // 2. parameters
@@ -904,8 +905,10 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             const TapeTensor& tb = T.tensors[L.b];
             sb = Src{tb.raw, tb.scale, tb.shift, tb.per_plane, tb.bcast_d};
         }
-        double* bias_scratch = c.get<double>((size_t)channel_sum_splits(out.g) * out.g.c);
-        if (!c.plan) c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
+        if (!L.norm) {   // a bare layer: dz is the upstream gradient itself, its channel sums need a pass of their own
+            double* bias_scratch = c.get<double>((size_t)channel_sum_splits(out.g) * out.g.c);
+            if (!c.plan) c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
+        }
         const float* weight = L.s2d_cin ? L.weight_used : L.P->weight;
         const int taps = L.kd * 9;
         // space-to-depth layer: the gradient of the 3x3 weights is formed in scratch, then gathered into the 5x5 one

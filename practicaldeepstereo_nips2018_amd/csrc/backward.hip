@@ -96,26 +96,52 @@ __global__ __launch_bounds__(64) void in_bwd_params_kernel(const double* __restr
     }
 }
 
-// dz = lrelu'(t) * gamma * r * (g - m1 - n * m2)
+// dz = lrelu'(t) * gamma * r * (g - m1 - n * m2); every block also leaves the sum of the dz it wrote in bias_partial
+// [(n*C + c)*D + d][block] (the bias gradient is that sum over everything but c: no extra pass over dz)
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ t,
                                                            const Geom geom, int per_plane,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ m1, const float* __restrict__ m2,
-                                                           float* __restrict__ dz) {
+                                                           float* __restrict__ dz, double* __restrict__ bias_partial) {
     const int nc = blockIdx.z, d = blockIdx.y;
     const int c = nc % geom.c;
     const int grp = per_plane ? nc * geom.d + d : nc;
     const float mu = mean[grp], r = rstd[grp], a = gamma[c] * r, b1 = m1[grp], b2 = m2[grp];
     const size_t px = geom.plane();
     const size_t base = ((size_t)nc * geom.d + d) * px;
+    float sum = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < px; i += (size_t)gridDim.x * 256) {
         const float tv = t[base + i];
         const float n = (tv - mu) * r;
         const float dt = a * (g[base + i] - b1 - n * b2);
-        dz[base + i] = tv > 0.f ? dt : dt * kLeakySlope;
+        const float v = tv > 0.f ? dt : dt * kLeakySlope;
+        dz[base + i] = v;
+        sum += v;
     }
+    __shared__ double red[4];
+    const double ws = wave_sum((double)sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        bias_partial[((size_t)nc * geom.d + d) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// db[c] (+)= sum over n and the [D * blocks] partials of (n, c)
+__global__ __launch_bounds__(256) void bias_partial_reduce_kernel(const double* __restrict__ partial, int N, int C,
+                                                                  int per_nc, float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const double* p = partial + (size_t)(n * C + c) * per_nc;
+        for (int i = threadIdx.x; i < per_nc; i += 256) s += p[i];
+    }
+    __shared__ double red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 static unsigned plane_tiles(const Geom& g) {
@@ -125,15 +151,17 @@ static unsigned plane_tiles(const Geom& g) {
 
 // scratch (doubles): partial records N*C*D*tiles*2 + group records 2*groups ; floats: m1, m2 [groups]
 size_t in_bwd_scratch_doubles(const Geom& g) {
-    return (size_t)g.n * g.c * g.d * plane_tiles(g) * 2 + (size_t)g.n * g.c * g.d * 2;
+    return (size_t)g.n * g.c * g.d * plane_tiles(g) * 2 + (size_t)g.n * g.c * g.d * 2 +
+           (size_t)g.n * g.c * g.d * plane_tiles(g) * 4;   // + the bias partials of the apply kernel
 }
 
 int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
                   const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
-                  float* dgamma, float* dbeta, int accumulate_params, hipStream_t s) {
+                  float* dgamma, float* dbeta, float* dbias, int accumulate_params, hipStream_t s) {
     const unsigned tiles = plane_tiles(geom);
     double* partials = scratch;
     double* qs = scratch + (size_t)geom.n * geom.c * geom.d * tiles * 2;
+    double* bias_partial = qs + (size_t)geom.n * geom.c * geom.d * 2;
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(tiles, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
                        partials);
     const int inner = per_plane ? geom.d : 1;
@@ -145,7 +173,9 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
     hipLaunchKernelGGL(in_bwd_params_kernel, dim3(geom.c), dim3(64), 0, s, qs, geom.n, geom.c, inner, dgamma, dbeta,
                        accumulate_params);
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(tiles * 4, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
-                       per_plane, mean, rstd, gamma, m1, m2, dz);
+                       per_plane, mean, rstd, gamma, m1, m2, dz, bias_partial);
+    hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(geom.c), dim3(256), 0, s, bias_partial, geom.n, geom.c,
+                       (int)(geom.d * tiles * 4), dbias, accumulate_params);
     return check_launch("in_bwd");
 }
 

@@ -150,7 +150,7 @@ int launch_in_finalize(const double* partials, int groups, int per_group, double
 size_t in_bwd_scratch_doubles(const Geom& g);
 int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
                   const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
-                  float* dgamma, float* dbeta, int accumulate_params, hipStream_t s);
+                  float* dgamma, float* dbeta, float* dbias, int accumulate_params, hipStream_t s);
 int channel_sum_splits(const Geom& g);
 int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s);
 int launch_flip_weights(const float* w, float* wf, int cout, int cin, int taps, hipStream_t s);
