@@ -929,6 +929,10 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             if (!c.plan)
                 c.run(launch_wgrad3d_s2_mfma(L.type, sa, sb, dz, dweight, L.in_g, L.out_g, 0, ws, c.s));
         } else {
+            static const bool debug_fallback = getenv("PDS_DEBUG_ARENA") != nullptr;
+            if (debug_fallback && !c.plan)
+                fprintf(stderr, "[pds] VALU weight gradient: type %d kd %d stride %d in [%d,%d,%d,%d,%d] out c %d two-source %d\n",
+                        L.type, L.kd, L.stride, L.in_g.n, L.in_g.c, L.in_g.d, L.in_g.h, L.in_g.w, L.out_g.c, sb.p != nullptr);
             double* weight_scratch = c.get<double>(bwd_weight_scratch_doubles(L.type, L.kd, L.in_g, L.out_g));
             if (!c.plan)
                 c.run(launch_bwd_weight(L.type, L.kd, L.stride, sa, sb, dz, dweight, L.in_g, L.out_g, 0, weight_scratch,

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
                 for (int j = 0; j < BATCH; ++j) {     // loads first: unconditional, clamped addresses
                     const int cr = cr0 + j, c = cr / 3, rr = cr - c * 3;
                     const int yc = min(max(y - 1 + rr, 0), A.H - 1);
-                    const size_t off = ((size_t)(n * A.Cin + cg0 + c) * A.D + d) * plane + (size_t)yc * A.W + xc;
+                    const int chc = min(cg0 + c, A.Cin - 1);   // (a last group may hold fewer than 64 channels)
+                    const size_t off = ((size_t)(n * A.Cin + chc) * A.D + d) * plane + (size_t)yc * A.W + xc;
                     va[j] = A.a.p[off];
                     vb[j] = A.b.p ? A.b.p[off] : 0.f;
                 }
@@ -89,14 +90,15 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
                 for (int j = 0; j < BATCH; ++j) {
                     const int cr = cr0 + j, c = cr / 3, rr = cr - c * 3;
                     const int yy = y - 1 + rr;
-                    const int ch = cg0 + c;
+                    const bool chok = cg0 + c < A.Cin;
+                    const int ch = min(cg0 + c, A.Cin - 1);
                     const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
                     float v = A.a.scale ? fmaf(A.a.scale[g], va[j], A.a.shift[g]) : va[j];
                     if (A.b.p) {
                         const int gb = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
                         v += A.b.scale ? fmaf(A.b.scale[gb], vb[j], A.b.shift[gb]) : vb[j];
                     }
-                    v = (colok && yy >= 0 && yy < A.H) ? v : 0.f;
+                    v = (chok && colok && yy >= 0 && yy < A.H) ? v : 0.f;
                     if (lane < TWG + 2) xl[c * XS + rr * RSX + xx] = v;
                 }
             }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int oc = mb * 16 + 4 * (lane >> 4) + rr;
-            if (oc < A.Cout) dst[((size_t)oc * A.Cin + c) * 9 + t] = acc[i][rr];
+            if (oc < A.Cout && c < A.Cin) dst[((size_t)oc * A.Cin + c) * 9 + t] = acc[i][rr];
         }
     }
 }
@@ -182,7 +184,7 @@ int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, floa
 
 bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, const Geom& in, const Geom& out) {
     if (transposed || kd != 1 || stride != 1) return false;
-    if (in.c % CG != 0) return false;
+    if (in.c % CG != 0 && in.c > CG) return false;   // whole groups of 64 channels, or one partial group
     if (!(out.c == 64 || out.c <= 16)) return false;
     if (b.p && b.bcast_d) return false;
     return true;
@@ -215,7 +217,7 @@ int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, 
     A.segs = (in.w + TWG - 1) / TWG;
     A.items = in.n * in.d * in.h * A.segs;
     const int wgs = wgrad2d_workgroups(in);
-    dim3 grid(wgs, in.c / CG);
+    dim3 grid(wgs, (in.c + CG - 1) / CG);
     if (out.c == 64)
         hipLaunchKernelGGL((wgrad2d_mfma_kernel<4>), grid, dim3(THREADS), 0, s, A);
     else
