@@ -36,7 +36,7 @@ struct WArgs {
 
 }  // namespace
 
-template <int MBW>
+template <int MBW, bool HAS_B>
 __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A) {
     constexpr int PARTS = 4 / MBW;          // waves sharing one output block split the column blocks
     constexpr int NB = NBLK / PARTS;        // column blocks per wave
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // 16-byte staging needs rows that start 16-byte aligned
+    const bool vec_ok = (A.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.a.p) | reinterpret_cast<uintptr_t>(A.b.p)) & 15) == 0;
     for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
         int r = item;
         const int seg = r % A.segs;
@@ -68,7 +70,77 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
         // InstanceNorm coefficients are wave-uniform (scalar registers), the per-lane work is one load, one fma, one
         // LDS write.  (The first version walked a flat element index: two divisions and two coefficient loads per
         // element cost as much issue time as a third of the MFMAs.)
-        {
+        if (vec_ok) {
+            // Rows that are a multiple of 4 wide: a (channel, row) run is 8 aligned 16-byte loads plus its two halo
+            // columns, i.e. 10 lanes; a wave covers 6 runs per load instruction and its 48 runs in 8 instructions,
+            // all issued before the first one is needed.  (With one 4-byte load per lane and run -- 34 of 64 lanes,
+            // 136 bytes per instruction -- the 48 instructions per wave went out in six dependent batches and staging
+            // took twice as long as the MFMAs of the item.)
+            constexpr int RPI = 6, ITER = 8;          // runs per instruction, instructions per wave (6 * 8 = 48 runs)
+            static_assert(CG * 3 == 4 * RPI * ITER, "a wave stages a quarter of the runs");
+            const int rs = lane / 10, part = lane - rs * 10;
+            const bool lane_on = rs < RPI;
+            const int xq = x0 + 4 * min(part, 7);     // interior quad (parts 0..7)
+            const int xh = part == 8 ? x0 - 1 : x0 + TWG;   // halo column (parts 8, 9)
+            const bool halo = part >= 8;
+            const bool colok = halo ? (xh >= 0 && xh < A.W) : xq < A.W;
+            const int xcol = halo ? min(max(xh, 0), A.W - 1) : min(xq, A.W - 4);
+            constexpr int FLY = MBW == 4 ? 4 : 8;     // instructions in flight (144 accumulator registers leave room for 4)
+            for (int it0 = 0; it0 < ITER; it0 += FLY) {
+            f32x4 qa[FLY], qb[HAS_B ? FLY : 1];
+#pragma unroll
+            for (int itl = 0; itl < FLY; ++itl) {
+                const int it = it0 + itl;
+                const int cr = min(wave * (RPI * ITER) + it * RPI + rs, CG * 3 - 1), c = cr / 3, rr = cr - c * 3;
+                const int yc = min(max(y - 1 + rr, 0), A.H - 1);
+                const int chc = min(cg0 + c, A.Cin - 1);
+                const size_t off = ((size_t)(n * A.Cin + chc) * A.D + d) * plane + (size_t)yc * A.W + xcol;
+                if (halo) {
+                    qa[itl] = f32x4{A.a.p[off], 0.f, 0.f, 0.f};
+                    if (HAS_B) qb[itl] = f32x4{A.b.p[off], 0.f, 0.f, 0.f};
+                } else {
+                    qa[itl] = *reinterpret_cast<const f32x4*>(A.a.p + off);
+                    if (HAS_B) qb[itl] = *reinterpret_cast<const f32x4*>(A.b.p + off);
+                }
+            }
+#pragma unroll
+            for (int itl = 0; itl < FLY; ++itl) {
+                const int it = it0 + itl;
+                const int cr = min(wave * (RPI * ITER) + it * RPI + rs, CG * 3 - 1), c = cr / 3, rr = cr - c * 3;
+                const int yy = y - 1 + rr;
+                const bool chok = cg0 + c < A.Cin;
+                const int ch = min(cg0 + c, A.Cin - 1);
+                const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                float sa = 1.f, ha = 0.f, sb2 = 1.f, hb2 = 0.f;
+                if (A.a.scale) {
+                    sa = A.a.scale[g];
+                    ha = A.a.shift[g];
+                }
+                if (HAS_B && A.b.scale) {
+                    const int gb = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                    sb2 = A.b.scale[gb];
+                    hb2 = A.b.shift[gb];
+                }
+                const bool ok = chok && colok && yy >= 0 && yy < A.H;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = fmaf(sa, qa[itl][j], ha);
+                    if (HAS_B) t += fmaf(sb2, qb[itl][j], hb2);
+                    v[j] = ok ? t : 0.f;
+                }
+                float* dst = xl + c * XS + rr * RSX;
+                if (lane_on) {
+                    if (halo) {
+                        dst[part == 8 ? 0 : TWG + 1] = v[0];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dst[1 + 4 * part + j] = v[j];
+                    }
+                }
+            }
+            }
+        } else {
             const int xx = min(lane, TWG + 1);        // lanes 0..33 active, the rest shadow lane 33
             const int x = x0 - 1 + xx;
             const bool colok = x >= 0 && x < A.W;
@@ -103,8 +175,25 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
                 }
             }
         }
-        // ---- stage dz: (padded) output channels x 32 positions: a wave stages two channel rows per step ----
-        {
+        // ---- stage dz: (padded) output channels x 32 positions ---------------------------------------------------
+        if (vec_ok && (reinterpret_cast<uintptr_t>(A.dz) & 15) == 0) {
+            // 16-byte loads: 8 lanes per channel row, two rows of loads per thread for 64 channels
+#pragma unroll
+            for (int k = 0; k < (MBW * 16 * 8 + THREADS - 1) / THREADS; ++k) {
+                const int e = tid + k * THREADS;
+                const int oc = e >> 3, q = e & 7;
+                if (oc < MBW * 16) {
+                    const int x = x0 + 4 * q;
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (oc < A.Cout && x < A.W)
+                        v = *reinterpret_cast<const f32x4*>(
+                            A.dz + ((size_t)(n * A.Cout + oc) * A.D + d) * plane + (size_t)y * A.W + x);
+                    float* dst = dzl + oc * DS + 4 * q;
+                    *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);        // DS is even: 8-byte aligned
+                    *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+                }
+            }
+        } else {
             const int px = lane & 31, x = x0 + px;
             for (int o2 = wave; o2 < MBW * 8; o2 += 4) {
                 const int oc = o2 * 2 + (lane >> 5);
@@ -218,10 +307,13 @@ int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, 
     A.items = in.n * in.d * in.h * A.segs;
     const int wgs = wgrad2d_workgroups(in);
     dim3 grid(wgs, (in.c + CG - 1) / CG);
-    if (out.c == 64)
-        hipLaunchKernelGGL((wgrad2d_mfma_kernel<4>), grid, dim3(THREADS), 0, s, A);
-    else
-        hipLaunchKernelGGL((wgrad2d_mfma_kernel<1>), grid, dim3(THREADS), 0, s, A);
+    if (out.c == 64) {
+        if (b.p) hipLaunchKernelGGL((wgrad2d_mfma_kernel<4, true>), grid, dim3(THREADS), 0, s, A);
+        else hipLaunchKernelGGL((wgrad2d_mfma_kernel<4, false>), grid, dim3(THREADS), 0, s, A);
+    } else {
+        if (b.p) hipLaunchKernelGGL((wgrad2d_mfma_kernel<1, true>), grid, dim3(THREADS), 0, s, A);
+        else hipLaunchKernelGGL((wgrad2d_mfma_kernel<1, false>), grid, dim3(THREADS), 0, s, A);
+    }
     if (int rc = check_launch("wgrad2d_mfma")) return rc;
     return launch_wgrad_reduce_f32(scratch, (size_t)out.c * in.c * 9, wgs, dw, accumulate, s);
 }
