@@ -108,6 +108,9 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
     for (int e = tid; e < 16 * C::XS + 16 * DS; e += THREADS) smem[e] = 0.f;
     __syncthreads();
 
+    // 16-byte staging of the big tile needs rows that start 16-byte aligned
+    const bool vec_ok = (A.Wb & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.dz) | reinterpret_cast<uintptr_t>(A.a.p) |
+                                              reinterpret_cast<uintptr_t>(A.b.p)) & 15) == 0;
     for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
         int r = item;
         const int seg = r % A.segs;
@@ -119,6 +122,81 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
         const int x0 = seg * TWG;
 
         // ---- stage the big tile: 16 channels x K*K rows x 66 columns (2 x0 - 1 .. 2 x0 + 64), split by column parity
+        if (vec_ok) {
+            // a (channel, row) run = 16 aligned 16-byte loads (columns 2 x0 .. 2 x0 + 63) + its two halo columns = 18
+            // lanes; a wave covers 3 runs per load instruction and up to 8 instructions are in flight (the flat
+            // element loop below, one conditional 4-byte load per element, took 8 x longer than the MFMAs of an item)
+            constexpr int LPR = 18, RPI = 3, FLY = 8;
+            const int rs = lane / LPR, part = lane - rs * LPR;
+            const bool lane_on = rs < RPI;
+            const bool halo = part >= 16;
+            const int X = halo ? (part == 16 ? 2 * x0 - 1 : 2 * x0 + 2 * TWG) : 2 * x0 + 4 * part;
+            const bool colok = X >= 0 && X < A.Wb;
+            const int Xc = halo ? min(max(X, 0), A.Wb - 1) : min(X, A.Wb - 4);
+            const int runs = nb * C::ROWS;
+            const int iters = (runs + 4 * RPI - 1) / (4 * RPI);
+            for (int it0 = 0; it0 < iters; it0 += FLY) {
+                f32x4 qa[FLY], qb[FLY];
+#pragma unroll
+                for (int itl = 0; itl < FLY; ++itl) {
+                    const int run = min(((it0 + itl) * 4 + wave) * RPI + rs, runs - 1);
+                    const int c = run / C::ROWS, rr = run - c * C::ROWS;
+                    const int zc = min(max(2 * z - 1 + rr / K, 0), A.Db - 1), yc = min(max(2 * y - 1 + rr % K, 0), A.Hb - 1);
+                    const int g = n * A.Cb + b0 + c;
+                    const size_t inplane = (size_t)yc * A.Wb + Xc;
+                    const float* pa = (SMALL_NORM ? A.dz : A.a.p) + (size_t)g * vol_b + (size_t)zc * plane_b + inplane;
+                    const float* pb = (!SMALL_NORM && A.b.p)
+                                          ? A.b.p + (A.b.bcast_d ? (size_t)g * plane_b : (size_t)g * vol_b + (size_t)zc * plane_b) + inplane
+                                          : pa;
+                    if (halo) {
+                        qa[itl] = f32x4{*pa, 0.f, 0.f, 0.f};
+                        qb[itl] = f32x4{*pb, 0.f, 0.f, 0.f};
+                    } else {
+                        qa[itl] = *reinterpret_cast<const f32x4*>(pa);
+                        qb[itl] = *reinterpret_cast<const f32x4*>(pb);
+                    }
+                }
+#pragma unroll
+                for (int itl = 0; itl < FLY; ++itl) {
+                    const int run_raw = ((it0 + itl) * 4 + wave) * RPI + rs;
+                    const int run = min(run_raw, runs - 1);
+                    const int c = run / C::ROWS, rr = run - c * C::ROWS;
+                    const int zz = 2 * z - 1 + rr / K, yy = 2 * y - 1 + rr % K;
+                    const bool ok = colok && zz >= 0 && zz < A.Db && yy >= 0 && yy < A.Hb;
+                    float sa = 1.f, ha = 0.f, sb2 = 1.f, hb2 = 0.f;
+                    const bool two = !SMALL_NORM && A.b.p;
+                    if (!SMALL_NORM) {
+                        const int g = n * A.Cb + b0 + c;
+                        if (A.a.scale) {
+                            sa = A.a.scale[g];
+                            ha = A.a.shift[g];
+                        }
+                        if (two && A.b.scale) {
+                            sb2 = A.b.scale[g];
+                            hb2 = A.b.shift[g];
+                        }
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = SMALL_NORM ? qa[itl][j] : fmaf(sa, qa[itl][j], ha);
+                        if (two) t += fmaf(sb2, qb[itl][j], hb2);
+                        v[j] = ok ? t : 0.f;
+                    }
+                    if (lane_on && run_raw < runs) {
+                        float* dst = bl + c * C::XS + rr * RS;   // [odd columns (HS) | even columns (HS)]
+                        if (halo) {
+                            dst[part == 16 ? 0 : HS + TWG] = v[0];          // odd[0] = B[2 x0 - 1], even[32] = B[2 x0 + 64]
+                        } else {
+                            // columns 2 x0 + 4 q + (0..3): even[2q], odd[2q+1], even[2q+1], odd[2q+2]
+                            *reinterpret_cast<float2*>(dst + HS + 2 * part) = make_float2(v[0], v[2]);
+                            dst[2 * part + 1] = v[1];
+                            dst[2 * part + 2] = v[3];
+                        }
+                    }
+                }
+            }
+        } else
         for (int c = 0; c < nb; ++c) {
             const int ch = b0 + c;
             for (int e = tid; e < C::ROWS * BCOLS; e += THREADS) {
