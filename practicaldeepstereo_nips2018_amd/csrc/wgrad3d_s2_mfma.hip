@@ -79,8 +79,11 @@ template <int K, bool SMALL_NORM>
 __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args A) {
     using C = Cfg<K>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* bl = smem;                 // [16][XS]
-    float* sl = smem + 16 * C::XS;    // [16][DS]
+    // big tile: [rows][XS] with rows = min(16, Cb) (+ one all-zero row that the lanes beyond Cb read): few-channel layers
+    // (8 -> 4 at full half-resolution) need 20 KB instead of 70, so more workgroups fit on a CU
+    const int nbm = min(16, A.Cb), brows = nbm < 16 ? nbm + 1 : 16;
+    float* bl = smem;                     // [brows][XS]
+    float* sl = smem + brows * C::XS;     // [16][DS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
 
     // channel rows beyond the tensors' channel counts are zeroed once and never staged (few-channel layers: 8 -> 4)
     const int nb = min(16, A.Cb - b0), ns = min(16, A.Cs - s0);
-    for (int e = tid; e < 16 * C::XS + 16 * DS; e += THREADS) smem[e] = 0.f;
+    for (int e = tid; e < brows * C::XS + 16 * DS; e += THREADS) smem[e] = 0.f;
     __syncthreads();
 
     // 16-byte staging of the big tile needs rows that start 16-byte aligned
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
             // a (channel, row) run = 16 aligned 16-byte loads (columns 2 x0 .. 2 x0 + 63) + its two halo columns = 18
             // lanes; a wave covers 3 runs per load instruction and up to 8 instructions are in flight (the flat
             // element loop below, one conditional 4-byte load per element, took 8 x longer than the MFMAs of an item)
-            constexpr int LPR = 18, RPI = 3, FLY = 8;
+            constexpr int LPR = 18, RPI = 3, FLY = SMALL_NORM ? 6 : 8;
             const int rs = lane / LPR, part = lane - rs * LPR;
             const bool lane_on = rs < RPI;
             const bool halo = part >= 16;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
             const int runs = nb * C::ROWS;
             const int iters = (runs + 4 * RPI - 1) / (4 * RPI);
             for (int it0 = 0; it0 < iters; it0 += FLY) {
-                f32x4 qa[FLY], qb[FLY];
+                f32x4 qa[FLY], qb[SMALL_NORM ? 1 : FLY];
 #pragma unroll
                 for (int itl = 0; itl < FLY; ++itl) {
                     const int run = min(((it0 + itl) * 4 + wave) * RPI + rs, runs - 1);
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
                                           : pa;
                     if (halo) {
                         qa[itl] = f32x4{*pa, 0.f, 0.f, 0.f};
-                        qb[itl] = f32x4{*pb, 0.f, 0.f, 0.f};
+                        if (!SMALL_NORM) qb[itl] = f32x4{*pb, 0.f, 0.f, 0.f};
                     } else {
                         qa[itl] = *reinterpret_cast<const f32x4*>(pa);
-                        qb[itl] = *reinterpret_cast<const f32x4*>(pb);
+                        if (!SMALL_NORM) qb[itl] = *reinterpret_cast<const f32x4*>(pb);
                     }
                 }
 #pragma unroll
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = SMALL_NORM ? qa[itl][j] : fmaf(sa, qa[itl][j], ha);
-                        if (two) t += fmaf(sb2, qb[itl][j], hb2);
+                        if (!SMALL_NORM && two) t += fmaf(sb2, qb[SMALL_NORM ? 0 : itl][j], hb2);
                         v[j] = ok ? t : 0.f;
                     }
                     if (lane_on && run_raw < runs) {
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
         __syncthreads();
 
         const float* arow = sl + (lane & 15) * DS + (lane >> 4);
-        const float* brow = bl + (lane & 15) * C::XS + (lane >> 4);
+        const float* brow = bl + min(lane & 15, brows - 1) * C::XS + (lane >> 4);
 #pragma unroll 2
         for (int ks = 0; ks < TWG / 4; ++ks) {
             const float af = arow[ks * 4];
@@ -430,11 +433,12 @@ int launch_wgrad3d_s2_mfma(int transposed, const Src& a, const Src& b, const flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<3, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
+    const int nbm = big.c < 16 ? big.c + 1 : 16;
     if (transposed) {
-        const size_t lds = (size_t)(16 * Cfg<4>::XS + 16 * DS) * sizeof(float);
+        const size_t lds = (size_t)(nbm * Cfg<4>::XS + 16 * DS) * sizeof(float);
         hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<4, true>), dim3(wgs, pairs), dim3(THREADS), lds, s, A);
     } else {
-        const size_t lds = (size_t)(16 * Cfg<3>::XS + 16 * DS) * sizeof(float);
+        const size_t lds = (size_t)(nbm * Cfg<3>::XS + 16 * DS) * sizeof(float);
         hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<3, false>), dim3(wgs, pairs), dim3(THREADS), lds, s, A);
     }
     if (int rc = check_launch("wgrad3d_s2_mfma")) return rc;
