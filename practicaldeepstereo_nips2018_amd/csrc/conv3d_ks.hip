@@ -121,55 +121,48 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
         const float* ha = A.a.scale ? A.a.shift + (size_t)nb * A.Cin + c_first : nullptr;
         const float* sb = (two && A.b.scale) ? A.b.scale + (size_t)nb * A.Cin + c_first : nullptr;
         const float* hb = (two && A.b.scale) ? A.b.shift + (size_t)nb * A.Cin + c_first : nullptr;
-        // all loads of the wave are issued back to back (a few dozen per lane), then written: one round trip
-        constexpr int PER_LANE = (cq * G::NPOS + 63) / 64;
-        constexpr int total = cq * G::NPOS;
-        float va[PER_LANE], vb[PER_LANE];
-        auto locate = [&](int e, int& c, int& lo, bool& in, unsigned& off, unsigned& offb) {
-            c = e / G::NPOS;
-            const int p = e % G::NPOS;
-            const int xx = p % G::XT, yy = (p / G::XT) % G::YT, zz = p / (G::XT * G::YT);
-            lo = c * A.cs + p;
-            const int z = iz0 + zz, y = iy0 + yy, x = ix0 + xx;
-            in = (unsigned)z < (unsigned)A.Di && (unsigned)y < (unsigned)A.Hi && (unsigned)x < (unsigned)A.Wi;
-            off = in ? (unsigned)(((size_t)c * A.Di + z) * plane_i + (size_t)y * A.Wi + x) * 4u : ~0u;
-            offb = !in ? ~0u : (two && A.b.bcast_d ? (unsigned)((size_t)c * plane_i + (size_t)y * A.Wi + x) * 4u : off);
-        };
+        // all loads of the wave are issued back to back (a few dozen per lane), then written: one round trip.  The
+        // elements are walked channel by channel (lane + 64 i inside a channel), so the channel -- hence its InstanceNorm
+        // coefficients -- is a compile-time index: the first version walked one flat index and picked the coefficients
+        // with a select chain per element, 1 750 VALU instructions per wave for 216 MFMAs.
+        constexpr int PER_CH = (G::NPOS + 63) / 64;
+        float va[cq][PER_CH], vb[cq][PER_CH];
+        int lo_[PER_CH];
+        bool in_[PER_CH];
+        unsigned off_[PER_CH], offb_[PER_CH];
 #pragma unroll
-        for (int i = 0; i < PER_LANE; ++i) {
-            int c, lo;
-            bool in;
-            unsigned off, offb;
-            locate(min(lane + 64 * i, total - 1), c, lo, in, off, offb);   // (surplus lanes re-stage the last element)
-            va[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off, 0, 0));
-            if (two) vb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, offb, 0, 0));
+        for (int i = 0; i < PER_CH; ++i) {
+            const int p = min(lane + 64 * i, G::NPOS - 1);            // (surplus lanes re-stage the last element)
+            const int xx = p % G::XT, yy = (p / G::XT) % G::YT, zz = p / (G::XT * G::YT);
+            lo_[i] = p;
+            const int z = iz0 + zz, y = iy0 + yy, x = ix0 + xx;
+            in_[i] = (unsigned)z < (unsigned)A.Di && (unsigned)y < (unsigned)A.Hi && (unsigned)x < (unsigned)A.Wi;
+            off_[i] = in_[i] ? (unsigned)((size_t)z * plane_i + (size_t)y * A.Wi + x) * 4u : ~0u;
+            offb_[i] = !in_[i] ? ~0u : (two && A.b.bcast_d ? (unsigned)((size_t)y * A.Wi + x) * 4u : off_[i]);
         }
-        float sca[cq], sha[cq], scb[cq], shb[cq];   // wave-uniform InstanceNorm coefficients of the wave's channels
+        const unsigned cbytes_a = (unsigned)(cstride * sizeof(float)), cbytes_b = (unsigned)(cstride_b * sizeof(float));
+#pragma unroll
+        for (int c = 0; c < cq; ++c)
+#pragma unroll
+            for (int i = 0; i < PER_CH; ++i) {
+                // (the channel offset goes into the vector offset: an out-of-range marker plus a scalar offset could wrap)
+                const unsigned oa = in_[i] ? off_[i] + c * cbytes_a : ~0u;
+                va[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, oa, 0, 0));
+                if (two) {
+                    const unsigned ob = in_[i] ? offb_[i] + c * cbytes_b : ~0u;
+                    vb[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, ob, 0, 0));
+                }
+            }
 #pragma unroll
         for (int c = 0; c < cq; ++c) {
-            sca[c] = sa ? sa[c] : 1.f;
-            sha[c] = sa ? ha[c] : 0.f;
-            scb[c] = sb ? sb[c] : 1.f;
-            shb[c] = sb ? hb[c] : 0.f;
-        }
+            const float s1 = sa ? sa[c] : 1.f, h1 = sa ? ha[c] : 0.f;     // wave-uniform: scalar loads
+            const float s2 = sb ? sb[c] : 1.f, h2 = sb ? hb[c] : 0.f;
 #pragma unroll
-        for (int i = 0; i < PER_LANE; ++i) {
-            int c, lo;
-            bool in;
-            unsigned off, offb;
-            locate(min(lane + 64 * i, total - 1), c, lo, in, off, offb);
-            // the channel of element i: cq is 4 or 8, picked with a short select chain on the wave-uniform tables
-            float s1 = sca[0], h1 = sha[0], s2 = scb[0], h2 = shb[0];
-#pragma unroll
-            for (int cc = 1; cc < cq; ++cc) {
-                s1 = c == cc ? sca[cc] : s1;
-                h1 = c == cc ? sha[cc] : h1;
-                s2 = c == cc ? scb[cc] : s2;
-                h2 = c == cc ? shb[cc] : h2;
+            for (int i = 0; i < PER_CH; ++i) {
+                float v = fmaf(s1, va[c][i], h1);
+                if (two) v += fmaf(s2, vb[c][i], h2);
+                mine[c * A.cs + lo_[i]] = in_[i] ? v : 0.f;
             }
-            float v = fmaf(s1, va[i], h1);
-            if (two) v += fmaf(s2, vb[i], h2);
-            mine[lo] = in ? v : 0.f;
         }
     }
 
