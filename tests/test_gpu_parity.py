@@ -125,7 +125,8 @@ def test_fused_matching_golden(dev):
     assert helpers.maxdiff(out, out2) <= TOL_SIGNATURES
 
 
-@pytest.mark.parametrize('batch,h,w,maxd', [(2, 9, 21, 6), (1, 32, 64, 15), (1, 8, 16, 20), (1, 5, 7, 0)])
+@pytest.mark.parametrize('batch,h,w,maxd', [(2, 9, 21, 6), (1, 32, 64, 15), (1, 8, 16, 20), (1, 5, 7, 0),
+                                            (2, 6, 4, 5), (1, 4, 2, 3), (2, 20, 36, 11)])
 def test_fused_matching_shapes_vs_oracle(dev, batch, h, w, maxd):
     """Ragged sizes, batch > 1, disparity range wider than the image, single plane."""
     op = helpers.seeded(pds.MatchingOperation, seed=7)
