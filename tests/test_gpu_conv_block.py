@@ -79,6 +79,7 @@ CASES = [
     (2, 64, 64, 2, 40, 72, 1, 1, 1, True),     # 16x16-tile Winograd kernel (15 tiles vs 20 wide ones), ragged on both axes
     (1, 64, 64, 8, 16, 48, 1, 1, 1, False),    # 16x16-tile Winograd kernel, exact tiling, bare, XCD re-mapping active
     (1, 128, 64, 1, 24, 20, 1, 1, 0, True),    # 16x16 tiles, 128 input channels, width 20 (one partial tile column)
+    (2, 64, 64, 8, 32, 16, 1, 1, 1, True),     # 16x16 tiles, batch 2 x 8 planes: XCD re-mapping with a batch axis
     (1, 64, 8, 3, 10, 40, 1, 1, 1, False),     # 8 output channels: direct MFMA kernel, one channel block
     (2, 64, 16, 1, 5, 24, 1, 1, 1, True),
     (1, 8, 8, 6, 10, 20, 3, 1, 0, True),       # conv3d MFMA
