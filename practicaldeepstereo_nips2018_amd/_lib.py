@@ -167,8 +167,12 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 2   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
+
+
 def load():
-    """Returns the loaded library; raises if it has not been built."""
+    """Returns the loaded library; raises if it has not been built, or if the file on disk is a build of another ABI
+    version (a stale libpds_hip.so would read shifted arguments -- e.g. the ``weights_resident`` flag as the stream)."""
     global _lib
     with _lock:
         if _lib is None:
@@ -178,6 +182,13 @@ def load():
                     '`python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback.'
                     % LIB_PATH)
             lib = ctypes.CDLL(LIB_PATH)
+            lib.pds_abi_version.restype = ctypes.c_int
+            lib.pds_abi_version.argtypes = []
+            found = lib.pds_abi_version()
+            if found != ABI_VERSION:
+                raise RuntimeError(
+                    '%s implements ABI version %d, this package binds version %d: rebuild it with '
+                    '`python -c "import __graft_entry__ as g; g.build()"`' % (LIB_PATH, found, ABI_VERSION))
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype = res
@@ -232,9 +243,71 @@ def gradient_buffers(module):
 
 
 def parameter_signature(module):
-    """Identity and version of every parameter: equal signatures mean equal parameter VALUES (in-place updates by an
-    optimizer or load_state_dict bump ``_version``; re-assignment changes ``data_ptr``)."""
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+    """Identity and version of every parameter, or None when that cannot be established (inference tensors carry no
+    version counter).  Equal signatures mean: same storage, and no in-place update THROUGH THE PARAMETER since (an
+    optimizer step or load_state_dict bumps ``_version``; re-assignment changes ``data_ptr``).  Edits through
+    ``p.data`` (``p.data.copy_()``, EMA swaps, old-style init) do NOT bump it -- which is why the signature is only
+    trusted for modules whose weights the user froze explicitly (``resident_key``)."""
+    signature = []
+    for p in module.parameters():
+        if p.is_inference():
+            return None
+        signature.append((p.data_ptr(), p._version))
+    return tuple(signature)
+
+
+def resident_key(module, parameter_owner, geometry):
+    """Key under which a workspace may keep this module's re-laid-out weights between calls, or None (re-layout on every
+    call -- the default).  Residency is opt-in: ``module.freeze_weights()`` promises that the parameters are not
+    edited behind autograd's back until ``thaw_weights()`` / ``invalidate_weights()``; ``.to()`` / ``.cuda()`` /
+    ``load_state_dict`` / ``train()`` thaw on their own (FrozenWeightsMixin)."""
+    if not getattr(module, '_weights_frozen', False):
+        return None
+    signature = parameter_signature(parameter_owner)
+    if signature is None:
+        return None
+    return (geometry, signature)
+
+
+class FrozenWeightsMixin(object):
+    """Opt-in weight residency of a module that owns a ``Workspace`` (``self._workspace``).
+
+    By default every call re-lays out the weights (a handful of microsecond launches), which is always correct.
+    ``freeze_weights()`` lets the inference entry points skip that while the parameters stay untouched: the key still
+    carries (data_ptr, _version) of every parameter, so optimizer steps, ``load_state_dict`` and re-assignment are
+    seen; writes through ``p.data`` are not, and need ``invalidate_weights()``."""
+
+    _weights_frozen = False
+
+    def freeze_weights(self):
+        self._weights_frozen = True
+        return self
+
+    def thaw_weights(self):
+        self._weights_frozen = False
+        self._workspace.invalidate()
+        return self
+
+    def invalidate_weights(self):
+        """Forget the re-laid-out weights (call after editing parameters through ``.data``); stays frozen."""
+        self._workspace.invalidate()
+        return self
+
+    # nn.Module entry points that replace or rewrite parameters
+    def _apply(self, fn, *args, **kwargs):
+        result = super(FrozenWeightsMixin, self)._apply(fn, *args, **kwargs)
+        self._workspace.invalidate()
+        return result
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # called for every module of the hierarchy a load_state_dict walks (load_state_dict itself only on the root)
+        self._workspace.invalidate()
+        return super(FrozenWeightsMixin, self)._load_from_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        if mode and self._weights_frozen:
+            self.thaw_weights()
+        return super(FrozenWeightsMixin, self).train(mode)
 
 
 class Workspace(object):
@@ -242,9 +315,11 @@ class Workspace(object):
     buffer (stream order makes that safe), calls on different streams -- two pairs in flight -- never share one.
 
     The buffer also holds the module's re-laid-out weights (the arena of an entry point is deterministic), so it
-    remembers what they were made from: ``get(..., key)`` reports ``resident = True`` when the same buffer last
-    served the same ``key`` (call geometry + parameter signature), which lets the entry point skip its weight
-    re-layout launches (``weights_resident`` of include/pds_hip.h)."""
+    can remember what they were made from: ``get_resident(..., key)`` reports ``resident = True`` when the same
+    buffer last COMPLETED a call with the same ``key`` (call geometry + parameter signature), which lets the entry point
+    skip its weight re-layout launches (``weights_resident`` of include/pds_hip.h).  The key is recorded by
+    ``commit(token)`` only after the native call returned success: a call that raised in between (allocation failure,
+    non-zero return code) leaves the slot without a key, so the next call re-lays out."""
 
     MAX_STREAMS = 8   # buffers kept (least recently used first out): streams come and go in a long-lived process
 
@@ -252,24 +327,41 @@ class Workspace(object):
         self._buffers = {}
         self._keys = {}
 
-    def get(self, nbytes, device, key=None):
+    def _buffer(self, nbytes, device):
         slot = (device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = self._buffers.pop(slot, None)
         if buf is None or buf.numel() < nbytes:
             buf = None
-            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self._keys.pop(slot, None)
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         self._buffers[slot] = buf               # most recently used last
         while len(self._buffers) > self.MAX_STREAMS:
             old = next(iter(self._buffers))
             self._buffers.pop(old)
             self._keys.pop(old, None)
-        if key is None:
-            self._keys.pop(slot, None)
-            return buf
-        resident = self._keys.get(slot) == key
-        self._keys[slot] = key
-        return buf, resident
+        return slot, buf
+
+    def get(self, nbytes, device):
+        """Scratch only: whatever weights the buffer held are forgotten."""
+        slot, buf = self._buffer(nbytes, device)
+        self._keys.pop(slot, None)
+        return buf
+
+    def get_resident(self, nbytes, device, key):
+        """-> (buffer, resident, token); pass ``token`` to ``commit`` once the call that used the buffer succeeded."""
+        slot, buf = self._buffer(nbytes, device)
+        previous = self._keys.pop(slot, None)   # recorded again by commit(): a failed call leaves no key behind
+        resident = key is not None and previous == key
+        return buf, resident, (slot, key, buf.data_ptr())
+
+    def commit(self, token):
+        slot, key, address = token
+        buf = self._buffers.get(slot)
+        if key is not None and buf is not None and buf.data_ptr() == address:
+            self._keys[slot] = key
+
+    def invalidate(self):
+        self._keys.clear()
 
 
 def not_differentiable(name):

@@ -28,14 +28,36 @@ def shard_range(number_of_planes, rank, world_size):
 
 
 def _gather_planes_raw(local_planes, group):
+    """[batch, C, D_local, h, w] shards -> [batch, C, world * D_local, h, w], written in its FINAL layout: for every
+    (batch entry, channel) the D_local planes of a rank are one contiguous block, and the world blocks of that
+    (batch entry, channel) are contiguous in rank order -- exactly what ``all_gather_into_tensor`` produces.  So the
+    gather is batch * C collectives on contiguous views of the output (8 at batch 1), issued as ONE coalesced group
+    on RCCL (ncclGroupStart / End: one launch, every rank sends its block straight to its 7 xGMI peers), and no
+    re-layout copy of the 53 MB result runs afterwards (round 2 gathered rank-major and permuted)."""
     local_planes = local_planes.contiguous()
     world_size = dist.get_world_size(group)
     batch, channels, d_local, h, w = local_planes.shape
-    # flat buffers: every backend (RCCL and gloo) accepts "output = world_size x input" along dim 0
-    staged = local_planes.new_empty(world_size * local_planes.numel())
-    dist.all_gather_into_tensor(staged, local_planes.view(-1), group=group)
-    staged = staged.view((world_size,) + tuple(local_planes.shape))
-    return staged.permute(1, 2, 0, 3, 4, 5).reshape(batch, channels, world_size * d_local, h, w)
+    out = local_planes.new_empty((batch, channels, world_size * d_local, h, w))
+    pairs = [(out[b, c].view(-1), local_planes[b, c].view(-1)) for b in range(batch) for c in range(channels)]
+    if local_planes.is_cuda and dist.get_backend(group) == 'nccl' and len(pairs) > 1:
+        from torch.distributed.distributed_c10d import _coalescing_manager
+        with _coalescing_manager(group=group, device=local_planes.device, async_ops=False):
+            for whole, mine in pairs:
+                dist.all_gather_into_tensor(whole, mine, group=group)
+    else:
+        for whole, mine in pairs:
+            dist.all_gather_into_tensor(whole, mine, group=group)
+    return out
+
+
+def gather_description(group=None):
+    """What the bench line records about the collective (config.parallelism): its form and the RCCL knobs in force."""
+    import os
+    knobs = ', '.join('%s=%s' % (k, os.environ[k]) for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS',
+                                                                'NCCL_MAX_NCHANNELS', 'RCCL_MSCCL_ENABLE')
+                      if k in os.environ)
+    return ('batch x 8 all_gather_into_tensor calls on contiguous per-channel views of the [B, 8, D\', h, w] result, '
+            'coalesced into one group (no staging buffer, no re-layout copy); RCCL knobs: %s' % (knobs or 'library defaults'))
 
 
 class _GatherPlanes(torch.autograd.Function):
@@ -76,9 +98,11 @@ class _ReplicatedInput(torch.autograd.Function):
 def gather_planes(local_planes, group=None):
     """All-gathers [batch, C, D_local, h, w] shards along dim 2 in rank order.
 
-    One collective: all_gather_into_tensor into a rank-major staging buffer, then one strided
-    copy into the [batch, C, D, h, w] layout Regularization consumes.  Differentiable: the
-    gradient of a shard is the matching slice of the (replicated) gradient of the gathered tensor."""
+    One coalesced group of collectives straight into the [batch, C, D, h, w] layout Regularization consumes (see
+    ``_gather_planes_raw``).  Differentiable: the gradient of a shard is the matching slice of the gradient of the
+    gathered tensor, which MUST be replicated (identical on every rank) -- i.e. everything after the gather up to
+    the loss has to run on every rank on the same data; a rank-dependent tail (``ShardedHotPath`` runs the tail of
+    pair i on rank i % N only) is an inference schedule and must not be differentiated through."""
     world_size = dist.get_world_size(group)
     if world_size == 1:
         return local_planes
@@ -97,6 +121,8 @@ class ShardedMatching(nn.Module):
     over the ranks on the way out and (iii) the wrapped module's parameter gradients -- partial sums
     over the rank's planes -- are all-reduced by gradient hooks, all in autograd order, identical on
     every rank.  After ``backward()`` every rank holds the full gradients of the unsharded network.
+    PRECONDITION: the computation between the gather and the loss is replicated -- same code, same data on every
+    rank -- so that the gradient arriving at the gather is identical everywhere (it is not checked).
 
     State dict: the wrapper adds no level to the key path (``net._matching = ShardedMatching(net._matching)``
     keeps the reference's ``_matching._operation...`` keys), so reference checkpoints load into, and
@@ -106,7 +132,6 @@ class ShardedMatching(nn.Module):
         super(ShardedMatching, self).__init__()
         self._matching = matching_module
         self._group = group
-        self._hooked = False
         self._register_state_dict_hook(self._strip_wrapper_prefix)
         self._register_load_state_dict_pre_hook(self._add_wrapper_prefix)
 
@@ -127,8 +152,17 @@ class ShardedMatching(nn.Module):
         self._matching.set_maximum_disparity(maximum_disparity)
 
     def _hook_parameter_gradients(self):
-        if self._hooked:
+        """All-reduce hooks on the INNER module's parameters, registered once per (inner module, group): the handles
+        and the group live on the inner module, so wrapping the same Matching again (another wrapper object, or
+        another group) re-uses or replaces them instead of stacking a second all-reduce (which would multiply the
+        gradients by the world size)."""
+        inner = self._matching
+        state = getattr(inner, '_pds_grad_hooks', None)
+        if state is not None and state[0] is self._group:
             return
+        if state is not None:
+            for handle in state[1]:
+                handle.remove()
         group = self._group
 
         def reduce_over_ranks(grad):
@@ -137,9 +171,8 @@ class ShardedMatching(nn.Module):
             grad = grad.contiguous().clone()
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
             return grad
-        for p in self._matching.parameters():
-            p.register_hook(reduce_over_ranks)
-        self._hooked = True
+        handles = [p.register_hook(reduce_over_ranks) for p in inner.parameters()]
+        inner._pds_grad_hooks = (group, handles)
 
     def forward(self, left_embedding, right_embedding):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self._group) == 1:

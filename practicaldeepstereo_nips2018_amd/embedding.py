@@ -17,7 +17,7 @@ from practicaldeepstereo_nips2018_amd import _lib
 from practicaldeepstereo_nips2018_amd import network_blocks
 
 
-class Embedding(nn.Module):
+class Embedding(_lib.FrozenWeightsMixin, nn.Module):
     def __init__(self,
                  number_of_input_features=3,
                  number_of_embedding_features=64,
@@ -96,17 +96,21 @@ class _EmbeddingFunction(torch.autograd.Function):
                                device=image.device)
         nbytes = lib.pds_embedding_workspace_bytes(ctypes.byref(params), batch, h, w, pad_top, pad_left)
         training = any(ctx.needs_input_grad)
+        token = None
         if training:
             ws, resident = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device), False
         else:
-            # the workspace keeps the re-laid-out weights: skipped when it last served these shapes and parameter values
-            ws, resident = module._workspace.get(
-                nbytes, image.device, key=((batch, h, w, pad_top, pad_left), _lib.parameter_signature(module)))
+            # a frozen module's workspace keeps the re-laid-out weights: skipped when it last completed a call with these
+            # shapes and parameter values
+            ws, resident, token = module._workspace.get_resident(
+                nbytes, image.device, _lib.resident_key(module, module, (batch, h, w, pad_top, pad_left)))
         with torch.cuda.device(image.device):
             _lib.check(lib.pds_embedding_fwd(
                 ctypes.byref(params), _lib.ptr(image), _lib.ptr(descriptor), _lib.ptr(shortcut), batch, h, w,
                 pad_top, pad_left, _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(image.device)),
                 'pds_embedding_fwd')
+        if token is not None:
+            module._workspace.commit(token)
         del keep
         if training:
             ctx.module = module

@@ -170,7 +170,7 @@ class _ShiftConcatFunction(torch.autograd.Function):
         return grad_left, grad_right, None, None
 
 
-class Matching(nn.Module):
+class Matching(_lib.FrozenWeightsMixin, nn.Module):
     """Applies ``operation`` to cat([left, right shifted by d]) for d in [0, maximum_disparity]
     and stacks the results on dim 2 (matching.py:16-63)."""
 
@@ -239,14 +239,16 @@ class _FusedMatchingFunction(torch.autograd.Function):
         out = torch.empty((batch, operation.number_of_signature_features, count, h, w),
                           dtype=torch.float32, device=left.device)
         nbytes = lib.pds_matching_workspace_bytes(ctypes.byref(params), batch, h, w, count)
-        # the workspace keeps the re-laid-out weights: skipped when it last served these shapes and parameter values
-        ws, resident = module._workspace.get(nbytes, left.device,
-                                             key=((batch, h, w, count), _lib.parameter_signature(operation)))
+        # a frozen module's workspace keeps the re-laid-out weights: skipped when it last completed a call with these
+        # shapes and parameter values (the key is committed only after the native call succeeded)
+        ws, resident, token = module._workspace.get_resident(
+            nbytes, left.device, _lib.resident_key(module, operation, (batch, h, w, count)))
         with torch.cuda.device(left.device):
             _lib.check(lib.pds_matching_fwd(
                 ctypes.byref(params), _lib.ptr(left), _lib.ptr(right), _lib.ptr(out),
                 batch, h, w, begin, count, _lib.ptr(ws), ws.numel(), int(resident),
                 _lib.stream_handle(left.device)), 'pds_matching_fwd')
+        module._workspace.commit(token)
         del keep
         return out
 

@@ -36,6 +36,21 @@ class PdsNetwork(nn.Module):
         # the embedding downsamples 4x, so Matching covers (max + 1) / 4 planes (network.py:33-36)
         self._matching.set_maximum_disparity((maximum_disparity + 1) // 4 - 1)
 
+    def freeze_weights(self):
+        """Inference deployment: promise that the parameters stay untouched, so the modules keep their re-laid-out
+        weights between calls (``_lib.FrozenWeightsMixin``; not in the reference).  ``train()``, ``.to()`` and
+        ``load_state_dict`` undo it; after editing parameters through ``.data`` call ``invalidate_weights()``."""
+        for module in self.modules():
+            if module is not self and hasattr(module, 'freeze_weights'):
+                module.freeze_weights()
+        return self
+
+    def invalidate_weights(self):
+        for module in self.modules():
+            if module is not self and hasattr(module, 'invalidate_weights'):
+                module.invalidate_weights()
+        return self
+
     def _signatures(self, left_image, right_image):
         left_descriptor, shortcut_from_left = self._embedding(left_image)
         right_descriptor = self._embedding(right_image)[0]

@@ -167,7 +167,7 @@ class _ExpansionFunction(torch.autograd.Function):
         return (None, grad_x, grad_shortcut) + tuple(grads[id(p)] for p in module.parameters())
 
 
-class Regularization(nn.Module):
+class Regularization(_lib.FrozenWeightsMixin, nn.Module):
     """Hourglass 3-D network: /16 contraction, expansion back, then x2 (D, H, W) and x2 (H, W)
     up-sampling; returns matching cost for even disparities (regularization.py:60-126)."""
 
@@ -248,27 +248,36 @@ class _RegularizationFunction(torch.autograd.Function):
         if nbytes == 0:
             raise ValueError(lib.pds_last_error().decode())
         training = any(ctx.needs_input_grad) and estimator_window is None
+        # outputs first: nothing may fail between taking the workspace and the native call
+        if estimator_window is None:
+            out = torch.empty((batch, 2 * d, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
+        else:
+            crop_top, crop_left = estimator_window[2], estimator_window[3]
+            out = torch.empty((batch, 4 * h - crop_top, 4 * w - crop_left), dtype=torch.float32, device=ms.device)
+        token = None
         if training:
             ws, resident = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ms.device), False
         else:
-            # the workspace keeps the re-laid-out weights: skipped when it last served these shapes and parameter values
-            ws, resident = module._workspace.get(
-                nbytes, ms.device, key=((batch, d, h, w, estimator_window is None), _lib.parameter_signature(module)))
+            # a frozen module's workspace keeps the re-laid-out weights: skipped when it last completed a call with
+            # these shapes, this entry point / estimator window (the arena layout of the fused tail depends on the
+            # window: at most 4 taps per side takes the fused trunk) and these parameter values
+            window = None if estimator_window is None else (estimator_window[0], estimator_window[1])
+            ws, resident, token = module._workspace.get_resident(
+                nbytes, ms.device, _lib.resident_key(module, module, (batch, d, h, w, window)))
         with torch.cuda.device(ms.device):
             if estimator_window is None:
-                out = torch.empty((batch, 2 * d, 4 * h, 4 * w), dtype=torch.float32, device=ms.device)
                 _lib.check(lib.pds_regularization_fwd(
                     ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
                     batch, d, h, w, _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(ms.device)),
                     'pds_regularization_fwd')
             else:
-                crop_top, crop_left = estimator_window[2], estimator_window[3]
-                out = torch.empty((batch, 4 * h - crop_top, 4 * w - crop_left), dtype=torch.float32, device=ms.device)
                 _lib.check(lib.pds_regularization_subpixel_map_fwd(
                     ctypes.byref(params), _lib.ptr(ms), _lib.ptr(shortcut), _lib.ptr(out),
                     batch, d, h, w, estimator_window[0], estimator_window[1], crop_top, crop_left,
                     _lib.ptr(ws), ws.numel(), int(resident), _lib.stream_handle(ms.device)),
                     'pds_regularization_subpixel_map_fwd')
+        if token is not None:
+            module._workspace.commit(token)
         if training:
             ctx.module = module
             ctx.forward_workspace = ws

@@ -126,3 +126,78 @@ def test_backward_workspace_planning_succeeds():
     assert lib.pds_contraction_block_bwd_workspace_bytes(1, 8, 16, 16, 16) > 16 * 8 * 8 * 8 * 4
     assert lib.pds_expansion_block_bwd_workspace_bytes(1, 16, 8, 8, 8) > 8 * 16 * 16 * 16 * 4
     del keep
+
+
+def test_stale_library_of_another_abi_version_is_refused(hip_library, monkeypatch):
+    # load() itself must check pds_abi_version() (a stale git-ignored .so would read shifted arguments)
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match='ABI version'):
+        _lib.load()
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION - 1)
+    assert _lib.load().pds_abi_version() == _lib.ABI_VERSION
+
+
+def test_weight_residency_is_opt_in_and_guarded():
+    # not frozen: no key, i.e. the weights are re-laid out on every call (p.data edits are then always seen)
+    net = pds.PdsNetwork.default(63)
+    geometry = (1, 8, 16, 16)
+    assert _lib.resident_key(net._matching, net._matching._operation, geometry) is None
+    net.freeze_weights()
+    assert net._matching._weights_frozen and net._regularization._weights_frozen and net._embedding._weights_frozen
+    key = _lib.resident_key(net._matching, net._matching._operation, geometry)
+    assert key is not None and key == _lib.resident_key(net._matching, net._matching._operation, geometry)
+    with torch.no_grad():
+        next(net._matching.parameters()).mul_(2.0)          # bumps _version: a different key
+    assert _lib.resident_key(net._matching, net._matching._operation, geometry) != key
+    assert _lib.resident_key(net._matching, net._matching._operation, (2, 8, 16, 16)) != key
+    # inference tensors carry no version counter: never resident (and no crash)
+    with torch.inference_mode():
+        frozen = pds.MatchingOperation()
+    holder = pds.Matching(3, frozen).freeze_weights()
+    assert _lib.parameter_signature(frozen) is None
+    assert _lib.resident_key(holder, frozen, geometry) is None
+    # train() thaws; load_state_dict / _apply forget what the workspaces held
+    net.train()
+    assert not net._matching._weights_frozen and not net._regularization._weights_frozen
+    net.eval().freeze_weights()
+    net._regularization._workspace._keys[(0, 0)] = 'stale'
+    net._matching._workspace._keys[(0, 0)] = 'stale'
+    net.load_state_dict(net.state_dict())
+    assert not net._regularization._workspace._keys and not net._matching._workspace._keys
+    net._embedding._workspace._keys[(0, 0)] = 'stale'
+    net.double().float()
+    assert not net._embedding._workspace._keys
+
+
+def test_workspace_commits_its_key_only_after_success(monkeypatch):
+    ws = _lib.Workspace()
+    buffers = {}
+
+    def fake_buffer(nbytes, device):
+        slot = (0, 7)
+        buf = buffers.get(slot)
+        if buf is None or buf.numel() < nbytes:
+            ws._keys.pop(slot, None)
+            buf = buffers[slot] = torch.empty(int(nbytes), dtype=torch.uint8)
+        ws._buffers[slot] = buf
+        return slot, buf
+    monkeypatch.setattr(ws, '_buffer', fake_buffer)
+    buf, resident, token = ws.get_resident(1024, None, 'k1')
+    assert not resident and not ws._keys            # nothing recorded before commit
+    buf, resident, token = ws.get_resident(1024, None, 'k1')
+    assert not resident                              # the first call never committed (it "failed")
+    ws.commit(token)
+    buf, resident, token = ws.get_resident(1024, None, 'k1')
+    assert resident and not ws._keys                 # resident now; the key is out until THIS call commits
+    ws.commit(token)
+    assert ws.get_resident(1024, None, 'k2')[1] is False   # other key
+    buf, resident, token = ws.get_resident(1024, None, 'k1')
+    assert not resident                              # ... and the k2 call never committed
+    ws.commit(token)
+    buf, resident, token = ws.get_resident(4096, None, 'k1')
+    assert not resident                              # a grown buffer holds nothing
+    ws.commit(token)
+    ws.get(1024, None)                               # scratch use forgets the weights
+    assert ws.get_resident(1024, None, 'k1')[1] is False
+    assert ws.get_resident(1024, None, None)[1] is False   # no key: never resident

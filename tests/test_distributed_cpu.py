@@ -209,6 +209,13 @@ def gradient_worker(rank, world, port, results):
         ok = torch.allclose(loss, loss_ref, rtol=1e-5)
         ok = ok and torch.allclose(up, up_ref, rtol=1e-4, atol=1e-5)
         ok = ok and all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(params, params_ref))
+        # wrapping the SAME inner module again (the hooks used to stack, multiplying the parameter
+        # gradients by the world size) leaves one all-reduce per parameter
+        shared = LearnedShardMatching(7, 4)
+        run(pdist.ShardedMatching(shared))
+        loss2, up2, params2 = run(pdist.ShardedMatching(shared))
+        ok = ok and all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(params2, params_ref))
+        ok = ok and len(shared._pds_grad_hooks[1]) == len(list(shared.parameters()))
         # the wrapper adds no level to the state-dict key path (reference checkpoints stay loadable)
         inner = LearnedShardMatching(7, 4)
         wrapped = pdist.ShardedMatching(inner)

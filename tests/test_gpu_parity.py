@@ -11,6 +11,7 @@ import torch
 from oracle import pds_oracle as oracle
 from tests import helpers
 import practicaldeepstereo_nips2018_amd as pds
+from practicaldeepstereo_nips2018_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -474,12 +475,7 @@ def test_stream_pipelines_are_bit_identical(dev):
 
 
 # ----------------------------------------------------------------- weights kept in the workspace between calls
-def test_resident_weights_follow_parameter_updates(dev):
-    """The workspaces keep the re-laid-out weights and skip the packing launches while the parameter values are
-    unchanged (weights_resident of include/pds_hip.h); an in-place update (optimizer step, load_state_dict) must be
-    noticed through the parameters' version counters."""
-    torch.manual_seed(0)
-    net = pds.PdsNetwork.default(63).eval().to(dev)
+def _resident_case(dev):
     g = torch.Generator().manual_seed(5)
     left = torch.randn(1, 64, 32, 64, generator=g).to(dev)
     right = torch.randn(1, 64, 32, 64, generator=g).to(dev)
@@ -489,6 +485,21 @@ def test_resident_weights_follow_parameter_updates(dev):
         ms = n._matching(left, right)
         return ms, n._regularization.forward_with_estimator(ms, shortcut, n._estimator)
 
+    def expected_of(n):
+        fresh = pds.PdsNetwork.default(63).eval().to(dev)   # a module that has never packed anything
+        fresh.load_state_dict(n.state_dict())
+        return run(fresh)
+    return run, expected_of
+
+
+def test_resident_weights_follow_parameter_updates(dev):
+    """A frozen network's workspaces keep the re-laid-out weights and skip the packing launches while the parameter
+    values are unchanged (weights_resident of include/pds_hip.h); in-place updates through the parameters (optimizer
+    step, load_state_dict) are noticed through their version counters, edits through ``.data`` after
+    ``invalidate_weights()``."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(63).eval().to(dev).freeze_weights()
+    run, expected_of = _resident_case(dev)
     with torch.no_grad():
         first = run(net)
         again = run(net)            # second call: packing skipped
@@ -496,11 +507,75 @@ def test_resident_weights_follow_parameter_updates(dev):
         for p in net.parameters():  # in-place update bumps p._version
             p.mul_(1.01)
         updated = run(net)
-        fresh = pds.PdsNetwork.default(63).eval().to(dev)
-        fresh.load_state_dict(net.state_dict())
-        expected = run(fresh)       # a module that has never packed anything
-    assert not torch.equal(updated[0], first[0])
-    assert torch.equal(updated[0], expected[0]) and torch.equal(updated[1], expected[1])
+        expected = expected_of(net)
+        assert not torch.equal(updated[0], first[0])
+        assert torch.equal(updated[0], expected[0]) and torch.equal(updated[1], expected[1])
+        # an edit behind autograd's back (EMA swap, old-style init): no version bump, so the frozen module must be told
+        for p in net.parameters():
+            p.data.copy_(p.data * 0.97)
+        net.invalidate_weights()
+        swapped = run(net)
+        expected = expected_of(net)
+        assert not torch.equal(swapped[0], updated[0])
+        assert torch.equal(swapped[0], expected[0]) and torch.equal(swapped[1], expected[1])
+        # load_state_dict and .to() invalidate on their own
+        state = {k: v * 1.02 for k, v in net.state_dict().items()}
+        net.load_state_dict(state)
+        loaded = run(net)
+        expected = expected_of(net)
+        assert torch.equal(loaded[0], expected[0]) and torch.equal(loaded[1], expected[1])
+
+
+def test_unfrozen_modules_always_repack(dev):
+    """Default (not frozen): the weights are re-laid out on every call, so ``p.data.copy_()`` -- which no version
+    counter sees -- takes effect immediately; and train() thaws a frozen network."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(63).eval().to(dev)
+    run, expected_of = _resident_case(dev)
+    with torch.no_grad():
+        first = run(net)
+        for p in net.parameters():
+            p.data.copy_(p.data * 1.03)
+        edited = run(net)
+        expected = expected_of(net)
+        assert not torch.equal(edited[0], first[0])
+        assert torch.equal(edited[0], expected[0]) and torch.equal(edited[1], expected[1])
+        net.freeze_weights()
+        run(net)
+        net.train()
+        assert not net._matching._weights_frozen and not net._regularization._weights_frozen
+        net.eval()
+        for p in net.parameters():
+            p.data.copy_(p.data * 0.99)
+        thawed = run(net)
+        expected = expected_of(net)
+        assert torch.equal(thawed[0], expected[0]) and torch.equal(thawed[1], expected[1])
+
+
+def test_failed_call_leaves_no_resident_key(dev):
+    """The residency key is committed only after the native call succeeded: a call that raised in between (here: a
+    left/right shape the entry point refuses) must not make the next call skip its weight re-layout."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(63).eval().to(dev).freeze_weights()
+    run, expected_of = _resident_case(dev)
+    matching = net._matching
+    with torch.no_grad():
+        good = run(net)
+        slot_keys = dict(matching._workspace._keys)
+        assert slot_keys, 'a frozen module records its key after a successful call'
+        original = _lib.check
+
+        def failing(rc, what):
+            raise RuntimeError('injected failure in %s' % what)
+        _lib.check = failing
+        try:
+            with pytest.raises(RuntimeError):
+                run(net)
+        finally:
+            _lib.check = original
+        assert not matching._workspace._keys, 'the failed call must leave no key behind'
+        again = run(net)
+    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
 
 
 def test_unpad_is_folded_into_the_estimator_store(dev):
