@@ -43,6 +43,10 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s);        // conv2d_wino
 bool conv2d_wino_eligible(const ConvLayer& L);
 int conv2d_wino_tiles(const Geom& out_g);
 size_t conv2d_wino_packed_floats(int cin, int cout);
+int launch_conv2d_x3(const ConvLayer& L, hipStream_t s);          // conv2d_x3.hip (Cin -> 64, fp32 on the bf16 pipe)
+bool conv2d_x3_supported(const ConvLayer& L);
+int conv2d_x3_tiles(const Geom& out_g);
+size_t conv2d_x3_packed_floats(int cin);
 int launch_conv2d_t8(const ConvLayer& L, hipStream_t s);          // conv2d_t8.hip (64 -> 8 channels, bare)
 bool conv2d_t8_supported(const ConvLayer& L);
 int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma.hip
@@ -292,9 +296,10 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.plane_weight_sets = extra->plane_weight_sets;
     }
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
-    // Winograd domain (plain single-source Cin -> 64 layers)
+    // Winograd domain (plain single-source Cin -> 64 layers), 9 = conv2d on the bf16 pipe with three-way split operands
     int kind = 0;
     if (allow_mfma && !norm && !c.tape && conv2d_t8_supported(L)) kind = 8;   // persistent y-Toeplitz kernel, no packing
+    else if (allow_mfma && !(extra && extra->matching_extras()) && conv2d_x3_supported(L)) kind = 9;
     else if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino_eligible(L) ? 4 : 2;
     else if (allow_mfma && conv3d_t8_supported(L)) kind = 6;   // persistent z-Toeplitz kernel, no weight packing
     else if (allow_mfma && conv3d_ks_supported(L)) kind = 7;   // inner levels: K split over the waves
@@ -305,7 +310,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
-    if (L.out_batch_channels && kind != 4) {
+    if (kind == 9) L.packed = c.get<float>(conv2d_x3_packed_floats(in.c));
+    if (L.out_batch_channels && kind != 4 && kind != 9) {
         c.run(set_error(-1, "conv_block: a channel-slice output needs the Winograd kernel"));
         return o;
     }
@@ -319,7 +325,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
                                      : kind == 3 ? launch_conv3d_mfma(L, c.s)
                                                  : kind == 6 ? launch_conv3d_t8(L, c.s)
                                                              : kind == 7 ? launch_conv3d_ks(L, c.s)
-                                                                         : kind == 8 ? launch_conv2d_t8(L, c.s) : launch_conv_direct(L, c.s);
+                                                                         : kind == 8 ? launch_conv2d_t8(L, c.s)
+                                                                                     : kind == 9 ? launch_conv2d_x3(L, c.s) : launch_conv_direct(L, c.s);
     };
     const bool collecting = c.sink && c.sink->phase == kPackCollect && c.base != nullptr;
     if (collecting && kind != 0 && kind != 6 && kind != 8) c.run(launch());  // registers the pack job(s) only
@@ -327,6 +334,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
                                     : kind == 4 ? conv2d_wino_tiles(o.g)
+                                    : kind == 9 ? conv2d_x3_tiles(o.g)
                                     : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride)
                                     : kind == 6 ? conv3d_t8_records(o.g)
                                     : kind == 7 ? conv3d_ks_tiles(o.g) : conv_direct_tiles_for(o.g, stride);

@@ -1,0 +1,641 @@
+// conv2d 3x3 (pad 1, stride 1), Cin -> 64 channels over all (batch, disparity) planes in one launch, with fp32
+// operands emulated on the bf16 matrix pipe: the dominant layers of MatchingOperation (reference
+// practical_deep_stereo/matching.py:85-88, network_blocks.py:134-144; also the 64-channel layers of embedding.py).
+//
+// Arithmetic.  gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 MFMA rate, so the exact-fp32 Winograd kernel
+// (conv2d_wino16.hip) is pipe-bound at ~106 executed TFLOP/s.  Here every fp32 operand is split three ways into bf16,
+//     a = a1 + a2 + a3  (exact: 3 x 8 significand bits),        b = b1 + b2 + b3,
+// and the product is accumulated as the six partial products of order <= 2^-16,
+//     a*b ~= a1*b1 + a1*b2 + a2*b1 + a2*b2 + a1*b3 + a3*b1     (dropped: a2*b3 + a3*b2 + a3*b3 <= 2^-23 |a*b|),
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Measured on an MI355X
+// (tools/ubench/bf16x3_probe.hip, K = 576 as in this layer): mean |error| 2.4e-7 against 3.1e-7 of the fp32 fmaf chain
+// -- the emulation is not a precision trade (fewer, wider-accumulated roundings), and it is range-safe (bf16 has the
+// fp32 exponent).  Six bf16 MFMAs do the work of eight fp32 ones at 16x the rate: 2.7x the fp32 pipe's peak; the bare
+// MFMA stream sustains 323 fp32-equivalent TFLOP/s on random data (power-limited clock), 0.38 ms for this layer's
+// 122.3 GFLOP at config 2.  Weights are split once (round-to-nearest, pack.hip mode 6), activations while they are
+// staged (truncation split: and / sub / and / sub, then v_perm packs two channels per dword).
+//
+// Shape.  One persistent 512-thread workgroup per CU (all of its LDS) pulls 16 x 32-pixel tiles of one plane from eight
+// per-XCD queues (atomic counters; planes stay on one XCD's L2, idle workgroups steal).  A tile is a GEMM
+// [512 px] x [64 oc] x [K = Cin * 9] with the PIXELS on the M side, and the waves are specialised:
+//   waves 0-3   MFMA waves, one per SIMD: wave w owns rows 4w .. 4w+3 of the tile (four M blocks of one row x 32
+//               columns) and all 64 output channels (two N blocks): 4 x 2 accumulator tiles of 32 x 32 = 128 VGPRs.
+//               They only read fragments (ds_read_b128, double-buffered by half-taps) and issue MFMAs: per tap
+//               12 pixel + 12 weight fragments feed 48 MFMAs.  In the D fragment a lane holds one output channel
+//               and FOUR CONSECUTIVE pixels per register quad, so the epilogue stores 16 bytes per lane and the
+//               InstanceNorm statistics are sums over a lane's own registers (plus one lane exchange).
+//               Tiles whose right half lies outside the image (240 = 7.5 x 32) map their M blocks to 2 rows x 16
+//               columns instead: two M blocks per wave, half the MFMAs, none spent off the plane.
+//   waves 4-7   staging waves, one per SIMD: global loads, the deferred InstanceNorm of the producer, the bf16 split
+//               and the LDS writes run beside the MFMA waves' matrix work (separate pipes, the hardware interleaves
+//               the waves); they also draw the next tile and fold the statistics records.
+//   K-step      16 input channels; stage = (K-step, dy) = 3 taps, one barrier per stage (144 MFMAs per MFMA wave).
+//   LDS         inputs  IN[2][part 3][channel group 2][18 rows][34 columns][8 bf16]   2 x 58 752 B, written once per
+//               K-step and read by all nine taps; a lane's fragment is one 16-byte slot and the 32 lanes of an M block
+//               read 32 consecutive slots (conflict free for any row);
+//               weights W[2][dx 3][part 3][N block 2][64 lanes][16 B]                  2 x 18 432 B per stage, in
+//               fragment order (lane-linear reads).
+//   staging     one stage ahead: what was requested during stage s-1 is converted and written during stage s (inputs
+//               of the next K-step by thirds, weights of stage s+1), then the next requests are issued; the sequence
+//               runs across tile boundaries (the next tile is drawn at stage 0), so a CU never drains between tiles.
+//   epilogue    bias, LeakyReLU, float4 stores, per-(plane, channel) sum / sum of squares -> one fp64 record per tile
+//               (the deferred InstanceNorm of common.hpp), folded by the staging waves during the next tile.
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int TH = 16, TW = 32, ROWS = TH + 2, COLS = TW + 2, PIX = ROWS * COLS;   // halo tile 18 x 34 = 612 pixels
+constexpr int THREADS = 512, STAGERS = 256;
+constexpr int IN_PART = 2 * PIX * 16;          // bytes of one split part: [channel group][row][column][8 bf16]
+constexpr int IN_BUF = 3 * IN_PART;            // 58 752
+constexpr int W_FRAG = 64 * 16;                // one B fragment
+constexpr int W_STAGE = 3 * 3 * 2 * W_FRAG;    // [dx][part][N block]: 18 432
+constexpr int LDS_W = 2 * IN_BUF;
+constexpr int LDS_RED = LDS_W + 2 * W_STAGE;   // [4 MFMA waves][64 channels][2] floats
+constexpr int LDS_NEXT = LDS_RED + 4 * 64 * 2 * 4;
+constexpr int CMAX = 256;                      // most input channels with a deferred InstanceNorm on the input
+constexpr int LDS_COEF = LDS_NEXT + 16;        // [tile parity 2][scale | shift][CMAX] floats
+constexpr int LDS_BYTES = LDS_COEF + 2 * 2 * CMAX * 4;
+constexpr int THIRD_ROWS = ROWS / 3, THIRD_PIX = THIRD_ROWS * COLS;   // 204 staging items per channel group and third
+constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;       // 16-byte pieces of a weight stage per stager: 5
+static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+static_assert(THIRD_PIX <= STAGERS, "one item per staging thread and channel group");
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct X3Args {
+    Src a;
+    const unsigned char* __restrict__ wpk;   // [stage = kstep * 3 + dy][W_STAGE bytes]
+    const float* __restrict__ bias;
+    float* __restrict__ out;
+    double* __restrict__ partials;
+    int* __restrict__ queue;                  // 8 counters, zeroed before the launch
+    int N, Cin, D, H, W, Cout;
+    int CoutStride;                           // channels per batch entry of the output tensor (>= Cout)
+    int lrelu;
+    int tiles_x, tiles_y, tiles;              // per plane
+    int tiles_x_full;                         // tile columns whose right half is inside the image
+    int planes;                               // N * D
+    int nks;                                  // Cin / 16
+};
+
+struct Tile {
+    int n, d, tile, y0, x0;
+};
+
+// One lane draws the next tile: its home queue first, then the others (work stealing).  Virtual tile id =
+// plane * tiles + tile, or -1 when every queue is empty.  Queue q holds the planes p = q (mod 8): all their full tiles
+// (plane-major, row-major), then the tiles whose right half lies outside the image.
+__device__ __forceinline__ int draw_tile(int* queue, int home, int planes, int tiles, int tiles_x, int tiles_x_full,
+                                         int n_full) {
+    const int n_half = tiles - n_full;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int q = (home + attempt) & 7;
+        const int planes_q = (planes - q + 7) >> 3;
+        if (planes_q <= 0) continue;
+        const int j = atomicAdd(queue + q, 1);
+        if (j >= planes_q * tiles) continue;
+        int pl, tile;
+        if (j < planes_q * n_full) {
+            pl = j / n_full;
+            const int r = j - pl * n_full;
+            const int ty = r / tiles_x_full;
+            tile = ty * tiles_x + (r - ty * tiles_x_full);
+        } else {
+            const int r = j - planes_q * n_full;
+            pl = r / n_half;
+            const int rr = r - pl * n_half;
+            const int cols_half = tiles_x - tiles_x_full;
+            const int ty = rr / cols_half;
+            tile = ty * tiles_x + tiles_x_full + (rr - ty * cols_half);
+        }
+        return (q + 8 * pl) * tiles + tile;
+    }
+    return -1;
+}
+
+// The MFMAs of one stage (K-step, kernel row): three taps x NMB M blocks = steps of 12 MFMAs (two N blocks x six partial
+// products).  Fragments are double-buffered at two rates: the six weight fragments of a tap are requested, a pair per
+// step, during the previous tap; the three pixel fragments of an M block during the previous step.  A scheduling
+// barrier closes every step, so the requests of step k + 1 are in flight while the MFMAs of step k issue and the
+// compiler cannot pile up more fragments than the two sets (128 accumulator + 72 fragment registers).
+// xb: the lane's pixel slot of M block 0 at (dy, dx = 0) in part 0; wb: the lane's slot in the stage's weights.
+// NARROW: M blocks are 2 rows x 16 columns and there are two of them.
+// scheduling pattern of a step: N x (one MFMA, one fragment request), then the remaining MFMAs
+template <int N>
+__device__ __forceinline__ void x3_interleave() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        x3_interleave<N - 1>();
+    }
+}
+
+template <bool NARROW, int T, int I>
+__device__ __forceinline__ void x3_step(f32x16 (&acc)[4][2], bf16x8 (&fw)[2][3][2], bf16x8 (&fp)[2][3],
+                                        const unsigned char* xb, const unsigned char* wb) {
+    constexpr int NMB = NARROW ? 2 : 4;
+    constexpr int K = T * NMB + I;
+    constexpr int ROWSTEP = NARROW ? 2 : 1;
+    // requests: pixel fragments of the next step ...
+    if constexpr (I + 1 < NMB || T < 2) {
+        constexpr int tn = I + 1 < NMB ? T : T + 1, in = I + 1 < NMB ? I + 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            fp[(K + 1) & 1][p] =
+                *reinterpret_cast<const bf16x8*>(xb + p * IN_PART + (in * ROWSTEP * COLS + tn) * 16);
+    }
+    // ... and this step's share of the next tap's weight fragments (parts 0, 1, 2 over the first steps of the tap)
+    if constexpr (T < 2) {
+        constexpr int first = NARROW ? (I == 0 ? 0 : 2) : I, last = NARROW ? (I == 0 ? 1 : 2) : (I < 3 ? I : -1);
+#pragma unroll
+        for (int p = first; p <= last; ++p)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                fw[(T + 1) & 1][p][nb] =
+                    *reinterpret_cast<const bf16x8*>(wb + (((T + 1) * 3 + p) * 2 + nb) * W_FRAG);
+    }
+    // small partial products first
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int pa = c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 1 : 0;   // pixel part
+        const int pb = c == 0 ? 2 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 1 : c == 4 ? 0 : 0;   // weight part
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            acc[I][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[K & 1][pa], fw[T & 1][pb][nb], acc[I][nb], 0, 0, 0);
+    }
+    // the requests go out in the shadow of the first MFMAs (each on registers of the idle set), not after the last use
+    // of the registers they would otherwise recycle
+    constexpr int NP = (I + 1 < NMB || T < 2) ? 3 : 0;
+    constexpr int NW = T < 2 ? (NARROW ? (I == 0 ? 4 : 2) : (I < 3 ? 2 : 0)) : 0;
+    x3_interleave<NP + NW>();
+    __builtin_amdgcn_sched_group_barrier(0x008, 12 - NP - NW, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool NARROW>
+__device__ __forceinline__ void x3_mfma_stage(f32x16 (&acc)[4][2], const unsigned char* xb, const unsigned char* wb) {
+    bf16x8 fw[2][3][2], fp[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        fp[0][p] = *reinterpret_cast<const bf16x8*>(xb + p * IN_PART);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) fw[0][p][nb] = *reinterpret_cast<const bf16x8*>(wb + (p * 2 + nb) * W_FRAG);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#define PDS_X3_TAP(T)                                         \
+    x3_step<NARROW, T, 0>(acc, fw, fp, xb, wb);               \
+    x3_step<NARROW, T, 1>(acc, fw, fp, xb, wb);               \
+    if constexpr (!NARROW) {                                  \
+        x3_step<NARROW, T, 2>(acc, fw, fp, xb, wb);           \
+        x3_step<NARROW, T, 3>(acc, fw, fp, xb, wb);           \
+    }
+    PDS_X3_TAP(0)
+    PDS_X3_TAP(1)
+    PDS_X3_TAP(2)
+#undef PDS_X3_TAP
+}
+
+__device__ __forceinline__ Tile decode_tile(const X3Args& A, int v) {
+    Tile t;
+    const int p = v / A.tiles;
+    t.tile = v - p * A.tiles;
+    t.n = p / A.D;
+    t.d = p - t.n * A.D;
+    const int ty = t.tile / A.tiles_x;
+    t.y0 = ty * TH;
+    t.x0 = (t.tile - ty * A.tiles_x) * TW;
+    return t;
+}
+__device__ __forceinline__ Tile pick_tile(bool second, const Tile& b, const Tile& a) {   // uniform selects, no branch
+    Tile t;
+    t.n = second ? b.n : a.n;
+    t.d = second ? b.d : a.d;
+    t.tile = second ? b.tile : a.tile;
+    t.y0 = second ? b.y0 : a.y0;
+    t.x0 = second ? b.x0 : a.x0;
+    return t;
+}
+
+// Both roles walk the same sequence of tiles and stages and meet at the same barriers (three in the prologue, one per
+// stage, one before the last statistics record); each is a loop nest of its own so that the accumulators of the MFMA
+// waves and the staging registers of the others never share a live range.
+
+// ---- waves 0-3 -----------------------------------------------------------------------------------------------------
+struct MfmaLane {
+    int wave, m32, kgl;
+    int x_lane, w_lane;      // byte offsets of the lane's pixel slot (M block 0, dy = dx = 0, part 0) and weight slot
+    float bias0, bias1;
+    unsigned cstride;
+    size_t plane;
+};
+
+// One tile on an MFMA wave: all stages, then the epilogue.  The accumulators live and die inside this function, per
+// variant, so they never cross a control-flow merge (a phi of 128 registers costs copies and their live ranges).
+// Returns the id of the next tile (read at stage 1).
+template <bool NARROW>
+__device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds, const MfmaLane& L, const Tile& cur,
+                                            int& upar, int& wpar) {
+    const int nstages = 3 * A.nks;
+    const int* next_slot = reinterpret_cast<const int*>(lds + LDS_NEXT);
+    int nxt_id = -1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+#pragma unroll 1
+    for (int rs = 0; rs < nstages; ++rs) {
+        const int dy = rs % 3;
+        if (rs == 1) nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
+        const unsigned char* wb = lds + LDS_W + wpar * W_STAGE + L.w_lane;
+        const unsigned char* xb = lds + upar * IN_BUF + dy * (COLS * 16) + L.x_lane;
+        x3_mfma_stage<NARROW>(acc, xb, wb);
+        if (dy == 2) upar ^= 1;
+        wpar ^= 1;
+        __syncthreads();
+    }
+    // ---- epilogue of the tile: bias, LeakyReLU, 16-byte stores, statistics
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    float* obase = A.out + (((size_t)cur.n * A.CoutStride) * A.D + cur.d) * L.plane;   // uniform
+    const bool vec = (A.W & 3) == 0;
+    constexpr int MBLOCKS = NARROW ? 2 : 4;
+#pragma unroll
+    for (int mb = 0; mb < MBLOCKS; ++mb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m0 = 8 * g + 4 * L.kgl;   // first of the lane's four consecutive pixels of the M block
+            const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (m0 >> 4) : mb);
+            const int x = cur.x0 + (NARROW ? (m0 & 15) : m0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const float bv = nb ? L.bias1 : L.bias0;
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t[e] = acc[mb][nb][4 * g + e] + bv;
+                    if (A.lrelu) t[e] = t[e] > 0.f ? t[e] : t[e] * kLeakySlope;
+                }
+                float* po = obase + (size_t)(nb * 32 + L.m32) * L.cstride + (size_t)y * A.W + x;
+                float ls = 0.f, lq = 0.f;
+                if (y < A.H) {
+                    if (vec) {
+                        if (x < A.W) {
+                            *reinterpret_cast<f32x4*>(po) = f32x4{t[0], t[1], t[2], t[3]};
+                            ls = (t[0] + t[1]) + (t[2] + t[3]);
+                            lq = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], t[3] * t[3])));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (x + e < A.W) {
+                                po[e] = t[e];
+                                ls += t[e];
+                                lq = fmaf(t[e], t[e], lq);
+                            }
+                    }
+                }
+                if (nb) {
+                    s1 += ls;
+                    q1 += lq;
+                } else {
+                    s0 += ls;
+                    q0 += lq;
+                }
+            }
+        }
+    }
+    if (A.partials) {
+        // the two halves of the wave hold the same channels (pixels 4 apart): one exchange, then lanes 0-31 write
+        s0 += __shfl_xor(s0, 32, 64);
+        q0 += __shfl_xor(q0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        q1 += __shfl_xor(q1, 32, 64);
+        if (L.kgl == 0) {
+            float* red = reinterpret_cast<float*>(lds + LDS_RED);
+            *reinterpret_cast<float2*>(red + (L.wave * 64 + L.m32) * 2) = make_float2(s0, q0);
+            *reinterpret_cast<float2*>(red + (L.wave * 64 + 32 + L.m32) * 2) = make_float2(s1, q1);
+        }
+    }
+    return nxt_id;
+}
+
+__device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* lds, int wave, int lane, int cur_id) {
+    MfmaLane L;
+    L.wave = wave;
+    L.m32 = lane & 31;
+    L.kgl = lane >> 5;
+    L.w_lane = lane * 16;
+    L.plane = (size_t)A.H * A.W;
+    L.cstride = (unsigned)(A.D * L.plane);
+    L.bias0 = A.bias ? A.bias[L.m32] : 0.f;
+    L.bias1 = A.bias ? A.bias[32 + L.m32] : 0.f;
+    const int x_full = (L.kgl * PIX + (4 * wave) * COLS + L.m32) * 16;                            // M block = row, 32 columns
+    const int x_narrow = (L.kgl * PIX + (4 * wave + (L.m32 >> 4)) * COLS + (L.m32 & 15)) * 16;    // M block = 2 rows x 16
+    int upar = 0, wpar = 0;   // LDS buffer of the K-step / weight stage being consumed
+    __syncthreads();
+    __syncthreads();
+    for (;;) {
+        const Tile cur = decode_tile(A, cur_id);
+        if (cur.x0 + 16 >= A.W) {   // the right half of the tile is outside the image (uniform)
+            L.x_lane = x_narrow;
+            cur_id = x3_mfma_tile<true>(A, lds, L, cur, upar, wpar);
+        } else {
+            L.x_lane = x_full;
+            cur_id = x3_mfma_tile<false>(A, lds, L, cur, upar, wpar);
+        }
+        if (cur_id < 0) break;
+    }
+    __syncthreads();
+}
+
+// ---- waves 4-7 -----------------------------------------------------------------------------------------------------
+template <bool NORM>
+__device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char* lds, int st, int cur_id) {
+    const size_t plane = (size_t)A.H * A.W;
+    const unsigned cstride = (unsigned)(A.D * plane);          // floats between channels
+    const int nks = A.nks, nstages = 3 * nks;
+    // one pixel x 16 channels per thread and third of a K-step (two items of 8 channels: the two channel groups)
+    const bool stager = st < THIRD_PIX;
+    const int lrow = stager ? st / COLS : 0, lcol = stager ? st % COLS : 0;
+    const int lds_item = (lrow * COLS + lcol) * 16;     // + (part * 2 + group) * PIX * 16 + third * THIRD_PIX * 16
+    int* next_slot = reinterpret_cast<int*>(lds + LDS_NEXT);
+    const int home = blockIdx.x & 7;
+    const int n_full = A.tiles_y * A.tiles_x_full;
+
+    float xin[2][8];     // the pixel's two items requested during the previous stage
+    u32x4 win[W_ITERS];  // this thread's pieces of the weight stage requested during the previous stage
+    const int wlast = W_STAGE / 16 - 1;
+    float* coef_tab = reinterpret_cast<float*>(lds + LDS_COEF);
+
+    auto request_inputs = [&](const Tile& t, int ks, int third) {
+        const int y = t.y0 - 1 + third * THIRD_ROWS + lrow, x = t.x0 - 1 + lcol;
+        const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
+        const float* src = A.a.p + ((size_t)(t.n * A.Cin + ks * 16) * A.D + t.d) * plane;   // uniform
+        const unsigned off = (unsigned)(yc * A.W + xc);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xin[g][i] = src[off + (unsigned)(g * 8 + i) * cstride];
+    };
+    auto write_inputs = [&](const Tile& t, int ks, int third, unsigned char* buf, const float* coef) {
+        const int y = t.y0 - 1 + third * THIRD_ROWS + lrow, x = t.x0 - 1 + lcol;
+        const bool inimg = y >= 0 && y < A.H && x >= 0 && x < A.W;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float v[8];
+            if (NORM) {
+                // the producer's folded InstanceNorm of this (batch entry, plane): table of the tile in LDS, one
+                // address per wave (broadcast reads)
+                const f32x4* ps = reinterpret_cast<const f32x4*>(coef + ks * 16 + g * 8);
+                const f32x4* ph = reinterpret_cast<const f32x4*>(coef + CMAX + ks * 16 + g * 8);
+                const f32x4 s0 = ps[0], s1 = ps[1], h0 = ph[0], h1 = ph[1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = fmaf(s0[i], xin[g][i], h0[i]);
+                    v[4 + i] = fmaf(s1[i], xin[g][4 + i], h1[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = xin[g][i];
+            }
+            // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
+            unsigned h[3][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float r = inimg ? v[i] : 0.f;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned u = __builtin_bit_cast(unsigned, r);
+                    h[p][i] = u;
+                    if (p < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
+                }
+            }
+            if (stager) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    u32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)   // bytes [3:2] of the odd channel above bytes [3:2] of the even one
+                        w[j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
+                    *reinterpret_cast<u32x4*>(buf + (p * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = w;
+                }
+            }
+        }
+    };
+    // folded InstanceNorm coefficients of a tile's (batch entry, plane): requested for the NEXT tile at every stage,
+    // written into the other table during the following one (branch-free; redundant writes carry equal values)
+    float coef_s = 1.f, coef_h = 0.f;
+    const int coef_c = min(st, A.Cin - 1);
+    auto request_coef = [&](const Tile& t) {
+        if (NORM) {
+            const size_t g = A.a.per_plane ? ((size_t)(t.n * A.Cin + coef_c) * A.D + t.d) : (size_t)(t.n * A.Cin + coef_c);
+            coef_s = A.a.scale[g];
+            coef_h = A.a.shift[g];
+        }
+    };
+    auto write_coef = [&](int table) {
+        if (NORM) {
+            coef_tab[table * 2 * CMAX + coef_c] = coef_s;
+            coef_tab[table * 2 * CMAX + CMAX + coef_c] = coef_h;
+        }
+    };
+    auto request_weights = [&](int stage) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(A.wpk + (size_t)stage * W_STAGE);
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) win[it] = src[min(it * STAGERS + st, wlast)];
+    };
+    auto write_weights = [&](unsigned char* buf) {
+        u32x4* dst = reinterpret_cast<u32x4*>(buf);
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) dst[min(it * STAGERS + st, wlast)] = win[it];
+    };
+    // one fp64 (sum, sum of squares) record per tile and channel from the four MFMA waves' rows
+    auto fold_statistics = [&](const Tile& t) {
+        if (A.partials && st < 128) {
+            const float* red = reinterpret_cast<const float*>(lds + LDS_RED);
+            const int oc = st >> 1, k = st & 1;
+            double v = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) v += (double)red[(wv * 64 + oc) * 2 + k];
+            A.partials[((((size_t)t.n * A.Cout + oc) * A.D + t.d) * A.tiles + t.tile) * 2 + k] = v;
+        }
+    };
+
+    // ---- prologue: the first tile's coefficient table, first K-step and weight stage; requests of what stage 0 writes
+    Tile cur = decode_tile(A, cur_id);
+    Tile nxt = cur, done = cur;
+    int nxt_id = -1;
+    int tpar = 0;             // coefficient table of the current tile
+    request_coef(cur);
+    write_coef(0);
+    request_weights(0);
+    write_weights(lds + LDS_W);
+    __syncthreads();
+    for (int third = 0; third < 3; ++third) {
+        request_inputs(cur, 0, third);
+        write_inputs(cur, 0, third, lds, coef_tab);
+    }
+    request_weights(1);
+    request_inputs(cur, 1, 0);
+    request_coef(cur);
+    int upar = 0, wpar = 0;   // LDS buffer of the K-step / weight stage being consumed
+    bool fold_pending = false;
+    __syncthreads();
+
+    for (;;) {
+        for (int rs = 0; rs < nstages; ++rs) {
+            const int ks = rs / 3, dy = rs - 3 * ks;
+            if (rs == 1) {   // the tile drawn during stage 0 (published by its barrier)
+                nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
+                if (nxt_id >= 0) nxt = decode_tile(A, nxt_id);
+            }
+            // -- write what stage rs - 1 requested: third (rs % 3) of K-step ks + 1 and weight stage rs + 1.
+            // No branch stands around a request or its use (a phi of loaded values makes the compiler wait for
+            // the loads where the branches merge): past the last tile the sequence re-stages the current tile
+            // into the idle buffer, which nobody reads.
+            {
+                const bool into_next = ks + 1 >= nks;
+                write_inputs(pick_tile(into_next, nxt, cur), into_next ? 0 : ks + 1, dy, lds + (upar ^ 1) * IN_BUF,
+                             coef_tab + ((into_next ? tpar ^ 1 : tpar) * 2 * CMAX));
+                write_weights(lds + LDS_W + (wpar ^ 1) * W_STAGE);
+                write_coef(tpar ^ 1);
+            }
+            // -- requests: sequence position rs + 4 (K-step, third) and weight stage rs + 2
+            {
+                const int q = rs + 4;
+                const int ksl = q / 3, third = q - 3 * ksl;
+                const bool into_next = ksl >= nks;
+                request_inputs(pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
+                int ws = rs + 2;
+                if (ws >= nstages) ws -= nstages;
+                request_weights(ws);
+                request_coef(nxt);
+            }
+            // -- housekeeping with the staging waves' spare time
+            if (rs == 0 && st == 0)
+                next_slot[0] = draw_tile(A.queue, home, A.planes, A.tiles, A.tiles_x, A.tiles_x_full, n_full);
+            if (rs == 1 && fold_pending) fold_statistics(done);
+            if (dy == 2) upar ^= 1;
+            wpar ^= 1;
+            __syncthreads();
+        }
+        done = cur;
+        fold_pending = true;
+        if (nxt_id < 0) break;
+        cur = nxt;   // (nxt stays a valid tile -- this one -- until the next draw is read at stage 1)
+        nxt_id = -1;
+        tpar ^= 1;
+    }
+    __syncthreads();
+    fold_statistics(done);
+}
+
+}  // namespace
+
+template <bool NORM>
+__global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int* next_slot = reinterpret_cast<int*>(lds + LDS_NEXT);
+    if (tid == STAGERS)
+        next_slot[0] = draw_tile(A.queue, blockIdx.x & 7, A.planes, A.tiles, A.tiles_x, A.tiles_x_full,
+                                 A.tiles_y * A.tiles_x_full);
+    __syncthreads();
+    const int cur_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
+    if (cur_id < 0) return;
+    if (wave < 4) x3_mfma_waves(A, lds, wave, tid & 63, cur_id);
+    else x3_staging_waves<NORM>(A, lds, tid - STAGERS, cur_id);
+}
+
+// ---------------------------------------------------------------------------------------------
+bool conv2d_x3_supported(const ConvLayer& L) {
+    static const bool enabled = []() {  // PDS_X3=0 keeps the exact-fp32 MFMA kernels (A/B, debugging)
+        const char* e = getenv("PDS_X3");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return false;
+    if (L.kd != 1 || L.stride != 1 || L.out_g.c != 64) return false;
+    if (L.in.c % 16 != 0 || L.in.c < 32 || L.in.c > CMAX) return false;
+    if (L.b.p || L.l0A || L.side_out || L.plane_weight_sets > 0) return false;
+    if ((size_t)L.in.d * L.in.h * L.in.w * 8 >= ((size_t)1 << 30)) return false;   // 32-bit channel offsets
+    if ((size_t)L.in.n * L.in.d >= ((size_t)1 << 20)) return false;
+    return true;
+}
+
+int conv2d_x3_tiles(const Geom& o) { return ((o.h + TH - 1) / TH) * ((o.w + TW - 1) / TW); }
+
+// dwords of packed weights + the eight queue counters behind them
+size_t conv2d_x3_packed_floats(int cin) { return (size_t)(cin / 16) * 3 * (W_STAGE / 4) + 64; }
+
+int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
+    if (!L.packed) return set_error(-1, "conv2d_x3: packed weights missing");
+    const int total = (L.in.c / 16) * 3 * (W_STAGE / 4);
+    const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
+    if (phase != kPackDone) {
+        PackJob j;
+        j.src = L.weight;
+        j.dst = L.packed;
+        j.cout = L.out_g.c;
+        j.cin = L.in.c;
+        j.mblocks = 2;
+        j.kc = 4;
+        j.taps = 9;
+        j.mode = 6;   // three-way bf16 split in v_mfma_f32_32x32x16_bf16 A-fragment order
+        j.total = total;
+        if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
+        if (int rc = launch_multi_pack(&j, 1, s)) return rc;
+    }
+    X3Args A;
+    A.a = L.a;
+    A.wpk = reinterpret_cast<const unsigned char*>(L.packed);
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.queue = reinterpret_cast<int*>(L.packed + total);
+    A.N = L.in.n;
+    A.Cin = L.in.c;
+    A.D = L.in.d;
+    A.H = L.in.h;
+    A.W = L.in.w;
+    A.Cout = L.out_g.c;
+    A.CoutStride = L.out_batch_channels > 0 ? L.out_batch_channels : L.out_g.c;
+    A.lrelu = L.lrelu;
+    A.tiles_x = (A.W + TW - 1) / TW;
+    A.tiles_y = (A.H + TH - 1) / TH;
+    A.tiles = A.tiles_x * A.tiles_y;
+    const int rem = A.W % TW;
+    A.tiles_x_full = A.tiles_x - ((rem != 0 && rem <= 16) ? 1 : 0);
+    A.planes = A.N * A.D;
+    A.nks = A.Cin / 16;
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    static int cus[32] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus[dev & 31] = n > 0 ? n : 256;
+    }
+    const long long all = (long long)A.planes * A.tiles;
+    const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
+    if (hipMemsetAsync(A.queue, 0, 8 * sizeof(int), s) != hipSuccess) return check_launch("conv2d_x3 queue reset");
+    if (L.a.scale) hipLaunchKernelGGL((conv2d_x3_kernel<true>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
+    else hipLaunchKernelGGL((conv2d_x3_kernel<false>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
+    return check_launch("conv2d_x3");
+}
+
+}  // namespace pds

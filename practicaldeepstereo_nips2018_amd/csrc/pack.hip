@@ -8,6 +8,9 @@
 //           value = Wt[c][oc][kd][kh][kw] for the transposed-conv tap that parity uses at that input
 //           offset, else 0; plus one 27-bit tap mask per 16-channel block (see conv3d_mfma.hip).
 //   cell   (mode 5, taps 8): the dense per-cell form of the k4 s2 transposed convolution (conv3d_ks.hip).
+//   x3     (mode 6): conv 3x3 weights split three ways into bf16 (round-to-nearest: w = w1 + w2 + w3 exactly) in the
+//           A-fragment order of v_mfma_f32_32x32x16_bf16, for conv2d_x3.hip:
+//           [k-step of 16 channels][dy][dx][part][32-channel block][lane][8 bf16]; `total` counts dwords (2 bf16).
 #include "common.hpp"
 
 namespace pds {
@@ -34,6 +37,21 @@ __device__ __forceinline__ bool deconv_tap_valid(int mode, int cls, int tap, int
     return kd >= 0 && kh >= 0 && kw >= 0;
 }
 
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// part 0, 1, 2 of the three-way bf16 split of v (as the 16 bits of a bf16)
+__device__ __forceinline__ unsigned bf16_split_part(float v, int part) {
+    unsigned h = bf16_rne_bits(v);
+    for (int p = 0; p < part; ++p) {
+        v -= __builtin_bit_cast(float, h << 16);
+        h = bf16_rne_bits(v);
+    }
+    return h;
+}
+
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const PackJob J = T.j[blockIdx.y];
     const int ks_n = J.kc / 4;
@@ -41,6 +59,27 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const int kdn = J.mode == 1 ? 4 : 3;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
+        if (J.mode == 6) {
+            const int i2 = r % 4;
+            r /= 4;
+            const int ln = r % 64;
+            r /= 64;
+            const int mb = r % J.mblocks;
+            r /= J.mblocks;
+            const int part = r % 3;
+            r /= 3;
+            const int dx = r % 3;
+            r /= 3;
+            const int dy = r % 3;
+            const int kstep = r / 3;
+            const int oc = mb * 32 + (ln & 31), ic = kstep * 16 + (ln >> 5) * 8 + 2 * i2;
+            unsigned lo = 0, hi = 0;
+            if (oc < J.cout && ic < J.cin) lo = bf16_split_part(J.src[((size_t)oc * J.cin + ic) * 9 + dy * 3 + dx], part);
+            if (oc < J.cout && ic + 1 < J.cin)
+                hi = bf16_split_part(J.src[((size_t)oc * J.cin + ic + 1) * 9 + dy * 3 + dx], part);
+            reinterpret_cast<unsigned*>(J.dst)[e] = lo | (hi << 16);
+            continue;
+        }
         const int i = r % 16;
         r /= 16;
         const int k = r % 4;

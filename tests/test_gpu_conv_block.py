@@ -4,7 +4,9 @@ One block of reference network_blocks.py:47-72 (Conv -> LeakyReLU(0.1) -> Instan
 plain tensor.  The shapes walk every kernel behind the entry point: the Winograd-domain 64-channel kernel
 (conv2d_wino.hip: even widths, partial 64-column tiles, 12 / 64 input channels, several planes and batch entries,
 per-plane and per-volume statistics, bare convolution), the direct MFMA kernel (odd widths, 8 / 16 output channels),
-the 3-D MFMA kernel (stride 1 and 2) and the VALU fallback (channel counts no MFMA tiling covers).
+the 3-D MFMA kernel (stride 1 and 2) and the VALU fallback (channel counts no MFMA tiling covers).  Since round 3 the
+Cin % 16 == 0 -> 64 layers run on conv2d_x3.hip (fp32 operands split three ways into bf16, six partial products on
+the bf16 matrix pipe): the same cases and the same tolerance, plus cases that walk its persistent tile queues.
 Tolerance (stated): max-abs <= 2e-5 on the O(1) activations, and on the normalised output scale * raw + shift."""
 import ctypes
 
@@ -80,6 +82,9 @@ CASES = [
     (1, 64, 64, 8, 16, 48, 1, 1, 1, False),    # 16x16-tile Winograd kernel, exact tiling, bare, XCD re-mapping active
     (1, 128, 64, 1, 24, 20, 1, 1, 0, True),    # 16x16 tiles, 128 input channels, width 20 (one partial tile column)
     (2, 64, 64, 8, 32, 16, 1, 1, 1, True),     # 16x16 tiles, batch 2 x 8 planes: XCD re-mapping with a batch axis
+    (1, 64, 64, 48, 48, 80, 1, 1, 1, True),    # conv2d_x3: 432 tiles, more than one per persistent workgroup (queues, stealing)
+    (3, 64, 64, 5, 17, 47, 1, 1, 1, True),     # conv2d_x3: 15 planes (uneven queues), ragged rows, right-half-empty tile column
+    (1, 32, 64, 2, 20, 36, 1, 1, 0, True),     # conv2d_x3: two K-steps only, per-volume statistics
     (1, 64, 8, 3, 10, 40, 1, 1, 1, False),     # 8 output channels: direct MFMA kernel, one channel block
     (2, 64, 16, 1, 5, 24, 1, 1, 1, True),
     (1, 8, 8, 6, 10, 20, 3, 1, 0, True),       # conv3d MFMA

@@ -27,7 +27,7 @@ def main():
         con = sqlite3.connect(db)
         for name, gx, gy, gz, calls, avg in con.execute(
                 "select name, grid_x, grid_y, grid_z, count(*), avg(end - start) / 1000.0 from kernels "
-                "where name like '%conv2d_wino%' or name like '%conv2d_mfma_kernel<4%' "
+                "where name like '%conv2d_wino%' or name like '%conv2d_x3%' or name like '%conv2d_mfma_kernel<4%' "
                 "group by name, grid_x, grid_y, grid_z order by avg(end - start) desc"):
             lines.append('%-100s %22s %8d %12.1f' % (name[:100], '%dx%dx%d' % (gx, gy, gz), calls, avg))
     open(dst, 'w').write('\n'.join(lines) + '\n')
