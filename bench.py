@@ -111,7 +111,7 @@ def make_inputs(device):
     baseline later receives host copies of the very same descriptors, so both sides see bit-identical inputs.
     Returns the network, [(left descriptor, right descriptor, left shortcut)] and [(left image, right image)]."""
     torch.manual_seed(0)
-    net = pds.PdsNetwork.default(MAX_DISPARITY).eval().to(device)
+    net = pds.PdsNetwork.default(MAX_DISPARITY).eval().to(device).freeze_weights()   # inference deployment: weights stay packed
     descriptors, images = [], []
     for i in range(PAIRS):
         g = torch.Generator().manual_seed(1 + i)

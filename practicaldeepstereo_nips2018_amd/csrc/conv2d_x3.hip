@@ -47,7 +47,7 @@ namespace pds {
 namespace {
 
 constexpr int TH = 16, TW = 32, ROWS = TH + 2, COLS = TW + 2, PIX = ROWS * COLS;   // halo tile 18 x 34 = 612 pixels
-constexpr int THREADS = 512, STAGERS = 256;
+constexpr int THREADS = 512, STAGERS = 256, GROUP = 128;   // waves 0-3 MFMA, 4-5 / 6-7 the two staging groups
 constexpr int IN_PART = 2 * PIX * 16;          // bytes of one split part: [channel group][row][column][8 bf16]
 constexpr int IN_BUF = 3 * IN_PART;            // 58 752
 constexpr int W_FRAG = 64 * 16;                // one B fragment
@@ -59,9 +59,9 @@ constexpr int CMAX = 256;                      // most input channels with a def
 constexpr int LDS_COEF = LDS_NEXT + 16;        // [tile parity 2][scale | shift][CMAX] floats
 constexpr int LDS_BYTES = LDS_COEF + 2 * 2 * CMAX * 4;
 constexpr int THIRD_ROWS = ROWS / 3, THIRD_PIX = THIRD_ROWS * COLS;   // 204 staging items per channel group and third
-constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;       // 16-byte pieces of a weight stage per stager: 5
+constexpr int W_ITERS = (W_STAGE / 16 + GROUP - 1) / GROUP;           // 16-byte pieces of a weight stage per thread: 9
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-static_assert(THIRD_PIX <= STAGERS, "one item per staging thread and channel group");
+static_assert(THIRD_PIX <= 2 * GROUP, "two pixels per staging thread and third");
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -202,6 +202,19 @@ __device__ __forceinline__ void x3_mfma_stage(f32x16 (&acc)[4][2], const unsigne
 #undef PDS_X3_TAP
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of
+// the wave (vmcnt(0)): for the staging waves that would drain the requests they have just issued, for the MFMA waves
+// the epilogue's stores -- both are meant to stay in flight across the barrier.
+__device__ __forceinline__ void x3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// a * b + c as ONE v_fma_f32: left to the compiler, pairs of these become v_pk_fma_f32, which issues to the matrix pipe's
+// side of the SIMD and starves behind the MFMA wave that shares it (measured: +190 us per 48-plane launch)
+__device__ __forceinline__ float x3_fma(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ Tile decode_tile(const X3Args& A, int v) {
     Tile t;
     const int p = v / A.tiles;
@@ -258,12 +271,17 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
         if (rs == 1) nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
         const unsigned char* wb = lds + LDS_W + wpar * W_STAGE + L.w_lane;
         const unsigned char* xb = lds + upar * IN_BUF + dy * (COLS * 16) + L.x_lane;
+#ifndef PDS_X3_NOMFMA   // (PDS_X3_NO*: timing ablations, never defined in the product build)
         x3_mfma_stage<NARROW>(acc, xb, wb);
+#endif
         if (dy == 2) upar ^= 1;
         wpar ^= 1;
-        __syncthreads();
+        x3_barrier();
     }
     // ---- epilogue of the tile: bias, LeakyReLU, 16-byte stores, statistics
+#ifdef PDS_X3_NOEPI
+    if (acc[0][0][0] != 12345.f) return nxt_id;
+#endif
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     float* obase = A.out + (((size_t)cur.n * A.CoutStride) * A.D + cur.d) * L.plane;   // uniform
     const bool vec = (A.W & 3) == 0;
@@ -341,8 +359,11 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
     const int x_full = (L.kgl * PIX + (4 * wave) * COLS + L.m32) * 16;                            // M block = row, 32 columns
     const int x_narrow = (L.kgl * PIX + (4 * wave + (L.m32 >> 4)) * COLS + (L.m32 & 15)) * 16;    // M block = 2 rows x 16
     int upar = 0, wpar = 0;   // LDS buffer of the K-step / weight stage being consumed
-    __syncthreads();
-    __syncthreads();
+    x3_barrier();
+    x3_barrier();
+#ifndef PDS_X3_NOPRIO
+    __builtin_amdgcn_s_setprio(3);   // the matrix pipe's feeders issue ahead of the staging wave of their SIMD
+#endif
     for (;;) {
         const Tile cur = decode_tile(A, cur_id);
         if (cur.x0 + 16 >= A.W) {   // the right half of the tile is outside the image (uniform)
@@ -354,179 +375,235 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
         }
         if (cur_id < 0) break;
     }
-    __syncthreads();
+    x3_barrier();
 }
 
 // ---- waves 4-7 -----------------------------------------------------------------------------------------------------
+// Two groups of two waves take the stages in turn (group = stage parity): a group writes, at its stage, what it
+// requested at its previous one -- two stages earlier -- and then issues the requests for its next one.  A request
+// therefore has a whole stage of MFMA time plus its own stage to land (global latency under load is ~2 us, about one
+// stage); with one group and a one-stage lag every stage began by waiting for the loads issued at the end of the
+// previous one.
 template <bool NORM>
 __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char* lds, int st, int cur_id) {
     const size_t plane = (size_t)A.H * A.W;
     const unsigned cstride = (unsigned)(A.D * plane);          // floats between channels
     const int nks = A.nks, nstages = 3 * nks;
-    // one pixel x 16 channels per thread and third of a K-step (two items of 8 channels: the two channel groups)
-    const bool stager = st < THIRD_PIX;
-    const int lrow = stager ? st / COLS : 0, lcol = stager ? st % COLS : 0;
-    const int lds_item = (lrow * COLS + lcol) * 16;     // + (part * 2 + group) * PIX * 16 + third * THIRD_PIX * 16
+    const int group = __builtin_amdgcn_readfirstlane(st >> 7);
+    const int t = st & (GROUP - 1);
+    // a thread stages two pixels (t and t + 128 of the 204 of a third) x 16 channels (the two groups of 8)
+    int lds_item[2];
+    int prow[2], pcol[2];
+    bool valid[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int px = t + k * GROUP;
+        valid[k] = px < THIRD_PIX;
+        prow[k] = valid[k] ? px / COLS : 0;
+        pcol[k] = valid[k] ? px % COLS : 0;
+        lds_item[k] = (prow[k] * COLS + pcol[k]) * 16;   // + (part * 2 + channel group) * PIX * 16 + third * THIRD_PIX * 16
+    }
     int* next_slot = reinterpret_cast<int*>(lds + LDS_NEXT);
     const int home = blockIdx.x & 7;
     const int n_full = A.tiles_y * A.tiles_x_full;
 
-    float xin[2][8];     // the pixel's two items requested during the previous stage
-    u32x4 win[W_ITERS];  // this thread's pieces of the weight stage requested during the previous stage
+    float xin[2][2][8];  // [pixel][channel group][channel]: requested at this group's previous stage
+    u32x4 win[W_ITERS];  // this thread's pieces of the weight stage requested at this group's previous stage
     const int wlast = W_STAGE / 16 - 1;
     float* coef_tab = reinterpret_cast<float*>(lds + LDS_COEF);
 
-    auto request_inputs = [&](const Tile& t, int ks, int third) {
-        const int y = t.y0 - 1 + third * THIRD_ROWS + lrow, x = t.x0 - 1 + lcol;
-        const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
-        const float* src = A.a.p + ((size_t)(t.n * A.Cin + ks * 16) * A.D + t.d) * plane;   // uniform
-        const unsigned off = (unsigned)(yc * A.W + xc);
+    auto request_inputs = [&](const Tile& tl, int ks, int third) {
+        const float* src = A.a.p + ((size_t)(tl.n * A.Cin + ks * 16) * A.D + tl.d) * plane;   // uniform
+        unsigned off[2];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int k = 0; k < 2; ++k) {
+            const int y = tl.y0 - 1 + third * THIRD_ROWS + prow[k], x = tl.x0 - 1 + pcol[k];
+            const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
+            off[k] = (unsigned)(yc * A.W + xc);
+        }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xin[g][i] = src[off + (unsigned)(g * 8 + i) * cstride];
-    };
-    auto write_inputs = [&](const Tile& t, int ks, int third, unsigned char* buf, const float* coef) {
-        const int y = t.y0 - 1 + third * THIRD_ROWS + lrow, x = t.x0 - 1 + lcol;
-        const bool inimg = y >= 0 && y < A.H && x >= 0 && x < A.W;
+        for (int c = 0; c < 16; ++c) {
+            const float* sc = src + (size_t)c * cstride;   // uniform channel base (scalar registers) + one lane offset
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            float v[8];
-            if (NORM) {
-                // the producer's folded InstanceNorm of this (batch entry, plane): table of the tile in LDS, one
-                // address per wave (broadcast reads)
-                const f32x4* ps = reinterpret_cast<const f32x4*>(coef + ks * 16 + g * 8);
-                const f32x4* ph = reinterpret_cast<const f32x4*>(coef + CMAX + ks * 16 + g * 8);
-                const f32x4 s0 = ps[0], s1 = ps[1], h0 = ph[0], h1 = ph[1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = fmaf(s0[i], xin[g][i], h0[i]);
-                    v[4 + i] = fmaf(s1[i], xin[g][4 + i], h1[i]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = xin[g][i];
-            }
-            // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
-            unsigned h[3][8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float r = inimg ? v[i] : 0.f;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const unsigned u = __builtin_bit_cast(unsigned, r);
-                    h[p][i] = u;
-                    if (p < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
-                }
-            }
-            if (stager) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    u32x4 w;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)   // bytes [3:2] of the odd channel above bytes [3:2] of the even one
-                        w[j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
-                    *reinterpret_cast<u32x4*>(buf + (p * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = w;
-                }
-            }
+            for (int k = 0; k < 2; ++k) xin[k][c >> 3][c & 7] = sc[off[k]];
         }
     };
-    // folded InstanceNorm coefficients of a tile's (batch entry, plane): requested for the NEXT tile at every stage,
-    // written into the other table during the following one (branch-free; redundant writes carry equal values)
-    float coef_s = 1.f, coef_h = 0.f;
-    const int coef_c = min(st, A.Cin - 1);
-    auto request_coef = [&](const Tile& t) {
+    auto write_inputs = [&](const Tile& tl, int ks, int third, unsigned char* buf, const float* coef) {
+        // the producer's folded InstanceNorm of this (batch entry, plane): table of the tile in LDS, one address per
+        // wave (broadcast reads), all sixteen channels requested up front (one LDS round trip per turn, not per item)
+        f32x4 cs[4], ch[4];
         if (NORM) {
-            const size_t g = A.a.per_plane ? ((size_t)(t.n * A.Cin + coef_c) * A.D + t.d) : (size_t)(t.n * A.Cin + coef_c);
-            coef_s = A.a.scale[g];
-            coef_h = A.a.shift[g];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#ifdef PDS_X3_NOCOEFREAD
+                cs[j] = f32x4{1.f, 1.5f, 0.5f, 0.75f};
+                ch[j] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+#else
+                cs[j] = *reinterpret_cast<const f32x4*>(coef + ks * 16 + 4 * j);
+                ch[j] = *reinterpret_cast<const f32x4*>(coef + CMAX + ks * 16 + 4 * j);
+#endif
+            }
         }
-    };
-    auto write_coef = [&](int table) {
-        if (NORM) {
-            coef_tab[table * 2 * CMAX + coef_c] = coef_s;
-            coef_tab[table * 2 * CMAX + CMAX + coef_c] = coef_h;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int y = tl.y0 - 1 + third * THIRD_ROWS + prow[k], x = tl.x0 - 1 + pcol[k];
+            const bool inimg = y >= 0 && y < A.H && x >= 0 && x < A.W;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = NORM ? x3_fma(cs[2 * g + (i >> 2)][i & 3], xin[k][g][i], ch[2 * g + (i >> 2)][i & 3]) : xin[k][g][i];
+                // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
+                unsigned h[3][8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float r = inimg ? v[i] : 0.f;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned u = __builtin_bit_cast(unsigned, r);
+                        h[p][i] = u;
+                        if (p < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
+                    }
+                }
+                if (valid[k]) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        u32x4 w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)   // bytes [3:2] of the odd channel above bytes [3:2] of the even one
+                            w[j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
+                        *reinterpret_cast<u32x4*>(buf + (p * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item[k]) = w;
+                    }
+                }
+            }
         }
     };
     auto request_weights = [&](int stage) {
         const u32x4* src = reinterpret_cast<const u32x4*>(A.wpk + (size_t)stage * W_STAGE);
 #pragma unroll
-        for (int it = 0; it < W_ITERS; ++it) win[it] = src[min(it * STAGERS + st, wlast)];
+        for (int it = 0; it < W_ITERS; ++it) win[it] = src[min(it * GROUP + t, wlast)];
     };
     auto write_weights = [&](unsigned char* buf) {
         u32x4* dst = reinterpret_cast<u32x4*>(buf);
 #pragma unroll
-        for (int it = 0; it < W_ITERS; ++it) dst[min(it * STAGERS + st, wlast)] = win[it];
+        for (int it = 0; it < W_ITERS; ++it) dst[min(it * GROUP + t, wlast)] = win[it];
+    };
+    // folded InstanceNorm coefficients of the NEXT tile's (batch entry, plane) -> its table in LDS: part of every
+    // request / write turn (two channels per thread, so each group covers all of them), branch-free -- a load inside
+    // a branch merges with "no load" in a phi and the compiler then drains ALL outstanding loads at the merge.
+    // The writes of the first turns carry the placeholder tile's values and are overwritten by the later ones well
+    // before the table is first read (stage 3 * nks - 3 >= 6).
+    float coef_s[2] = {1.f, 1.f}, coef_h[2] = {0.f, 0.f};
+    auto coef_channel = [&](int k) { return min(t + k * GROUP, A.Cin - 1); };
+    auto coef_index = [&](const Tile& tl, int c) -> size_t {
+        return A.a.per_plane ? ((size_t)(tl.n * A.Cin + c) * A.D + tl.d) : (size_t)(tl.n * A.Cin + c);
+    };
+    auto request_coef = [&](const Tile& tl) {
+#ifndef PDS_X3_NOCOEFLOAD
+        if (NORM) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const size_t g = coef_index(tl, coef_channel(k));
+                coef_s[k] = A.a.scale[g];
+                coef_h[k] = A.a.shift[g];
+            }
+        }
+#endif
+    };
+    auto write_coef = [&](int table) {
+        if (NORM) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                coef_tab[table * 2 * CMAX + coef_channel(k)] = coef_s[k];
+                coef_tab[table * 2 * CMAX + CMAX + coef_channel(k)] = coef_h[k];
+            }
+        }
     };
     // one fp64 (sum, sum of squares) record per tile and channel from the four MFMA waves' rows
-    auto fold_statistics = [&](const Tile& t) {
+    auto fold_statistics = [&](const Tile& tl) {
         if (A.partials && st < 128) {
             const float* red = reinterpret_cast<const float*>(lds + LDS_RED);
             const int oc = st >> 1, k = st & 1;
             double v = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) v += (double)red[(wv * 64 + oc) * 2 + k];
-            A.partials[((((size_t)t.n * A.Cout + oc) * A.D + t.d) * A.tiles + t.tile) * 2 + k] = v;
+            A.partials[((((size_t)tl.n * A.Cout + oc) * A.D + tl.d) * A.tiles + tl.tile) * 2 + k] = v;
         }
     };
 
-    // ---- prologue: the first tile's coefficient table, first K-step and weight stage; requests of what stage 0 writes
+    // ---- prologue: the first tile's coefficient table, first K-step and weight stage (group 0); then each group's
+    // requests of what its first stage writes
     Tile cur = decode_tile(A, cur_id);
     Tile nxt = cur, done = cur;
     int nxt_id = -1;
     int tpar = 0;             // coefficient table of the current tile
     request_coef(cur);
     write_coef(0);
-    request_weights(0);
-    write_weights(lds + LDS_W);
-    __syncthreads();
-    for (int third = 0; third < 3; ++third) {
-        request_inputs(cur, 0, third);
-        write_inputs(cur, 0, third, lds, coef_tab);
+    if (group == 0) {
+        request_weights(0);
+        write_weights(lds + LDS_W);
     }
-    request_weights(1);
-    request_inputs(cur, 1, 0);
+    x3_barrier();
+    if (group == 0) {
+        for (int third = 0; third < 3; ++third) {
+            request_inputs(cur, 0, third);
+            write_inputs(cur, 0, third, lds, coef_tab);
+        }
+    }
+    // group g's first stage is stage g: it writes third g of K-step 1 and weight stage g + 1
+    request_weights(1 + group);
+    request_inputs(cur, 1, group);
     request_coef(cur);
     int upar = 0, wpar = 0;   // LDS buffer of the K-step / weight stage being consumed
+    int gpar = 0;             // parity of the global stage count: the group whose turn it is
     bool fold_pending = false;
-    __syncthreads();
+    x3_barrier();
 
     for (;;) {
+#pragma unroll 1
         for (int rs = 0; rs < nstages; ++rs) {
             const int ks = rs / 3, dy = rs - 3 * ks;
             if (rs == 1) {   // the tile drawn during stage 0 (published by its barrier)
                 nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
                 if (nxt_id >= 0) nxt = decode_tile(A, nxt_id);
             }
-            // -- write what stage rs - 1 requested: third (rs % 3) of K-step ks + 1 and weight stage rs + 1.
-            // No branch stands around a request or its use (a phi of loaded values makes the compiler wait for
-            // the loads where the branches merge): past the last tile the sequence re-stages the current tile
-            // into the idle buffer, which nobody reads.
-            {
-                const bool into_next = ks + 1 >= nks;
-                write_inputs(pick_tile(into_next, nxt, cur), into_next ? 0 : ks + 1, dy, lds + (upar ^ 1) * IN_BUF,
-                             coef_tab + ((into_next ? tpar ^ 1 : tpar) * 2 * CMAX));
-                write_weights(lds + LDS_W + (wpar ^ 1) * W_STAGE);
-                write_coef(tpar ^ 1);
+            // requests whose answer this stage itself needs go out first (a counted wait then skips the younger ones)
+            int drawn = -1;
+            if (rs == 0 && st == 0) drawn = draw_tile(A.queue, home, A.planes, A.tiles, A.tiles_x, A.tiles_x_full, n_full);
+#ifndef PDS_X3_NOSTAGE
+            if (group == gpar) {
+                // -- write what this group requested two stages ago: third (rs % 3) of K-step ks + 1 and weight stage
+                // rs + 1.  No branch stands between a request and its use (a phi of loaded values makes the compiler
+                // wait where the branches merge): past the last tile the sequence re-stages the current tile into
+                // the idle buffer, which nobody reads.
+                {
+                    const bool into_next = ks + 1 >= nks;
+                    write_inputs(pick_tile(into_next, nxt, cur), into_next ? 0 : ks + 1, dy, lds + (upar ^ 1) * IN_BUF,
+                                 coef_tab + ((into_next ? tpar ^ 1 : tpar) * 2 * CMAX));
+                    write_weights(lds + LDS_W + (wpar ^ 1) * W_STAGE);
+                    write_coef(tpar ^ 1);
+                }
+                // -- requests for this group's next stage (rs + 2): sequence position rs + 5, weight stage rs + 3
+                {
+                    const int q = rs + 5;
+                    const int ksl = q / 3, third = q - 3 * ksl;
+                    const bool into_next = ksl >= nks;
+                    request_inputs(pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
+                    int ws = rs + 3;
+                    if (ws >= nstages) ws -= nstages;
+                    request_weights(ws);
+                    request_coef(nxt);
+                }
             }
-            // -- requests: sequence position rs + 4 (K-step, third) and weight stage rs + 2
-            {
-                const int q = rs + 4;
-                const int ksl = q / 3, third = q - 3 * ksl;
-                const bool into_next = ksl >= nks;
-                request_inputs(pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
-                int ws = rs + 2;
-                if (ws >= nstages) ws -= nstages;
-                request_weights(ws);
-                request_coef(nxt);
-            }
+#endif
             // -- housekeeping with the staging waves' spare time
-            if (rs == 0 && st == 0)
-                next_slot[0] = draw_tile(A.queue, home, A.planes, A.tiles, A.tiles_x, A.tiles_x_full, n_full);
+            if (rs == 0 && st == 0) next_slot[0] = drawn;
             if (rs == 1 && fold_pending) fold_statistics(done);
             if (dy == 2) upar ^= 1;
             wpar ^= 1;
-            __syncthreads();
+            gpar ^= 1;
+            x3_barrier();
         }
         done = cur;
         fold_pending = true;
@@ -535,7 +612,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         nxt_id = -1;
         tpar ^= 1;
     }
-    __syncthreads();
+    x3_barrier();
     fold_statistics(done);
 }
 
@@ -565,7 +642,7 @@ bool conv2d_x3_supported(const ConvLayer& L) {
     }();
     if (!enabled) return false;
     if (L.kd != 1 || L.stride != 1 || L.out_g.c != 64) return false;
-    if (L.in.c % 16 != 0 || L.in.c < 32 || L.in.c > CMAX) return false;
+    if (L.in.c % 16 != 0 || L.in.c < 48 || L.in.c > CMAX) return false;   // three K-steps at least (staging lead)
     if (L.b.p || L.l0A || L.side_out || L.plane_weight_sets > 0) return false;
     if ((size_t)L.in.d * L.in.h * L.in.w * 8 >= ((size_t)1 << 30)) return false;   // 32-bit channel offsets
     if ((size_t)L.in.n * L.in.d >= ((size_t)1 << 20)) return false;
@@ -633,7 +710,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     const long long all = (long long)A.planes * A.tiles;
     const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
     if (hipMemsetAsync(A.queue, 0, 8 * sizeof(int), s) != hipSuccess) return check_launch("conv2d_x3 queue reset");
-    if (L.a.scale) hipLaunchKernelGGL((conv2d_x3_kernel<true>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
+    if (L.a.scale && !getenv("PDS_X3_FORCE_PLAIN")) hipLaunchKernelGGL((conv2d_x3_kernel<true>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
     else hipLaunchKernelGGL((conv2d_x3_kernel<false>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
     return check_launch("conv2d_x3");
 }

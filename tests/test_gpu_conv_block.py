@@ -84,7 +84,7 @@ CASES = [
     (2, 64, 64, 8, 32, 16, 1, 1, 1, True),     # 16x16 tiles, batch 2 x 8 planes: XCD re-mapping with a batch axis
     (1, 64, 64, 48, 48, 80, 1, 1, 1, True),    # conv2d_x3: 432 tiles, more than one per persistent workgroup (queues, stealing)
     (3, 64, 64, 5, 17, 47, 1, 1, 1, True),     # conv2d_x3: 15 planes (uneven queues), ragged rows, right-half-empty tile column
-    (1, 32, 64, 2, 20, 36, 1, 1, 0, True),     # conv2d_x3: two K-steps only, per-volume statistics
+    (1, 48, 64, 2, 20, 36, 1, 1, 0, True),     # conv2d_x3: three K-steps (the fewest it takes), per-volume statistics
     (1, 64, 8, 3, 10, 40, 1, 1, 1, False),     # 8 output channels: direct MFMA kernel, one channel block
     (2, 64, 16, 1, 5, 24, 1, 1, 1, True),
     (1, 8, 8, 6, 10, 20, 3, 1, 0, True),       # conv3d MFMA
