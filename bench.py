@@ -21,10 +21,12 @@ pair i + 1 -- not N redundant copies.  The total work is one pair per step, so s
 are reported beside it.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     - the dominant kernel (conv2d 3x3 64->64 over all disparity planes, fp32 MFMA): its
-                 launch is timed in isolation with HIP events through pds_conv_block_fwd;
-                 achieved = 122.31 algorithmic GFLOP per launch / mean duration against the 157.3 TFLOP/s
-                 peak (the kernel works in the Winograd domain and executes 2/3 of them: executed_tflops).
+  roofline     - the dominant kernel (conv2d 3x3 64->64 over all disparity planes): its launch is timed in
+                 isolation with HIP events through pds_conv_block_fwd; achieved = EXECUTED matrix flops per launch
+                 (6 bf16 flops per algorithmic one: three-way split operands) / mean duration against the dense
+                 bf16 MFMA peak; the algorithmic fp32 figures ride along.
+  path_roofline- the whole hot path at ms_per_frame against SURVEY.md 8d's counts.
+  gpu_baseline - the same restatement on the MI355X through PyTorch-ROCm / MIOpen (no hand-written kernels).
   cpu_baseline - the oracle (oracle/pds_oracle.py, PyTorch-CPU restatement of the reference) on the
                  same inputs on this host's cores (rank 0, N=1 only), and the parity of the GPU result
                  against it.
@@ -49,12 +51,13 @@ from practicaldeepstereo_nips2018_amd.distributed import PairStreams, ShardedHot
 
 HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of the same table
 # dense 2*MAC count of one 64->64 3x3 convolution over [1, 64, 48, 144, 240] (122.31 GF)
 CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
 # HBM bytes per launch of that kernel come from the PMC record committed with the round's profiles (rocprofv3 must
 # wrap the process to collect counters, so this script cannot re-collect them): tools/collect_profiles.sh writes the
-# counters, profiles/r02_conv64_pmc.json holds FETCH_SIZE / WRITE_SIZE of this kernel and the guide's gfx950 correction
-CONV64_PMC_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_conv64_pmc.json')
+# counters, profiles/r03_conv64_pmc.json holds FETCH_SIZE / WRITE_SIZE of this kernel and the guide's gfx950 correction
+CONV64_PMC_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_conv64_pmc.json')
 
 
 def conv64_hbm_traffic():
@@ -66,16 +69,22 @@ def conv64_hbm_traffic():
         return None, 'no PMC record: %s' % e
     nbytes = (rec['FETCH_SIZE_KB'] * rec['fetch_correction'] + rec['WRITE_SIZE_KB']) * 1e3
     return nbytes, ('rocprofv3 FETCH_SIZE %.1f MB x %g (gfx950 wide-read correction) + WRITE_SIZE %.1f MB, separate '
-                    '--pmc passes, profiles/r02_conv64_pmc.json <- profiles/r02_pmc_all_kernels.txt (algorithmic %.1f MB)'
+                    '--pmc passes, profiles/r03_conv64_pmc.json <- profiles/r03_conv64_pmc.txt (algorithmic %.1f MB)'
                     % (rec['FETCH_SIZE_KB'] / 1e3, rec['fetch_correction'], rec['WRITE_SIZE_KB'] / 1e3,
                        rec['algorithmic_bytes'] / 1e6))
 
 
-# The layer runs in the Winograd domain (F(2,3) along x): 2/3 of the multiplies of the direct form.  Default:
-# csrc/conv2d_wino16.hip, 16 x 16-pixel tiles that cover 144 x 240 exactly; PDS_WINO_TILE16=0: csrc/conv2d_wino.hip,
-# 4 x 64 tiles (256 columns computed for 240)
-CONV64_EXECUTED_GFLOP = CONV64_GFLOP * (2.0 / 3.0) * (
-    256.0 / 240.0 if os.environ.get('PDS_WINO_TILE16', '1')[:1] == '0' else 1.0)
+# Round 3: the layer runs on the bf16 matrix pipe (csrc/conv2d_x3.hip): every fp32 operand is split three ways into
+# bf16 and six of the nine partial products are accumulated in fp32 -- as accurate as the fp32 fmaf chain (measured,
+# tools/ubench/bf16x3_probe.hip).  EXECUTED work = 6 bf16 MFMA flops per algorithmic flop, priced against the dense bf16
+# MFMA peak; PDS_X3=0 selects the exact-fp32 Winograd kernel of round 2 (2/3 of the flops on the fp32 MFMA pipe).
+X3 = os.environ.get('PDS_X3', '1')[:1] != '0'
+CONV64_EXECUTED_GFLOP = CONV64_GFLOP * 6.0 if X3 else CONV64_GFLOP * (2.0 / 3.0)
+CONV64_EXECUTED_PEAK = BF16_MFMA_PEAK_TFLOPS if X3 else FP32_MFMA_PEAK_TFLOPS
+# algorithmic work of the whole hot path per pair at configs[1]
+PATH_GFLOP_REFERENCE = 791.9   # as the reference executes it (dense first layer)
+PATH_GFLOP_MINIMAL = 552.4     # with the exact layer-0 factorisation
+PATH_ALGORITHMIC_MB = 3900.0 + 1148.7 + 214.5   # Matching (factorised) + Regularization + estimator activations
 
 
 def parse():
@@ -96,6 +105,10 @@ def parse():
     ap.add_argument('--graph', action='store_true',
                     help='replay the hot path as one captured HIP graph (N = 1); measured equal to eager launches '
                          'because the GPU is saturated, so eager is the default')
+    ap.add_argument('--train', action='store_true',
+                    help='BASELINE.json configs[4] instead of the inference hot path: one full-size training step per '
+                         'step (train-mode forward, SubpixelCrossEntropy, backward, RMSprop), one pair per GPU, '
+                         'DistributedDataParallel over RCCL for N > 1 (weak scaling)')
     ap.add_argument('--backend', default='nccl', help='process-group backend for N > 1 ("nccl" is RCCL)')
     ap.add_argument('--share-device', action='store_true',
                     help='functional test only: every rank uses cuda:0 (needs --backend gloo)')
@@ -211,7 +224,94 @@ def cpu_baseline(net, ld, rd, shortcut, gpu_disparity, gpu_signatures=None, gpu_
             'sample': 'best of %d full passes (first one is warm-up, ~12 s of host time) of the same 960x540 D=192 pair, '
                       'PyTorch-CPU oracle, %s, %d usable cores' % (passes, cpu_name, usable),
             'ms_per_pair': best * 1e3}
+    # SURVEY.md 8d also asks for the single-thread figure: ONE pass (about 10-15 s), no warm-up
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        oracle.hot_path(params, ld, rd, shortcut, MAX_DISPARITY)
+        single = time.perf_counter() - t0
+    torch.set_num_threads(threads)
+    base['single_thread'] = {'value': 1.0 / single, 'unit': 'pairs/s', 'cores': 1, 'ms_per_pair': single * 1e3,
+                             'sample': 'one full pass of the same pair, torch.set_num_threads(1)'}
     return base, parity
+
+
+def gpu_baseline(net, ld, rd, shortcut, device, gpu_disparity):
+    """The same restatement (oracle.hot_path: plain PyTorch ops) on the MI355X through PyTorch-ROCm / MIOpen: what a
+    user gets on this GPU without the hand-written kernels.  Same inputs, after the
+    timed region; best of 3 after 2 warm-up passes (MIOpen picks its kernels in the first)."""
+    from oracle import pds_oracle as oracle
+    params = {k: v.detach() for k, v in net.state_dict().items()}
+    best = float('inf')
+    disparity = None
+    with torch.no_grad():
+        for i in range(5):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            disparity = oracle.hot_path(params, ld, rd, shortcut, MAX_DISPARITY)
+            torch.cuda.synchronize(device)
+            if i >= 2:
+                best = min(best, time.perf_counter() - t0)
+    delta = (gpu_disparity.double() - disparity.double()).abs()
+    return {'value': 1.0 / best, 'unit': 'pairs/s', 'ms_per_pair': best * 1e3, 'kind': 'port',
+            'sample': 'best of 3 full passes after 2 warm-up passes of the same 960x540 D=192 pair: oracle/pds_oracle.py '
+                      '(plain torch.nn.functional ops) on cuda:0 = PyTorch-ROCm %s + MIOpen' % torch.__version__,
+            'disparity_mae_vs_hip_path': float(delta.mean())}
+
+
+def train_main(args, world, rank, device):
+    """--train: the config-5 line (same timing contract: W warm-up steps, then exactly K steps between barriers and
+    synchronisations, MAX over ranks; rank 0 prints one JSON line)."""
+    from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
+    trainer = DataParallelTrainer(MAX_DISPARITY, device, share_device=args.share_device)
+    left, right, truth = synthetic_example(HEIGHT, WIDTH, MAX_DISPARITY, 1 + rank, device)   # another pair per rank
+    losses = [trainer.step(left, right, truth) for _ in range(args.warmup)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(trainer.step(left, right, truth))
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    in_sync = True
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        in_sync = trainer.replicas_in_sync()
+    # forward / backward split of one more (untimed) step on rank 0's pair
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    trainer.optimizer.zero_grad(set_to_none=True)
+    cost = trainer.network(left, right)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    trainer.criterion(cost, truth).backward()
+    torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
+    if rank == 0:
+        values = [float(v) for v in losses]
+        print(json.dumps({
+            'metric': 'training steps (stereo pairs)/sec, 960x540 D=192: PdsNetwork train forward + SubpixelCrossEntropy '
+                      '+ backward through the HIP modules + RMSprop',
+            'value': world * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[4]: one 960x540 pair per GPU, D=192, batch 1 per rank, train mode, '
+                                   'random-init weights seed 0, ground truth with an unknown band',
+                       'parallelism': ('DistributedDataParallel x%d, gradient all-reduce over %s' %
+                                       (world, 'RCCL' if args.backend == 'nccl' else args.backend))
+                       if world > 1 else 'single GPU'},
+            'forward_ms': (t1 - t0) * 1e3, 'loss_backward_ms': (t2 - t1) * 1e3,
+            'first_loss': values[0], 'last_loss': values[-1], 'replicas_in_sync': in_sync,
+            'peak_memory_gb': torch.cuda.max_memory_allocated(device) / 2 ** 30}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def free_port():
@@ -256,6 +356,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.train:
+        return train_main(args, world, rank, device)
     net, descriptors, images = make_inputs(device)
     ld_g, rd_g, sc_g = descriptors[0]
     regularization, estimator = net._regularization, net._estimator
@@ -483,24 +585,40 @@ def main():
             line['time_per_image'].pop('three_pixels_error', None)
         with torch.no_grad():
             kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)
-        achieved = CONV64_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
+        executed = CONV64_EXECUTED_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
         traffic, traffic_source = conv64_hbm_traffic()
-        line['roofline'] = {'kernel': 'conv2d 3x3 64->64 (+bias, LeakyReLU, InstanceNorm partials) over 48 planes '
-                                      'of 144x240, one launch', 'bound': 'mfma', 'achieved': achieved,
-                            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                            'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_source,
-                            'launch_ms': kernel_ms, 'gflop_per_launch': CONV64_GFLOP,
-                            'algorithm': 'Winograd F(2,3) along x on the fp32 MFMA units (16x16-pixel tiles): "achieved" '
-                                         'counts the ALGORITHMIC flops of the direct convolution; the MFMA pipe '
-                                         'executes executed_gflop_per_launch',
-                            'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
-                            'executed_tflops': CONV64_EXECUTED_GFLOP / kernel_ms,
-                            'frac_executed': CONV64_EXECUTED_GFLOP / kernel_ms / FP32_MFMA_PEAK_TFLOPS}
-        if os.environ.get('PDS_WINOGRAD', '1')[:1] == '0':
-            line['roofline']['algorithm'] = 'direct implicit GEMM (PDS_WINOGRAD=0)'
-            line['roofline']['executed_gflop_per_launch'] = CONV64_GFLOP
-            line['roofline']['executed_tflops'] = achieved
-            line['roofline']['frac_executed'] = achieved / FP32_MFMA_PEAK_TFLOPS
+        # "achieved" / "frac" are the EXECUTED matrix flops against the peak of the pipe that executes them (SURVEY.md 8d:
+        # F_executed / (t * peak)); the algorithmic figures of the direct fp32 convolution are carried beside them
+        line['roofline'] = {
+            'kernel': 'conv2d 3x3 64->64 (+bias, LeakyReLU, InstanceNorm partials) over 48 planes of 144x240, one launch '
+                      '(%s)' % ('conv2d_x3_kernel' if X3 else 'conv2d_wino16_kernel'),
+            'bound': 'mfma', 'achieved': executed, 'peak': CONV64_EXECUTED_PEAK, 'unit': 'TFLOP/s',
+            'frac': executed / CONV64_EXECUTED_PEAK,
+            'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_source,
+            'launch_ms': kernel_ms, 'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
+            'algorithm': ('fp32 operands split three ways into bf16, six partial products per multiply on '
+                          'v_mfma_f32_32x32x16_bf16 with fp32 accumulation (as accurate as the fp32 fmaf chain): executed '
+                          'flops = 6 x algorithmic, priced against the dense bf16 MFMA peak; the bare six-product MFMA '
+                          'stream sustains 1940 TFLOP/s on this chip (power-limited clock, tools/ubench/bf16x3_probe.hip)')
+                         if X3 else 'Winograd F(2,3) along x on the fp32 MFMA units: executed flops = 2/3 algorithmic',
+            'algorithmic_gflop_per_launch': CONV64_GFLOP,
+            'algorithmic_tflops': CONV64_GFLOP / kernel_ms,
+            'algorithmic_frac_of_fp32_mfma_peak': CONV64_GFLOP / kernel_ms / FP32_MFMA_PEAK_TFLOPS}
+        frame_ms = line['ms_per_frame']
+        line['path_roofline'] = {
+            'what': 'whole hot path, one pair strictly after the other (ms_per_frame)',
+            'ms_per_frame': frame_ms,
+            'algorithmic_gflop_reference': PATH_GFLOP_REFERENCE,
+            'algorithmic_gflop_minimal': PATH_GFLOP_MINIMAL,
+            'tflops_reference_count': PATH_GFLOP_REFERENCE / frame_ms,
+            'tflops_minimal_count': PATH_GFLOP_MINIMAL / frame_ms,
+            'frac_of_fp32_mfma_peak_minimal_count': PATH_GFLOP_MINIMAL / frame_ms / FP32_MFMA_PEAK_TFLOPS,
+            'fp32_mfma_floor_ms_minimal_count': PATH_GFLOP_MINIMAL / FP32_MFMA_PEAK_TFLOPS,
+            'algorithmic_mb': PATH_ALGORITHMIC_MB,
+            'hbm_gbps_algorithmic': PATH_ALGORITHMIC_MB / frame_ms,
+            'hbm_frac_of_8tbps': PATH_ALGORITHMIC_MB / frame_ms / 8000.0,
+            'note': 'SURVEY.md 8d counts; the 64-channel layers run on the bf16 pipe (6 executed flops per algorithmic '
+                    'one), so the fp32-MFMA floor is a yardstick here, not a bound'}
         ordered = sorted(args.steps / w for w in windows)
         line['windows'] = {'count': len(windows), 'median': ordered[len(ordered) // 2], 'min': ordered[0],
                            'max': ordered[-1], 'unit': 'pairs/s',
@@ -515,6 +633,10 @@ def main():
             del cost_g
             line['cpu_baseline'] = base
             line['parity'] = parity
+            try:
+                line['gpu_baseline'] = gpu_baseline(net, ld_g, rd_g, sc_g, device, disparity)
+            except Exception as e:   # a baseline leg must never take the line down
+                line['gpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,96 @@
+"""GPU (-m gpu): the data-parallel training step of BASELINE.json configs[4], as far as one GPU can
+exercise it: two processes (gloo; both bound to cuda:0 -- RCCL needs one device per rank) wrap the network in
+DistributedDataParallel, each trains on its own stereo pair for two RMSprop steps (reference pds_trainer.py:35-46,
+train_on_flyingthings3d.py:55-68).  Afterwards both ranks must hold bit-identical parameters, and they must equal a
+single-process run that averages the two pairs' gradients by hand before each optimizer step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HEIGHT, WIDTH, MAX_DISPARITY, STEPS = 64, 128, 63, 2
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        trainer = DataParallelTrainer(MAX_DISPARITY, dev, share_device=True)
+        left, right, truth = synthetic_example(HEIGHT, WIDTH, MAX_DISPARITY, 1 + rank, dev)
+        losses = [float(trainer.step(left, right, truth)) for _ in range(STEPS)]
+        in_sync = trainer.replicas_in_sync()
+        torch.cuda.synchronize()
+        results[rank] = {'in_sync': in_sync, 'losses': losses,
+                         'params': [p.detach().cpu() for p in trainer.network.parameters()]}
+    finally:
+        dist.destroy_process_group()
+
+
+def single_process_reference(dev):
+    """The same two steps in one process: gradient of each pair in turn, averaged, one RMSprop step."""
+    from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
+    trainer = DataParallelTrainer(MAX_DISPARITY, dev)
+    examples = [synthetic_example(HEIGHT, WIDTH, MAX_DISPARITY, 1 + r, dev) for r in range(2)]
+    params = list(trainer.network.parameters())
+    for _ in range(STEPS):
+        total = [torch.zeros_like(p) for p in params]
+        for left, right, truth in examples:
+            trainer.optimizer.zero_grad(set_to_none=True)
+            trainer.criterion(trainer.network(left, right), truth).backward()
+            for t, p in zip(total, params):
+                t += p.grad
+        for t, p in zip(total, params):
+            p.grad = t / len(examples)
+        trainer.optimizer.step()
+    return [p.detach().cpu() for p in params]
+
+
+def test_two_rank_data_parallel_training_steps(hip_library):
+    assert torch.cuda.is_available()
+    ctx = mp.get_context('spawn')
+    results = ctx.Manager().dict()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():   # a hung rendezvous must not outlive the test
+            p.kill()
+            p.join(10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    first, second = results[0], results[1]
+    assert first['in_sync'] and second['in_sync']
+    assert all(torch.equal(a, b) for a, b in zip(first['params'], second['params']))
+    assert all(l == l and abs(l) < 1e3 for l in first['losses'] + second['losses'])
+    # the two ranks saw different pairs: their losses differ, the averaged update is shared
+    assert first['losses'][0] != second['losses'][0]
+    expected = single_process_reference(torch.device('cuda:0'))
+    initial = single_process_initial()
+    moved = 0.0
+    for got, want, start in zip(first['params'], expected, initial):
+        # same arithmetic up to the order of the two-term gradient sum (exact) and RMSprop's elementwise math
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), float((got - want).abs().max())
+        moved = max(moved, float((got - start).abs().max()))
+    assert moved > 1e-3, 'the optimizer steps must have changed the parameters'
+
+
+def single_process_initial():
+    import practicaldeepstereo_nips2018_amd as pds
+    torch.manual_seed(0)
+    return [p.detach().clone() for p in pds.PdsNetwork.default(MAX_DISPARITY).parameters()]

@@ -44,26 +44,13 @@ def main():
         else:
             dist.init_process_group(args.backend)
     height, width, max_disparity = (int(v) for v in args.size.split('x'))
-    torch.manual_seed(0)                      # identical initial weights on every rank
-    net = pds.PdsNetwork.default(max_disparity).to(device).train()
-    model = net
-    if world > 1:
-        from torch.nn.parallel import DistributedDataParallel
-        model = DistributedDataParallel(net, device_ids=None if args.share_device else [local_rank])
-    optimizer = torch.optim.RMSprop(net.parameters(), lr=1e-2)
-    criterion = pds.SubpixelCrossEntropy()
-    g = torch.Generator().manual_seed(1 + rank)   # a different synthetic pair per rank
-    left = (torch.rand(1, 3, height, width, generator=g) * 255).to(device)
-    right = (torch.rand(1, 3, height, width, generator=g) * 255).to(device)
-    truth = (torch.rand(1, height, width, generator=g) * (max_disparity - 1)).to(device)
-    truth[:, :16] = float('inf')              # a band without ground truth
+    from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
+    trainer = DataParallelTrainer(max_disparity, device, share_device=args.share_device)
+    net = trainer.network
+    left, right, truth = synthetic_example(height, width, max_disparity, 1 + rank, device)   # another pair per rank
 
     def step():
-        optimizer.zero_grad(set_to_none=True)
-        loss = criterion(model(left, right), truth)
-        loss.backward()
-        optimizer.step()
-        return loss.detach()
+        return trainer.step(left, right, truth)
 
     losses = []
     for _ in range(args.warmup):
@@ -82,12 +69,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # every rank must hold the same weights after the same number of synchronised steps
-        flat = torch.cat([p.detach().flatten() for p in net.parameters()])
-        lo, hi = flat.clone(), flat.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        in_sync = bool(torch.equal(lo, hi))
+        in_sync = trainer.replicas_in_sync()
     if rank == 0:
         values = [float(v) for v in losses]
         line = {'metric': 'training steps (stereo pairs)/sec, %dx%d D=%d, PdsNetwork train + SubpixelCrossEntropy + '
