@@ -403,7 +403,16 @@ def g11_training_step():
     rep['param_grad_reference_fp32_vs_fp64_rel_max'] = float(reference_rel[live].max())
     rep['param_grad_oracle_fp32_vs_fp64_rel_max'] = float(oracle_rel[live].max())
     assert float(oracle_rel[live].max()) <= max(3.0 * float(reference_rel[live].max()), 1e-4), rep
+    # element-wise evidence: a strided sub-sample (at most 512 entries) of every parameter gradient, from the
+    # reference's fp32 run and from its fp64 run, concatenated; tensor i owns [grad_sub_offsets[i], grad_sub_offsets[i+1])
+    def sub(t):
+        flat = t.detach().flatten()
+        return flat[::max(1, -(-flat.numel() // 512))]
+    subs32 = [sub(grads[n]).double() for n in names]
+    subs64 = [sub(grads64[n]) for n in names]
+    offsets = np.cumsum([0] + [t.numel() for t in subs64])
     save('g11_training_step', loss=value.detach(), ground_truth=gt,
+         grad_sub_offsets=offsets, grad_sub=torch.cat(subs32).float(), grad_sub_fp64=torch.cat(subs64),
          grad_norms=np.array([grads[n].double().norm().item() for n in names]),
          grad_norms_fp64=np.array([grads64[n].norm().item() for n in names]),
          grad_abs_max=np.array([grads[n].abs().max().item() for n in names]),

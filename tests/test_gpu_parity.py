@@ -271,9 +271,11 @@ def test_config1_hot_path_vs_golden(dev):
     # the gates are the smooth error, the number of flips, and the fp64 arbiter (as for config 2 below).
     rep = helpers.disparity_report(disparity, g['disparity'])
     print('config1 disparity', rep)
+    flipped = round(rep['flips'] * disparity.numel())
     assert rep['mae_noflip'] <= 1e-4, rep
-    assert rep['flips'] <= 1e-4, rep           # at most 3 pixels
-    assert rep['mae'] <= 5e-3, rep
+    assert flipped <= 3, rep
+    # raw MAE: 1e-3 (north_star) with no flip; every flipped arg-max may add its own jump (at most 63 px / 32 768 px)
+    assert rep['mae'] <= TOL_DISPARITY_MAE + flipped * 63.0 / disparity.numel(), rep
     p32 = {k: v.cpu() for k, v in net.state_dict().items()}
     with torch.no_grad():
         disp64 = oracle.hot_path(oracle.cast_params(p32, torch.float64), ld.double(), rd.double(),
@@ -325,21 +327,22 @@ def test_config2_full_size_vs_oracle_and_golden(dev):
     # differs from its fp64 output by MAE 5.4e-4 / 4 flips at this size (re-measured with
     # tools/noise_floor.py), so GPU-vs-CPU MAE is (GPU flips + CPU flips) * ~1.5e-4.  Gates:
     #   smooth error (pixels that did not flip)  <= 1e-4 px
-    #   flip fraction                            <= 3e-5  (16 of 552 960 pixels)
-    #   raw MAE                                  <= 2e-3, printed; the 1e-3 target is checked against
-    #                                               the fp64 arbiter in test_config2_fp64_arbiter
+    #   flipped arg-maxes                        <= 8 pixels of 552 960 (the reference's fp32-vs-fp64 count is 4)
+    #   raw MAE                                  <= 1e-3 (north_star), also against the fp64 arbiter in
+    #                                               test_config2_fp64_arbiter
     rep = helpers.disparity_report(disparity, disp_o)
     print('config2 disparity vs oracle', rep)
-    assert rep['flips'] <= 3e-5, rep
+    assert round(rep['flips'] * disparity.numel()) <= 8, rep
     assert rep['mae_noflip'] <= 1e-4, rep
-    assert rep['mae'] <= 2e-3, rep
+    assert rep['mae'] <= TOL_DISPARITY_MAE, rep
     sub = helpers.disparity_report(disparity[:, ::16, ::16], g['disparity_sub'])
     assert sub['mae'] <= 1e-1, sub     # 2 160 samples: one ~100 px flip alone is 0.046
     # fused eval path at full size
     _, _, fused = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     rep_f = helpers.disparity_report(fused, disp_o)
     print('config2 fused disparity vs oracle', rep_f)
-    assert rep_f['flips'] <= 3e-5 and rep_f['mae_noflip'] <= 1e-4 and rep_f['mae'] <= 2e-3, rep_f
+    assert round(rep_f['flips'] * fused.numel()) <= 8 and rep_f['mae_noflip'] <= 1e-4, rep_f
+    assert rep_f['mae'] <= TOL_DISPARITY_MAE, rep_f
     # BASELINE configs[2] at full size: the 48 planes as 2 / 4 / 8 shards of 24 / 12 / 6 planes (what the ranks of
     # distributed.ShardedMatching compute, here one after the other on this GPU); the gathered signatures must equal
     # the unsharded ones bit for bit, hence everything downstream too
@@ -392,8 +395,8 @@ def test_config4_kitti_shape_batch(dev):
     _, _, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     rep = helpers.disparity_report(disparity, disp_o)
     print('config4 disparity vs oracle', rep)
-    assert rep['flips'] <= 3e-5 and rep['mae_noflip'] <= 1e-4, rep
-    assert rep['mae'] <= 2e-3, rep
+    assert round(rep['flips'] * disparity.numel()) <= 12 and rep['mae_noflip'] <= 1e-4, rep   # 983 040 pixels
+    assert rep['mae'] <= TOL_DISPARITY_MAE, rep
     out = net._size_adapter.unpad(disparity)
     assert out.shape == (2, 375, 1242)
 
@@ -425,21 +428,38 @@ def test_hot_path_is_graph_capturable(dev):
             assert torch.equal(captured, eager)
 
 
-def test_config4_full_batch_runs(dev):
-    """BASELINE configs[3] at its full batch of 4 (shape and finiteness only; values are checked at
-    batch 2 against the oracle above)."""
+def test_config4_full_batch_values(dev):
+    """BASELINE configs[3] at its full batch of 4 (375x1242 -> 96x320 descriptors, D=256): shapes, ranges, and VALUES:
+    the oracle evaluates the batch entries one at a time on the host (InstanceNorm statistics are per batch entry, so
+    entry b of the batched HIP result must equal the oracle on entry b alone); signatures, cost (strided sub-sample)
+    and disparity are checked for the first and the last entry."""
     torch.manual_seed(0)
-    net = pds.PdsNetwork.default(255).eval().to(dev)
+    net = pds.PdsNetwork.default(255).eval()
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
     g = torch.Generator().manual_seed(12)
-    ld = torch.randn(4, 64, 96, 320, generator=g).to(dev)
-    rd = torch.randn(4, 64, 96, 320, generator=g).to(dev)
-    sc = torch.randn(4, 8, 96, 320, generator=g).to(dev)
+    ld = torch.randn(4, 64, 96, 320, generator=g)
+    rd = torch.randn(4, 64, 96, 320, generator=g)
+    sc = torch.randn(4, 8, 96, 320, generator=g)
     with torch.no_grad():
-        ms = net._matching(ld, rd)
-        disparity = net._regularization.forward_with_estimator(ms, sc, net._estimator)
+        ms = net._matching(ld.to(dev), rd.to(dev))
+        cost = net._regularization(ms, sc.to(dev))
+        cost_sub = cost[:, ::8, ::16, ::16].cpu()
+        del cost
+        disparity = net._regularization.forward_with_estimator(ms, sc.to(dev), net._estimator)
     assert ms.shape == (4, 8, 64, 96, 320) and disparity.shape == (4, 384, 1280)
     assert bool(torch.isfinite(disparity).all())
     assert float(disparity.min()) >= 0.0 and float(disparity.max()) <= 254.0 + 1e-3
+    for b in (0, 3):
+        with torch.no_grad():
+            ms_o, cost_o, disp_o = oracle.hot_path(params, ld[b:b + 1], rd[b:b + 1], sc[b:b + 1], 255,
+                                                   return_stages=True)
+        assert helpers.maxdiff(ms[b:b + 1], ms_o) <= TOL_SIGNATURES, b
+        assert helpers.maxdiff(cost_sub[b:b + 1], cost_o[:, ::8, ::16, ::16]) <= TOL_COST_MAX, b
+        rep = helpers.disparity_report(disparity[b:b + 1], disp_o)
+        print('config4 batch entry', b, rep)
+        assert round(rep['flips'] * disp_o.numel()) <= 6 and rep['mae_noflip'] <= 1e-4, rep
+        assert rep['mae'] <= TOL_DISPARITY_MAE, rep
 
 
 def test_stream_pipelines_are_bit_identical(dev):
