@@ -40,6 +40,8 @@
 //               runs across tile boundaries (the next tile is drawn at stage 0), so a CU never drains between tiles.
 //   epilogue    bias, LeakyReLU, float4 stores, per-(plane, channel) sum / sum of squares -> one fp64 record per tile
 //               (the deferred InstanceNorm of common.hpp), folded by the staging waves during the next tile.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace pds {
@@ -47,7 +49,7 @@ namespace pds {
 namespace {
 
 constexpr int TH = 16, TW = 32, ROWS = TH + 2, COLS = TW + 2, PIX = ROWS * COLS;   // halo tile 18 x 34 = 612 pixels
-constexpr int THREADS = 512, STAGERS = 256, GROUP = 128;   // waves 0-3 MFMA, 4-5 / 6-7 the two staging groups
+constexpr int THREADS = 512, STAGERS = 256;   // waves 0-3 MFMA, waves 4-7 staging
 constexpr int IN_PART = 2 * PIX * 16;          // bytes of one split part: [channel group][row][column][8 bf16]
 constexpr int IN_BUF = 3 * IN_PART;            // 58 752
 constexpr int W_FRAG = 64 * 16;                // one B fragment
@@ -59,9 +61,9 @@ constexpr int CMAX = 256;                      // most input channels with a def
 constexpr int LDS_COEF = LDS_NEXT + 16;        // [tile parity 2][scale | shift][CMAX] floats
 constexpr int LDS_BYTES = LDS_COEF + 2 * 2 * CMAX * 4;
 constexpr int THIRD_ROWS = ROWS / 3, THIRD_PIX = THIRD_ROWS * COLS;   // 204 staging items per channel group and third
-constexpr int W_ITERS = (W_STAGE / 16 + GROUP - 1) / GROUP;           // 16-byte pieces of a weight stage per thread: 9
+constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;       // 16-byte pieces of a weight stage per thread: 5
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-static_assert(THIRD_PIX <= 2 * GROUP, "two pixels per staging thread and third");
+static_assert(THIRD_PIX <= STAGERS, "one pixel per staging thread and third");
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -379,145 +381,104 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
 }
 
 // ---- waves 4-7 -----------------------------------------------------------------------------------------------------
-// Two groups of two waves take the stages in turn (group = stage parity): a group writes, at its stage, what it
-// requested at its previous one -- two stages earlier -- and then issues the requests for its next one.  A request
-// therefore has a whole stage of MFMA time plus its own stage to land (global latency under load is ~2 us, about one
-// stage); with one group and a one-stage lag every stage began by waiting for the loads issued at the end of the
-// previous one.
+// All four waves work at every stage, on a two-deep ring of request registers: at stage s a thread writes what it
+// requested at stage s - 2 (set s & 1) and re-uses that set for the requests of stage s + 2.  A request therefore has
+// two whole stages to land (global latency under load is ~2 us, about one stage; with a one-stage lag every stage
+// began by waiting for the loads issued at the end of the previous one).  The stage loop is unrolled by two so that
+// the set index is a compile-time constant; a stage body is one function that also does the end-of-tile bookkeeping.
 template <bool NORM>
 __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char* lds, int st, int cur_id) {
     const size_t plane = (size_t)A.H * A.W;
     const unsigned cstride = (unsigned)(A.D * plane);          // floats between channels
     const int nks = A.nks, nstages = 3 * nks;
-    const int group = __builtin_amdgcn_readfirstlane(st >> 7);
-    const int t = st & (GROUP - 1);
-    // a thread stages two pixels (t and t + 128 of the 204 of a third) x 16 channels (the two groups of 8)
-    int lds_item[2];
-    int prow[2], pcol[2];
-    bool valid[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int px = t + k * GROUP;
-        valid[k] = px < THIRD_PIX;
-        prow[k] = valid[k] ? px / COLS : 0;
-        pcol[k] = valid[k] ? px % COLS : 0;
-        lds_item[k] = (prow[k] * COLS + pcol[k]) * 16;   // + (part * 2 + channel group) * PIX * 16 + third * THIRD_PIX * 16
-    }
+    // a thread stages one pixel (of the 204 of a third) x 16 channels (the two groups of 8)
+    const bool valid = st < THIRD_PIX;
+    const int prow = valid ? st / COLS : 0, pcol = valid ? st % COLS : 0;
+    const int lds_item = (prow * COLS + pcol) * 16;   // + (part * 2 + channel group) * PIX * 16 + third * THIRD_PIX * 16
     int* next_slot = reinterpret_cast<int*>(lds + LDS_NEXT);
     const int home = blockIdx.x & 7;
     const int n_full = A.tiles_y * A.tiles_x_full;
 
-    float xin[2][2][8];  // [pixel][channel group][channel]: requested at this group's previous stage
-    u32x4 win[W_ITERS];  // this thread's pieces of the weight stage requested at this group's previous stage
+    float xin[2][16];         // [set][channel of the K-step]
+    u32x4 win[2][W_ITERS];    // [set][this thread's pieces of a weight stage]
+    float coef_s[2] = {1.f, 1.f}, coef_h[2] = {0.f, 0.f};   // [set]: the thread's channel of the NEXT tile's table
     const int wlast = W_STAGE / 16 - 1;
+    const int coef_c = min(st, A.Cin - 1);
     float* coef_tab = reinterpret_cast<float*>(lds + LDS_COEF);
 
-    auto request_inputs = [&](const Tile& tl, int ks, int third) {
+    auto request_inputs = [&](float (&x)[16], const Tile& tl, int ks, int third) {
         const float* src = A.a.p + ((size_t)(tl.n * A.Cin + ks * 16) * A.D + tl.d) * plane;   // uniform
-        unsigned off[2];
+        const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
+        const int yc = min(max(y, 0), A.H - 1), xc = min(max(xx, 0), A.W - 1);
+        const unsigned off = (unsigned)(yc * A.W + xc);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int y = tl.y0 - 1 + third * THIRD_ROWS + prow[k], x = tl.x0 - 1 + pcol[k];
-            const int yc = min(max(y, 0), A.H - 1), xc = min(max(x, 0), A.W - 1);
-            off[k] = (unsigned)(yc * A.W + xc);
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float* sc = src + (size_t)c * cstride;   // uniform channel base (scalar registers) + one lane offset
-#pragma unroll
-            for (int k = 0; k < 2; ++k) xin[k][c >> 3][c & 7] = sc[off[k]];
-        }
+        for (int c = 0; c < 16; ++c) x[c] = (src + (size_t)c * cstride)[off];   // uniform channel base + one lane offset
     };
-    auto write_inputs = [&](const Tile& tl, int ks, int third, unsigned char* buf, const float* coef) {
+    auto write_inputs = [&](const float (&x)[16], const Tile& tl, int ks, int third, unsigned char* buf,
+                            const float* coef) {
         // the producer's folded InstanceNorm of this (batch entry, plane): table of the tile in LDS, one address per
-        // wave (broadcast reads), all sixteen channels requested up front (one LDS round trip per turn, not per item)
+        // wave (broadcast reads), all sixteen channels up front (one LDS round trip per stage)
         f32x4 cs[4], ch[4];
         if (NORM) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#ifdef PDS_X3_NOCOEFREAD
-                cs[j] = f32x4{1.f, 1.5f, 0.5f, 0.75f};
-                ch[j] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
-#else
                 cs[j] = *reinterpret_cast<const f32x4*>(coef + ks * 16 + 4 * j);
                 ch[j] = *reinterpret_cast<const f32x4*>(coef + CMAX + ks * 16 + 4 * j);
-#endif
             }
         }
+        const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
+        const bool inimg = y >= 0 && y < A.H && xx >= 0 && xx < A.W;
+        // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
+        unsigned h[3][16];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int y = tl.y0 - 1 + third * THIRD_ROWS + prow[k], x = tl.x0 - 1 + pcol[k];
-            const bool inimg = y >= 0 && y < A.H && x >= 0 && x < A.W;
+        for (int c = 0; c < 16; ++c) {
+            float r = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : x[c];
+            r = inimg ? r : 0.f;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    v[i] = NORM ? x3_fma(cs[2 * g + (i >> 2)][i & 3], xin[k][g][i], ch[2 * g + (i >> 2)][i & 3]) : xin[k][g][i];
-                // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
-                unsigned h[3][8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float r = inimg ? v[i] : 0.f;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const unsigned u = __builtin_bit_cast(unsigned, r);
-                        h[p][i] = u;
-                        if (p < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
-                    }
-                }
-                if (valid[k]) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        u32x4 w;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)   // bytes [3:2] of the odd channel above bytes [3:2] of the even one
-                            w[j] = __builtin_amdgcn_perm(h[p][2 * j + 1], h[p][2 * j], 0x07060302u);
-                        *reinterpret_cast<u32x4*>(buf + (p * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item[k]) = w;
-                    }
-                }
+            for (int p = 0; p < 3; ++p) {
+                const unsigned u = __builtin_bit_cast(unsigned, r);
+                h[p][c] = u;
+                if (p < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
             }
+        }
+        if (valid) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    u32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)   // bytes [3:2] of the odd channel above bytes [3:2] of the even one
+                        w[j] = __builtin_amdgcn_perm(h[p][8 * g + 2 * j + 1], h[p][8 * g + 2 * j], 0x07060302u);
+                    *reinterpret_cast<u32x4*>(buf + (p * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = w;
+                }
         }
     };
-    auto request_weights = [&](int stage) {
+    auto request_weights = [&](u32x4 (&w)[W_ITERS], int stage) {
         const u32x4* src = reinterpret_cast<const u32x4*>(A.wpk + (size_t)stage * W_STAGE);
 #pragma unroll
-        for (int it = 0; it < W_ITERS; ++it) win[it] = src[min(it * GROUP + t, wlast)];
+        for (int it = 0; it < W_ITERS; ++it) w[it] = src[min(it * STAGERS + st, wlast)];
     };
-    auto write_weights = [&](unsigned char* buf) {
+    auto write_weights = [&](const u32x4 (&w)[W_ITERS], unsigned char* buf) {
         u32x4* dst = reinterpret_cast<u32x4*>(buf);
 #pragma unroll
-        for (int it = 0; it < W_ITERS; ++it) dst[min(it * GROUP + t, wlast)] = win[it];
+        for (int it = 0; it < W_ITERS; ++it) dst[min(it * STAGERS + st, wlast)] = w[it];
     };
     // folded InstanceNorm coefficients of the NEXT tile's (batch entry, plane) -> its table in LDS: part of every
-    // request / write turn (two channels per thread, so each group covers all of them), branch-free -- a load inside
-    // a branch merges with "no load" in a phi and the compiler then drains ALL outstanding loads at the merge.
-    // The writes of the first turns carry the placeholder tile's values and are overwritten by the later ones well
-    // before the table is first read (stage 3 * nks - 3 >= 6).
-    float coef_s[2] = {1.f, 1.f}, coef_h[2] = {0.f, 0.f};
-    auto coef_channel = [&](int k) { return min(t + k * GROUP, A.Cin - 1); };
-    auto coef_index = [&](const Tile& tl, int c) -> size_t {
-        return A.a.per_plane ? ((size_t)(tl.n * A.Cin + c) * A.D + tl.d) : (size_t)(tl.n * A.Cin + c);
-    };
-    auto request_coef = [&](const Tile& tl) {
-#ifndef PDS_X3_NOCOEFLOAD
+    // stage's requests / writes, branch-free -- a load inside a branch merges with "no load" in a phi and the compiler
+    // then drains ALL outstanding loads at the merge.  The writes of the first stages carry the placeholder tile's
+    // values and are overwritten by the later ones well before the table is first read (stage 3 * nks - 3 >= 6).
+    auto request_coef = [&](float& cs, float& ch, const Tile& tl) {
         if (NORM) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const size_t g = coef_index(tl, coef_channel(k));
-                coef_s[k] = A.a.scale[g];
-                coef_h[k] = A.a.shift[g];
-            }
+            const size_t g = A.a.per_plane ? ((size_t)(tl.n * A.Cin + coef_c) * A.D + tl.d) : (size_t)(tl.n * A.Cin + coef_c);
+            cs = A.a.scale[g];
+            ch = A.a.shift[g];
         }
-#endif
     };
-    auto write_coef = [&](int table) {
+    auto write_coef = [&](float cs, float ch, int table) {
         if (NORM) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                coef_tab[table * 2 * CMAX + coef_channel(k)] = coef_s[k];
-                coef_tab[table * 2 * CMAX + CMAX + coef_channel(k)] = coef_h[k];
-            }
+            coef_tab[table * 2 * CMAX + coef_c] = cs;
+            coef_tab[table * 2 * CMAX + CMAX + coef_c] = ch;
         }
     };
     // one fp64 (sum, sum of squares) record per tile and channel from the four MFMA waves' rows
@@ -532,85 +493,86 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         }
     };
 
-    // ---- prologue: the first tile's coefficient table, first K-step and weight stage (group 0); then each group's
-    // requests of what its first stage writes
+    // ---- prologue: the first tile's coefficient table, first K-step and weight stage; then the requests of what the
+    // first two stages write (set 0: stage 0, set 1: stage 1)
     Tile cur = decode_tile(A, cur_id);
     Tile nxt = cur, done = cur;
     int nxt_id = -1;
     int tpar = 0;             // coefficient table of the current tile
-    request_coef(cur);
-    write_coef(0);
-    if (group == 0) {
-        request_weights(0);
-        write_weights(lds + LDS_W);
-    }
+    request_coef(coef_s[0], coef_h[0], cur);
+    write_coef(coef_s[0], coef_h[0], 0);
+    request_weights(win[0], 0);
+    write_weights(win[0], lds + LDS_W);
     x3_barrier();
-    if (group == 0) {
-        for (int third = 0; third < 3; ++third) {
-            request_inputs(cur, 0, third);
-            write_inputs(cur, 0, third, lds, coef_tab);
-        }
+    for (int third = 0; third < 3; ++third) {
+        request_inputs(xin[0], cur, 0, third);
+        write_inputs(xin[0], cur, 0, third, lds, coef_tab);
     }
-    // group g's first stage is stage g: it writes third g of K-step 1 and weight stage g + 1
-    request_weights(1 + group);
-    request_inputs(cur, 1, group);
-    request_coef(cur);
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {   // stage `set` writes third `set` of K-step 1 and weight stage `set` + 1
+        request_weights(win[set], 1 + set);
+        request_inputs(xin[set], cur, 1, set);
+        request_coef(coef_s[set], coef_h[set], cur);
+    }
     int upar = 0, wpar = 0;   // LDS buffer of the K-step / weight stage being consumed
-    int gpar = 0;             // parity of the global stage count: the group whose turn it is
+    int rs = 0;               // stage within the current tile
     bool fold_pending = false;
     x3_barrier();
 
-    for (;;) {
-#pragma unroll 1
-        for (int rs = 0; rs < nstages; ++rs) {
-            const int ks = rs / 3, dy = rs - 3 * ks;
-            if (rs == 1) {   // the tile drawn during stage 0 (published by its barrier)
-                nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
-                if (nxt_id >= 0) nxt = decode_tile(A, nxt_id);
-            }
-            // requests whose answer this stage itself needs go out first (a counted wait then skips the younger ones)
-            int drawn = -1;
-            if (rs == 0 && st == 0) drawn = draw_tile(A.queue, home, A.planes, A.tiles, A.tiles_x, A.tiles_x_full, n_full);
-#ifndef PDS_X3_NOSTAGE
-            if (group == gpar) {
-                // -- write what this group requested two stages ago: third (rs % 3) of K-step ks + 1 and weight stage
-                // rs + 1.  No branch stands between a request and its use (a phi of loaded values makes the compiler
-                // wait where the branches merge): past the last tile the sequence re-stages the current tile into
-                // the idle buffer, which nobody reads.
-                {
-                    const bool into_next = ks + 1 >= nks;
-                    write_inputs(pick_tile(into_next, nxt, cur), into_next ? 0 : ks + 1, dy, lds + (upar ^ 1) * IN_BUF,
-                                 coef_tab + ((into_next ? tpar ^ 1 : tpar) * 2 * CMAX));
-                    write_weights(lds + LDS_W + (wpar ^ 1) * W_STAGE);
-                    write_coef(tpar ^ 1);
-                }
-                // -- requests for this group's next stage (rs + 2): sequence position rs + 5, weight stage rs + 3
-                {
-                    const int q = rs + 5;
-                    const int ksl = q / 3, third = q - 3 * ksl;
-                    const bool into_next = ksl >= nks;
-                    request_inputs(pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
-                    int ws = rs + 3;
-                    if (ws >= nstages) ws -= nstages;
-                    request_weights(ws);
-                    request_coef(nxt);
-                }
-            }
-#endif
-            // -- housekeeping with the staging waves' spare time
-            if (rs == 0 && st == 0) next_slot[0] = drawn;
-            if (rs == 1 && fold_pending) fold_statistics(done);
-            if (dy == 2) upar ^= 1;
-            wpar ^= 1;
-            gpar ^= 1;
-            x3_barrier();
+    // one stage on register set SET; returns true after the last stage of the last tile
+    auto stage = [&](auto set_constant) -> bool {
+        constexpr int SET = decltype(set_constant)::value;
+        const int ks = rs / 3, dy = rs - 3 * ks;
+        if (rs == 1) {   // the tile drawn during stage 0 (published by its barrier)
+            nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
+            if (nxt_id >= 0) nxt = decode_tile(A, nxt_id);
         }
+        // a request whose answer this stage itself needs goes out first (its counted wait skips the younger ones)
+        int drawn = -1;
+        if (rs == 0 && st == 0) drawn = draw_tile(A.queue, home, A.planes, A.tiles, A.tiles_x, A.tiles_x_full, n_full);
+#ifndef PDS_X3_NOSTAGE
+        // -- write what was requested two stages ago: third (rs % 3) of K-step ks + 1 and weight stage rs + 1.  No
+        // branch stands between a request and its use (see request_coef): past the last tile the sequence re-stages
+        // the current tile into the idle buffer, which nobody reads.
+        {
+            const bool into_next = ks + 1 >= nks;
+            write_inputs(xin[SET], pick_tile(into_next, nxt, cur), into_next ? 0 : ks + 1, dy,
+                         lds + (upar ^ 1) * IN_BUF, coef_tab + ((into_next ? tpar ^ 1 : tpar) * 2 * CMAX));
+            write_weights(win[SET], lds + LDS_W + (wpar ^ 1) * W_STAGE);
+            write_coef(coef_s[SET], coef_h[SET], tpar ^ 1);
+        }
+        // -- requests of what stage rs + 2 writes: sequence position rs + 5, weight stage rs + 3
+        {
+            const int q = rs + 5;
+            const int ksl = q / 3, third = q - 3 * ksl;
+            const bool into_next = ksl >= nks;
+            request_inputs(xin[SET], pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
+            int ws = rs + 3;
+            if (ws >= nstages) ws -= nstages;
+            request_weights(win[SET], ws);
+            request_coef(coef_s[SET], coef_h[SET], nxt);
+        }
+#endif
+        // -- housekeeping with the staging waves' spare time
+        if (rs == 0 && st == 0) next_slot[0] = drawn;
+        if (rs == 1 && fold_pending) fold_statistics(done);
+        if (dy == 2) upar ^= 1;
+        wpar ^= 1;
+        x3_barrier();
+        if (++rs < nstages) return false;
+        // -- end of the tile
+        rs = 0;
         done = cur;
         fold_pending = true;
-        if (nxt_id < 0) break;
+        if (nxt_id < 0) return true;
         cur = nxt;   // (nxt stays a valid tile -- this one -- until the next draw is read at stage 1)
         nxt_id = -1;
         tpar ^= 1;
+        return false;
+    };
+    for (;;) {
+        if (stage(std::integral_constant<int, 0>{})) break;
+        if (stage(std::integral_constant<int, 1>{})) break;
     }
     x3_barrier();
     fold_statistics(done);
