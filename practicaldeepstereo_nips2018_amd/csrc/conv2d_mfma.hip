@@ -374,19 +374,10 @@ static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
     return check_launch("conv2d_mfma");
 }
 
-// 8-channel chunks for the single-block kernels on plain sources (see Cfg): an experiment kept as an opt-in
-static int chunk_depth(const ConvLayer& L) {
-    static const bool deep = []() {  // opt-in (PDS_CONV2D_KC8=1): measured slower on the 64 -> 8 layer (470 vs 400 us)
-        const char* e = getenv("PDS_CONV2D_KC8");
-        return e && e[0] == '1';
-    }();
-    return (deep && mfma_blocks(L.out_g.c) == 1 && !L.l0A && L.plane_weight_sets == 0 && L.in.c % 8 == 0) ? 8 : KC;
-}
-
 int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     if (!L.packed) return set_error(-1, "conv2d_mfma: packed weights missing");
     const int mb = mfma_blocks(L.out_g.c);
-    const int kc = chunk_depth(L);
+    const int kc = KC;
     const int sets = L.plane_weight_sets > 0 ? L.plane_weight_sets : 1;
     if (L.plane_weight_sets > 0 && L.plane_weight_sets != L.in.d)
         return set_error(-1, "conv2d_mfma: %d weight sets for %d planes", L.plane_weight_sets, L.in.d);
@@ -439,19 +430,6 @@ int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s) {
     const bool has_b = L.b.p != nullptr, has_l0 = L.l0A != nullptr, has_a = L.a.p != nullptr;
     if (has_l0 && has_b) return set_error(-1, "conv2d_mfma: layer-0 terms and a second source together");
     const int src = has_l0 ? (has_a ? 3 : 2) : (has_b ? 1 : 0);
-    static const bool pairs_enabled = []() {  // opt-in (PDS_CONV2D_PAIRS=1): measured neutral on the 64 -> 8 layer
-        const char* e = getenv("PDS_CONV2D_PAIRS");
-        return e && e[0] == '1';
-    }();
-    const bool pairs = pairs_enabled && !has_l0 && !L.side_out && (A.W % 2) == 0 && A.W >= 2;
-    if (kc == 8) {  // mb == 1, plain sources
-        if (pairs) return src == 1 ? launch_cfg<1, 1, true, 8>(A, s) : launch_cfg<1, 0, true, 8>(A, s);
-        return src == 1 ? launch_cfg<1, 1, false, 8>(A, s) : launch_cfg<1, 0, false, 8>(A, s);
-    }
-    if (pairs) {
-        if (mb == 4) return src == 1 ? launch_cfg<4, 1, true>(A, s) : launch_cfg<4, 0, true>(A, s);
-        return src == 1 ? launch_cfg<1, 1, true>(A, s) : launch_cfg<1, 0, true>(A, s);
-    }
     if (mb == 4) {
         switch (src) {
             case 0: return launch_cfg<4, 0>(A, s);

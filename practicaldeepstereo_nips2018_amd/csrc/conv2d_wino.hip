@@ -407,30 +407,17 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     A.w_set_stride = L.plane_weight_sets > 0 ? (size_t)total : 0;
     A.bias_set_stride = L.plane_weight_sets > 0 ? L.out_g.c : 0;
     const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
-    static const int halves = []() {  // PDS_WINO_WAVES=4 selects the 4-wave form (A/B)
-        const char* e = getenv("PDS_WINO_WAVES");
-        return (e && e[0] == '4') ? 1 : 2;
-    }();
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (first_use_on_device(attr_done)) {
         const int bytes = (int)(160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
     const dim3 grid(A.tiles, A.D, A.N);
-    if (halves == 2) {
-        if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2>), grid, dim3(512), lds_bytes, s, A);
-        else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2>), grid, dim3(512), lds_bytes, s, A);
-    } else {
-        if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 1>), grid, dim3(256), lds_bytes, s, A);
-        else hipLaunchKernelGGL((conv2d_wino_kernel<false, 1>), grid, dim3(256), lds_bytes, s, A);
-    }
+    if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2>), grid, dim3(512), lds_bytes, s, A);
+    else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2>), grid, dim3(512), lds_bytes, s, A);
     return check_launch("conv2d_wino");
 }
 

@@ -104,15 +104,18 @@ __device__ __forceinline__ int draw_tile(int* queue, int home, int planes, int t
         const int j = atomicAdd(queue + q, 1);
         if (j >= planes_q * tiles) continue;
         int pl, tile;
-        if (j < planes_q * n_full) {
-            pl = j / n_full;
-            const int r = j - pl * n_full;
+        // the half-cost tiles (right half outside the image) come FIRST: workgroups that start on one run half a tile
+        // out of phase with the others for the rest of the launch, so the chip-wide store bursts of the epilogues
+        // (every CU finishes its tile at the same time otherwise) come in two halves
+        if (j >= planes_q * n_half) {
+            const int jj = j - planes_q * n_half;
+            pl = jj / n_full;
+            const int r = jj - pl * n_full;
             const int ty = r / tiles_x_full;
             tile = ty * tiles_x + (r - ty * tiles_x_full);
         } else {
-            const int r = j - planes_q * n_full;
-            pl = r / n_half;
-            const int rr = r - pl * n_half;
+            pl = j / n_half;
+            const int rr = j - pl * n_half;
             const int cols_half = tiles_x - tiles_x_full;
             const int ty = rr / cols_half;
             tile = ty * tiles_x + tiles_x_full + (rr - ty * cols_half);
@@ -244,6 +247,9 @@ __device__ __forceinline__ Tile pick_tile(bool second, const Tile& b, const Tile
 
 // ---- waves 0-3 -----------------------------------------------------------------------------------------------------
 struct MfmaLane {
+#ifdef PDS_X3_TIMING   // debugging: cycles in the MFMA stream, at the barriers, in the epilogue; stage count
+    long long tm[4] = {0, 0, 0, 0};
+#endif
     int wave, m32, kgl;
     int x_lane, w_lane;      // byte offsets of the lane's pixel slot (M block 0, dy = dx = 0, part 0) and weight slot
     float bias0, bias1;
@@ -273,66 +279,84 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
         if (rs == 1) nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
         const unsigned char* wb = lds + LDS_W + wpar * W_STAGE + L.w_lane;
         const unsigned char* xb = lds + upar * IN_BUF + dy * (COLS * 16) + L.x_lane;
+#ifdef PDS_X3_TIMING
+        const long long t_a = __builtin_readcyclecounter();
+#endif
 #ifndef PDS_X3_NOMFMA   // (PDS_X3_NO*: timing ablations, never defined in the product build)
         x3_mfma_stage<NARROW>(acc, xb, wb);
 #endif
         if (dy == 2) upar ^= 1;
         wpar ^= 1;
+#ifdef PDS_X3_TIMING
+        const long long t_b = __builtin_readcyclecounter();
+#endif
         x3_barrier();
+#ifdef PDS_X3_TIMING
+        const long long t_c = __builtin_readcyclecounter();
+        const_cast<MfmaLane&>(L).tm[0] += t_b - t_a;
+        const_cast<MfmaLane&>(L).tm[1] += t_c - t_b;
+        const_cast<MfmaLane&>(L).tm[3] += 1;
+#endif
     }
+#ifdef PDS_X3_TIMING
+    const long long t_e0 = __builtin_readcyclecounter();
+#endif
     // ---- epilogue of the tile: bias, LeakyReLU, 16-byte stores, statistics
 #ifdef PDS_X3_NOEPI
     if (acc[0][0][0] != 12345.f) return nxt_id;
 #endif
+    // The epilogue is VALU-bound on the one wave a SIMD has for it (measured 13 900 cycles per tile with ~2 500
+    // instructions; re-shaping the stores into 128-byte runs changed nothing), so it is kept to five operations per
+    // value: bias, LeakyReLU as max(v, slope * v), sum, sum of squares, and one 16-byte store per four values.  Tiles that
+    // touch the image border (or rows that are not 16-byte aligned) take the masked form.
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     float* obase = A.out + (((size_t)cur.n * A.CoutStride) * A.D + cur.d) * L.plane;   // uniform
-    const bool vec = (A.W & 3) == 0;
+    const float slope = A.lrelu ? kLeakySlope : 1.f;
     constexpr int MBLOCKS = NARROW ? 2 : 4;
-#pragma unroll
-    for (int mb = 0; mb < MBLOCKS; ++mb) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int m0 = 8 * g + 4 * L.kgl;   // first of the lane's four consecutive pixels of the M block
-            const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (m0 >> 4) : mb);
-            const int x = cur.x0 + (NARROW ? (m0 & 15) : m0);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const float bv = nb ? L.bias1 : L.bias0;
-                float t[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    t[e] = acc[mb][nb][4 * g + e] + bv;
-                    if (A.lrelu) t[e] = t[e] > 0.f ? t[e] : t[e] * kLeakySlope;
-                }
-                float* po = obase + (size_t)(nb * 32 + L.m32) * L.cstride + (size_t)y * A.W + x;
-                float ls = 0.f, lq = 0.f;
-                if (y < A.H) {
-                    if (vec) {
-                        if (x < A.W) {
-                            *reinterpret_cast<f32x4*>(po) = f32x4{t[0], t[1], t[2], t[3]};
-                            ls = (t[0] + t[1]) + (t[2] + t[3]);
-                            lq = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], t[3] * t[3])));
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (x + e < A.W) {
-                                po[e] = t[e];
-                                ls += t[e];
-                                lq = fmaf(t[e], t[e], lq);
-                            }
-                    }
-                }
-                if (nb) {
-                    s1 += ls;
-                    q1 += lq;
-                } else {
-                    s0 += ls;
-                    q0 += lq;
-                }
-            }
-        }
+    const bool interior = (A.W & 3) == 0 && cur.y0 + TH <= A.H && cur.x0 + (NARROW ? 16 : TW) <= A.W;   // uniform
+#define PDS_X3_EPILOGUE(MASKED)                                                                                       \
+    _Pragma("unroll") for (int mb = 0; mb < MBLOCKS; ++mb) {                                                          \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                               \
+            const int m0 = 8 * g + 4 * L.kgl;   /* first of the lane's four consecutive pixels of the M block */      \
+            const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (m0 >> 4) : mb);                                   \
+            const int x = cur.x0 + (NARROW ? (m0 & 15) : m0);                                                         \
+            _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                        \
+                const float bv = nb ? L.bias1 : L.bias0;                                                              \
+                float t[4];                                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                    const float v = acc[mb][nb][4 * g + e] + bv;                                                      \
+                    t[e] = fmaxf(v, v * slope);                                                                       \
+                }                                                                                                     \
+                float* po = obase + (size_t)(nb * 32 + L.m32) * L.cstride + (size_t)y * A.W + x;                      \
+                float ls = 0.f, lq = 0.f;                                                                             \
+                if (!(MASKED)) {                                                                                      \
+                    *reinterpret_cast<f32x4*>(po) = f32x4{t[0], t[1], t[2], t[3]};                                    \
+                    ls = (t[0] + t[1]) + (t[2] + t[3]);                                                               \
+                    lq = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], t[3] * t[3])));                           \
+                } else if (y < A.H) {                                                                                 \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
+                        if (x + e < A.W) {                                                                            \
+                            po[e] = t[e];                                                                             \
+                            ls += t[e];                                                                               \
+                            lq = fmaf(t[e], t[e], lq);                                                                \
+                        }                                                                                             \
+                }                                                                                                     \
+                if (nb) {                                                                                             \
+                    s1 += ls;                                                                                         \
+                    q1 += lq;                                                                                         \
+                } else {                                                                                              \
+                    s0 += ls;                                                                                         \
+                    q0 += lq;                                                                                         \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
     }
+    if (interior) {
+        PDS_X3_EPILOGUE(false)
+    } else {
+        PDS_X3_EPILOGUE(true)
+    }
+#undef PDS_X3_EPILOGUE
     if (A.partials) {
         // the two halves of the wave hold the same channels (pixels 4 apart): one exchange, then lanes 0-31 write
         s0 += __shfl_xor(s0, 32, 64);
@@ -345,6 +369,9 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
             *reinterpret_cast<float2*>(red + (L.wave * 64 + 32 + L.m32) * 2) = make_float2(s1, q1);
         }
     }
+#ifdef PDS_X3_TIMING
+    const_cast<MfmaLane&>(L).tm[2] += __builtin_readcyclecounter() - t_e0;
+#endif
     return nxt_id;
 }
 
@@ -377,6 +404,11 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
         }
         if (cur_id < 0) break;
     }
+#ifdef PDS_X3_TIMING
+    if ((blockIdx.x == 0 || blockIdx.x == 131) && lane == 0)
+        printf("[x3] wg %d wave %d: mfma %lld  barrier %lld  epilogue %lld cycles over %lld stages\n", (int)blockIdx.x, wave,
+               L.tm[0], L.tm[1], L.tm[2], L.tm[3]);
+#endif
     x3_barrier();
 }
 
@@ -672,7 +704,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     const long long all = (long long)A.planes * A.tiles;
     const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
     if (hipMemsetAsync(A.queue, 0, 8 * sizeof(int), s) != hipSuccess) return check_launch("conv2d_x3 queue reset");
-    if (L.a.scale && !getenv("PDS_X3_FORCE_PLAIN")) hipLaunchKernelGGL((conv2d_x3_kernel<true>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
+    if (L.a.scale) hipLaunchKernelGGL((conv2d_x3_kernel<true>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
     else hipLaunchKernelGGL((conv2d_x3_kernel<false>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
     return check_launch("conv2d_x3");
 }

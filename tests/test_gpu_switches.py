@@ -12,11 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
-    {'PDS_WINOGRAD': '0'},          # direct MFMA kernel for the 64-channel layers
-    {'PDS_WINO_WAVES': '4'},        # 4-wave form of the F(2,3) kernel
-    {'PDS_WINO_TILE16': '0'},       # wide (4 x 64) Winograd tiles everywhere
-    {'PDS_CONV2D_PAIRS': '1'},      # 8-byte staging in the direct kernel
-    {'PDS_CONV2D_KC8': '1'},        # 8-channel chunks in the single-block direct kernels
+    {'PDS_X3': '0'},                         # exact-fp32 MFMA kernels (Winograd domain) instead of the bf16-split kernel
+    {'PDS_X3': '0', 'PDS_WINOGRAD': '0'},    # ... and the direct exact-fp32 MFMA kernel
+    {'PDS_X3': '0', 'PDS_WINO_TILE16': '0'},   # ... with wide (4 x 64) Winograd tiles everywhere
     {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
     {'PDS_MATCHING_COLUMNS': '0'},  # whole-plane form of the layer-0 / layer-1 factorisation (3 + 5 planes)
     {'PDS_CONV3D_XCD_MAP': '0'},
