@@ -22,9 +22,10 @@ are reported beside it.  Rank 0 prints ONE JSON line.
 
 The line also carries
   roofline     - the dominant kernel (conv2d 3x3 64->64 over all disparity planes): its launch is timed in
-                 isolation with HIP events through pds_conv_block_fwd; achieved = EXECUTED matrix flops per launch
-                 (6 bf16 flops per algorithmic one: three-way split operands) / mean duration against the dense
-                 bf16 MFMA peak; the algorithmic fp32 figures ride along.
+                 isolation with HIP events through pds_conv_block_chained_fwd (input behind a deferred InstanceNorm,
+                 as in the hot path); achieved = EXECUTED matrix flops per launch (3 fp16 flops per algorithmic one:
+                 two-way split operands, three partial products) / mean duration against the dense 16-bit MFMA peak;
+                 the algorithmic fp32 figures ride along.
   path_roofline- the whole hot path at ms_per_frame against SURVEY.md 8d's counts.
   gpu_baseline - the same restatement on the MI355X through PyTorch-ROCm / MIOpen (no hand-written kernels).
   cpu_baseline - the oracle (oracle/pds_oracle.py, PyTorch-CPU restatement of the reference) on the
@@ -74,12 +75,15 @@ def conv64_hbm_traffic():
                        rec['algorithmic_bytes'] / 1e6))
 
 
-# Round 3: the layer runs on the bf16 matrix pipe (csrc/conv2d_x3.hip): every fp32 operand is split three ways into
-# bf16 and six of the nine partial products are accumulated in fp32 -- as accurate as the fp32 fmaf chain (measured,
-# tools/ubench/bf16x3_probe.hip).  EXECUTED work = 6 bf16 MFMA flops per algorithmic flop, priced against the dense bf16
-# MFMA peak; PDS_X3=0 selects the exact-fp32 Winograd kernel of round 2 (2/3 of the flops on the fp32 MFMA pipe).
+# Round 3: the layer runs on the 16-bit matrix pipe (csrc/conv2d_x3.hip): every fp32 operand is split into two fp16
+# parts (pre-scaled by exact powers of two) and three of the four partial products are accumulated in fp32 -- more
+# accurate than the fp32 fmaf chain (measured, tools/ubench/fp16x2_probe.hip).  EXECUTED work = 3 fp16 MFMA flops per
+# algorithmic flop, priced against the dense fp16 MFMA peak (== the bf16 one).  PDS_X3_FP16=0 selects the range-safe
+# bf16 form (three parts, six products), PDS_X3=0 the exact-fp32 Winograd kernel of round 2 (2/3 of the flops on the
+# fp32 MFMA pipe).
 X3 = os.environ.get('PDS_X3', '1')[:1] != '0'
-CONV64_EXECUTED_GFLOP = CONV64_GFLOP * 6.0 if X3 else CONV64_GFLOP * (2.0 / 3.0)
+X3_PRODUCTS = 3.0 if os.environ.get('PDS_X3_FP16', '1')[:1] != '0' else 6.0
+CONV64_EXECUTED_GFLOP = CONV64_GFLOP * X3_PRODUCTS if X3 else CONV64_GFLOP * (2.0 / 3.0)
 CONV64_EXECUTED_PEAK = BF16_MFMA_PEAK_TFLOPS if X3 else FP32_MFMA_PEAK_TFLOPS
 # algorithmic work of the whole hot path per pair at configs[1]
 PATH_GFLOP_REFERENCE = 791.9   # as the reference executes it (dense first layer)
@@ -145,7 +149,10 @@ def time_dominant_kernel(net, device, reps):
     block = net._matching._operation._matching_operation_modules[1].convolutions[0]
     params = _lib.conv_block_params(block.conv, block.norm)
     n, c, d, h, w = 1, 64, (MAX_DISPARITY + 1) // 4, 144, 240
-    x = torch.randn(n, c, d, h, w, device=device)
+    # as in the hot path: the input is the raw output of the previous block, the loader applies its folded InstanceNorm
+    x = torch.randn(n, c, d, h, w, device=device) * 1.7 + 0.3
+    x_scale = torch.full((n * c * d,), 1.0 / 1.7, device=device)
+    x_shift = torch.full((n * c * d,), -0.3 / 1.7, device=device)
     raw = torch.empty_like(x)
     scale = torch.empty(n * c * d, device=device)
     shift = torch.empty(n * c * d, device=device)
@@ -154,9 +161,10 @@ def time_dominant_kernel(net, device, reps):
     stream = _lib.stream_handle(device)
 
     def launch():
-        _lib.check(lib.pds_conv_block_fwd(ctypes.byref(params), _lib.ptr(x), _lib.ptr(raw), _lib.ptr(scale),
-                                          _lib.ptr(shift), n, c, c, d, h, w, 1, 1, 1, _lib.ptr(ws), ws.numel(),
-                                          stream), 'pds_conv_block_fwd')
+        _lib.check(lib.pds_conv_block_chained_fwd(ctypes.byref(params), _lib.ptr(x), _lib.ptr(x_scale), _lib.ptr(x_shift),
+                                                  1, _lib.ptr(raw), _lib.ptr(scale), _lib.ptr(shift), n, c, c, d, h, w,
+                                                  1, 1, 1, _lib.ptr(ws), ws.numel(), stream),
+                   'pds_conv_block_chained_fwd')
     for _ in range(2):
         launch()
     torch.cuda.synchronize(device)
@@ -596,10 +604,11 @@ def main():
             'frac': executed / CONV64_EXECUTED_PEAK,
             'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_source,
             'launch_ms': kernel_ms, 'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
-            'algorithm': ('fp32 operands split three ways into bf16, six partial products per multiply on '
-                          'v_mfma_f32_32x32x16_bf16 with fp32 accumulation (as accurate as the fp32 fmaf chain): executed '
-                          'flops = 6 x algorithmic, priced against the dense bf16 MFMA peak; the bare six-product MFMA '
-                          'stream sustains 1940 TFLOP/s on this chip (power-limited clock, tools/ubench/bf16x3_probe.hip)')
+            'algorithm': ('fp32 operands split into %s, %d partial products per multiply on v_mfma_f32_32x32x16_%s with fp32 '
+                          'accumulation (mean error below the fp32 fmaf chain\'s, tools/ubench/fp16x2_probe.hip): executed '
+                          'flops = %d x algorithmic, priced against the dense 16-bit MFMA peak; the bare MFMA stream '
+                          'sustains 1800-1900 TFLOP/s on this chip (power-limited clock)' %
+                          (('two fp16 parts', 3, 'f16', 3) if X3_PRODUCTS == 3.0 else ('three bf16 parts', 6, 'bf16', 6)))
                          if X3 else 'Winograd F(2,3) along x on the fp32 MFMA units: executed flops = 2/3 algorithmic',
             'algorithmic_gflop_per_launch': CONV64_GFLOP,
             'algorithmic_tflops': CONV64_GFLOP / kernel_ms,
@@ -618,7 +627,7 @@ def main():
             'hbm_gbps_algorithmic': PATH_ALGORITHMIC_MB / frame_ms,
             'hbm_frac_of_8tbps': PATH_ALGORITHMIC_MB / frame_ms / 8000.0,
             'note': 'SURVEY.md 8d counts; the 64-channel layers run on the bf16 pipe (6 executed flops per algorithmic '
-                    'one), so the fp32-MFMA floor is a yardstick here, not a bound'}
+                    'one), so the fp32-MFMA floor is a yardstick here, not a bound'.replace('6 executed', '3 executed')}
         ordered = sorted(args.steps / w for w in windows)
         line['windows'] = {'count': len(windows), 'median': ordered[len(ordered) // 2], 'min': ordered[0],
                            'max': ordered[-1], 'unit': 'pairs/s',

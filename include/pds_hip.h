@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDS_ABI_VERSION 2
+#define PDS_ABI_VERSION 3
 
 typedef void* pds_stream_t; /* hipStream_t */
 
@@ -176,6 +176,15 @@ size_t pds_conv_block_workspace_bytes(int n, int cin, int cout, int d, int h, in
 int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* raw, float* scale,
                        float* shift, int n, int cin, int cout, int d, int h, int w, int kd, int stride,
                        int per_plane, void* workspace, size_t workspace_bytes, pds_stream_t stream);
+/* ABI v3.  The same block chained behind another one, as inside the modules (network_blocks.py:47-72: Conv ->
+ * LeakyReLU -> InstanceNorm, then the next Conv): x is the producer's RAW output and the loader applies the producer's
+ * folded InstanceNorm, x^ = x_scale * x + x_shift ([n*cin], or [n*cin*d] when x_per_plane).  Same workspace size as
+ * pds_conv_block_fwd.  This is the form in which the 64 -> 64 layers of MatchingOperation (matching.py:85-88) run in
+ * the hot path, and the launch bench.py times for the roofline of the dominant kernel. */
+int pds_conv_block_chained_fwd(const PdsConvBlockParams* params, const float* x, const float* x_scale,
+                               const float* x_shift, int x_per_plane, float* raw, float* scale, float* shift,
+                               int n, int cin, int cout, int d, int h, int w, int kd, int stride, int per_plane,
+                               void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward (training: loss.backward() in reference pds_trainer.py:40-46 reaches these modules through

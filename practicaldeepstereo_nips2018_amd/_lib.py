@@ -89,12 +89,30 @@ def build_library(force=False, verbose=False):
     objdir = os.path.join(os.path.dirname(_PKG_DIR), 'build', 'obj')
     os.makedirs(objdir, exist_ok=True)
 
+    import hashlib
+    headers = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hpp')) + [HEADER_PATH]
+    base = hashlib.sha256(' '.join(BUILD_FLAGS).encode())
+    for path in headers:
+        with open(path, 'rb') as f:
+            base.update(f.read())
+
     def compile_one(src):
+        # an object is reused when the digest of flags + headers + its own source recorded beside it still matches
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
+        h = base.copy()
+        with open(src, 'rb') as f:
+            h.update(f.read())
+        mark = obj + '.sha256'
+        if not force and os.path.exists(obj) and os.path.exists(mark):
+            with open(mark) as f:
+                if f.read().strip() == h.hexdigest():
+                    return obj
         cmd = ['hipcc'] + BUILD_FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)
+        with open(mark, 'w') as f:
+            f.write(h.hexdigest() + '\n')
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
@@ -132,6 +150,8 @@ SIGNATURES = {
     'pds_conv_block_workspace_bytes': (_SZ, [_I] * 9),
     'pds_conv_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _VP,
                                 _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_conv_block_chained_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _I, _VP, _VP, _VP,
+                                        _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
     'pds_regularization_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(RegularizationParams), _I, _I, _I, _I]),
     'pds_regularization_bwd': (_I, [ctypes.POINTER(RegularizationParams), ctypes.POINTER(RegularizationParams),
                                     _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP, _SZ, _VP]),
@@ -167,7 +187,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 2   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
+ABI_VERSION = 3   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
 
 
 def load():

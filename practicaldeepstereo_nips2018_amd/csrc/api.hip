@@ -257,6 +257,7 @@ struct ConvExtra {
     // a k5 s2 layer evaluated as k3 s1 over space-to-depth input (any kernel): weights to use instead of P.weight
     const float* weight_used = nullptr;
     int s2d_cin = 0;
+    int unit_range = 0;   // conv2d_x3: the plain input is O(1) (a residual sum of normalised tensors)
     bool matching_extras() const { return l0A || side_out || plane_weight_sets > 0; }
 };
 
@@ -294,6 +295,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.d_begin = extra->d_begin;
         L.side_out = extra->side_out;
         L.plane_weight_sets = extra->plane_weight_sets;
+        L.unit_range = extra->unit_range;
     }
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
     // Winograd domain (plain single-source Cin -> 64 layers), 9 = conv2d on the bf16 pipe with three-way split operands
@@ -429,8 +431,11 @@ static void operation_tail(Ctx& c, const PdsMatchingParams& P, const Src& x0, co
     const int F = P.features;
     Src cur = x0;
     DT t2;
+    ConvExtra unit;   // x0 (a convolution of descriptors) and the residual sums are plain tensors of O(1) values
+    unit.unit_range = 1;
     for (int r = 0; r < P.residual_blocks; ++r) {
-        DT t1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
+        DT t1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1, nullptr, true, nullptr, nullptr,
+                           cur.scale ? nullptr : &unit);
         t2 = conv_block(c, t1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
         if (r + 1 < P.residual_blocks) {
             DT nxt;  // plain residual sum  x_{r+1} = norm(t2) + x_r
@@ -630,8 +635,10 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur, c.s));
     float* spare_a = t2.raw;                        // free from here on
     float* spare_b = c.get<float>(g.numel());
+    ConvExtra unit;          // x_r = norm(t2) + x_{r-1}: a plain tensor of O(1) values
+    unit.unit_range = 1;
     for (int r = 1; r < P.residual_blocks; ++r) {
-        t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a);
+        t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a, true, nullptr, nullptr, &unit);
         t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1, spare_b);
         if (r + 1 < P.residual_blocks) {
             float* nxt = spare_a;                   // t1 is dead: x_{r+1} = norm(t2) + x_r goes there
@@ -778,8 +785,11 @@ static void embedding_pipeline(Ctx& c, const PdsEmbeddingParams& P, const float*
     // residual blocks (embedding.py:38-41); the last sum is the descriptor
     const Geom g = t2.g;
     Src cur = t2.src();
+    ConvExtra unit;   // a residual sum of normalised tensors is a plain tensor of O(1) values (conv2d_x3: fp16 form)
+    unit.unit_range = 1;
     for (int r = 0; r < P.residual_blocks; ++r) {
-        DT u1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
+        DT u1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1, nullptr, true, nullptr, nullptr,
+                           cur.scale ? nullptr : &unit);
         DT u2 = conv_block(c, u1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
         DT nxt;
         nxt.g = g;
@@ -1184,6 +1194,27 @@ int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* 
     Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
     conv_block(c, plain_src(x), no_src(), Geom{n, cin, d, h, w}, *params, cout, kd, stride, per_plane, raw, true,
                scale, shift);
+    return c.err;
+}
+
+// The same block behind another block: x is the producer's RAW output and the loader applies the producer's folded
+// InstanceNorm, x^ = x_scale * x + x_shift (per (n, c), or per (n, c, d) when x_per_plane) -- how the blocks of
+// MatchingOperation / Regularization are chained inside the modules (no normalised tensor is ever stored).
+int pds_conv_block_chained_fwd(const PdsConvBlockParams* params, const float* x, const float* x_scale,
+                               const float* x_shift, int x_per_plane, float* raw, float* scale, float* shift, int n,
+                               int cin, int cout, int d, int h, int w, int kd, int stride, int per_plane,
+                               void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    PDS_REQUIRE(params && x && x_scale && x_shift && raw && workspace, "conv_block_chained: null pointer");
+    PDS_REQUIRE(params->weight && params->bias, "conv_block_chained: null weight/bias");
+    PDS_REQUIRE(n > 0 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, "conv_block_chained: bad shape");
+    PDS_REQUIRE((kd == 1 || kd == 3) && (stride == 1 || stride == 2) && !(kd == 1 && stride == 2),
+                "conv_block_chained: unsupported kd=%d stride=%d", kd, stride);
+    if (params->gamma) PDS_REQUIRE(params->beta && scale && shift, "conv_block_chained: null InstanceNorm outputs");
+    const size_t need = pds_conv_block_workspace_bytes(n, cin, cout, d, h, w, kd, stride, per_plane);
+    PDS_REQUIRE(workspace_bytes >= need, "conv_block_chained: workspace too small (%zu < %zu)", workspace_bytes, need);
+    Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
+    const Src src{x, x_scale, x_shift, x_per_plane ? 1 : 0, 0};
+    conv_block(c, src, no_src(), Geom{n, cin, d, h, w}, *params, cout, kd, stride, per_plane, raw, true, scale, shift);
     return c.err;
 }
 

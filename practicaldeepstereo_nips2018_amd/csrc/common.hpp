@@ -117,6 +117,9 @@ struct ConvLayer {
     float* side_out = nullptr;
     // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)
     int plane_weight_sets = 0;
+    // conv2d_x3 only: the (plain) input is known to be O(1) -- a residual sum of InstanceNorm'ed tensors -- so the
+    // fp16 split form applies (inputs behind a deferred InstanceNorm always qualify)
+    int unit_range = 0;
     PackSink* sink = nullptr;  // nullptr: pack inline
 };
 

@@ -1,27 +1,33 @@
 // conv2d 3x3 (pad 1, stride 1), Cin -> 64 channels over all (batch, disparity) planes in one launch, with fp32
-// operands emulated on the bf16 matrix pipe: the dominant layers of MatchingOperation (reference
+// operands emulated on the 16-bit matrix pipe: the dominant layers of MatchingOperation (reference
 // practical_deep_stereo/matching.py:85-88, network_blocks.py:134-144; also the 64-channel layers of embedding.py).
 //
-// Arithmetic.  gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 MFMA rate, so the exact-fp32 Winograd kernel
-// (conv2d_wino16.hip) is pipe-bound at ~106 executed TFLOP/s.  Here every fp32 operand is split three ways into bf16,
-//     a = a1 + a2 + a3  (exact: 3 x 8 significand bits),        b = b1 + b2 + b3,
-// and the product is accumulated as the six partial products of order <= 2^-16,
-//     a*b ~= a1*b1 + a1*b2 + a2*b1 + a2*b2 + a1*b3 + a3*b1     (dropped: a2*b3 + a3*b2 + a3*b3 <= 2^-23 |a*b|),
-// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Measured on an MI355X
-// (tools/ubench/bf16x3_probe.hip, K = 576 as in this layer): mean |error| 2.4e-7 against 3.1e-7 of the fp32 fmaf chain
-// -- the emulation is not a precision trade (fewer, wider-accumulated roundings), and it is range-safe (bf16 has the
-// fp32 exponent).  Six bf16 MFMAs do the work of eight fp32 ones at 16x the rate: 2.7x the fp32 pipe's peak; the bare
-// MFMA stream sustains 323 fp32-equivalent TFLOP/s on random data (power-limited clock), 0.38 ms for this layer's
-// 122.3 GFLOP at config 2.  Weights are split once (round-to-nearest, pack.hip mode 6), activations while they are
-// staged (truncation split: and / sub / and / sub, then v_perm packs two channels per dword).
-//
+// Arithmetic.  gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the 16-bit MFMA rate, so the exact-fp32 Winograd kernel
+// (conv2d_wino16.hip) is pipe-bound at ~106 executed TFLOP/s.  Here every fp32 operand is split into 16-bit parts and the
+// product is the sum of the leading partial products, each an exact 16-bit x 16-bit product accumulated in fp32 by
+// v_mfma_f32_32x32x16_{f16,bf16}.  Two forms (template parameter P = parts per operand):
+//   P = 2, fp16 (round 3b)  a = a1 + a2 (2 x 11 significand bits; |a - a1 - a2| <= 2^-22 |a|),
+//       a*b ~= a1*b2 + a2*b1 + a1*b1: THREE products.  fp16 has a 5-bit exponent, so the operands are pre-scaled by exact
+//       powers of two (weights x 2^10 when they are packed, normalised activations x 2^4 inside their InstanceNorm
+//       coefficients; the epilogue multiplies the sums back) -- low parts then stay in or near the normal range and
+//       MFMA inputs keep their subnormals.  Measured on an MI355X (tools/ubench/fp16x2_probe.hip, K = 576 as in this
+//       layer): mean |error| 2.0e-7 against 3.1e-7 of the fp32 fmaf chain, 1 800 TFLOP/s of fp16 = 600 fp32-equivalent
+//       TFLOP/s (power-limited clock): 0.20 ms of bare MFMA time for this layer's 122.3 GFLOP at config 2.
+//       Pre-condition: |activation| < 4 094 behind an InstanceNorm (always true: a normalised value is bounded by the
+//       square root of the plane size), < 65 504 for a plain input -- beyond that the result is inf / NaN, never
+//       silently wrong.  Used when the input is InstanceNorm'ed or the pipeline marks it as O(1) (ConvLayer::unit_range).
+//   P = 3, bf16 (round 3a)  a = a1 + a2 + a3 exactly (3 x 8 bits), SIX products of order <= 2^-16 (dropped:
+//       a2*b3 + a3*b2 + a3*b3 <= 2^-23 |a*b|); bf16 has the fp32 exponent, so this form is range-safe: it takes inputs of
+//       unknown scale (data gradients, plain tensors of the generic entry point).  Mean |error| 2.4e-7; 320
+//       fp32-equivalent TFLOP/s.
+// Weights are split once (round-to-nearest, pack.hip modes 6 / 7), activations while they are staged.
 // Shape.  One persistent 512-thread workgroup per CU (all of its LDS) pulls 16 x 32-pixel tiles of one plane from eight
 // per-XCD queues (atomic counters; planes stay on one XCD's L2, idle workgroups steal).  A tile is a GEMM
 // [512 px] x [64 oc] x [K = Cin * 9] with the PIXELS on the M side, and the waves are specialised:
 //   waves 0-3   MFMA waves, one per SIMD: wave w owns rows 4w .. 4w+3 of the tile (four M blocks of one row x 32
 //               columns) and all 64 output channels (two N blocks): 4 x 2 accumulator tiles of 32 x 32 = 128 VGPRs.
 //               They only read fragments (ds_read_b128, double-buffered by half-taps) and issue MFMAs: per tap
-//               12 pixel + 12 weight fragments feed 48 MFMAs.  In the D fragment a lane holds one output channel
+//               4P pixel + 2P weight fragments feed 8 x (3 or 6) MFMAs.  In the D fragment a lane holds one output channel
 //               and FOUR CONSECUTIVE pixels per register quad, so the epilogue stores 16 bytes per lane and the
 //               InstanceNorm statistics are sums over a lane's own registers (plus one lane exchange).
 //               Tiles whose right half lies outside the image (240 = 7.5 x 32) map their M blocks to 2 rows x 16
@@ -29,11 +35,11 @@
 //   waves 4-7   staging waves, one per SIMD: global loads, the deferred InstanceNorm of the producer, the bf16 split
 //               and the LDS writes run beside the MFMA waves' matrix work (separate pipes, the hardware interleaves
 //               the waves); they also draw the next tile and fold the statistics records.
-//   K-step      16 input channels; stage = (K-step, dy) = 3 taps, one barrier per stage (144 MFMAs per MFMA wave).
-//   LDS         inputs  IN[2][part 3][channel group 2][18 rows][34 columns][8 bf16]   2 x 58 752 B, written once per
+//   K-step      16 input channels; stage = (K-step, dy) = 3 taps, one barrier per stage (72 / 144 MFMAs per MFMA wave).
+//   LDS         inputs  IN[2][part P][channel group 2][18 rows][34 columns][8 x 16 bit]   2 x P x 19 584 B, written once per
 //               K-step and read by all nine taps; a lane's fragment is one 16-byte slot and the 32 lanes of an M block
 //               read 32 consecutive slots (conflict free for any row);
-//               weights W[2][dx 3][part 3][N block 2][64 lanes][16 B]                  2 x 18 432 B per stage, in
+//               weights W[2][dx 3][part P][N block 2][64 lanes][16 B]                  2 x P x 6 144 B per stage, in
 //               fragment order (lane-linear reads).
 //   staging     one stage ahead: what was requested during stage s-1 is converted and written during stage s (inputs
 //               of the next K-step by thirds, weights of stage s+1), then the next requests are issued; the sequence
@@ -50,25 +56,38 @@ namespace {
 
 constexpr int TH = 16, TW = 32, ROWS = TH + 2, COLS = TW + 2, PIX = ROWS * COLS;   // halo tile 18 x 34 = 612 pixels
 constexpr int THREADS = 512, STAGERS = 256;   // waves 0-3 MFMA, waves 4-7 staging
-constexpr int IN_PART = 2 * PIX * 16;          // bytes of one split part: [channel group][row][column][8 bf16]
-constexpr int IN_BUF = 3 * IN_PART;            // 58 752
+constexpr int IN_PART = 2 * PIX * 16;          // bytes of one split part: [channel group][row][column][8 x 16 bit]
 constexpr int W_FRAG = 64 * 16;                // one B fragment
-constexpr int W_STAGE = 3 * 3 * 2 * W_FRAG;    // [dx][part][N block]: 18 432
-constexpr int LDS_W = 2 * IN_BUF;
-constexpr int LDS_RED = LDS_W + 2 * W_STAGE;   // [4 MFMA waves][64 channels][2] floats
-constexpr int LDS_NEXT = LDS_RED + 4 * 64 * 2 * 4;
 constexpr int CMAX = 256;                      // most input channels with a deferred InstanceNorm on the input
-constexpr int LDS_COEF = LDS_NEXT + 16;        // [tile parity 2][scale | shift][CMAX] floats
-constexpr int LDS_BYTES = LDS_COEF + 2 * 2 * CMAX * 4;
 constexpr int THIRD_ROWS = ROWS / 3, THIRD_PIX = THIRD_ROWS * COLS;   // 204 staging items per channel group and third
-constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;       // 16-byte pieces of a weight stage per thread: 5
-static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 static_assert(THIRD_PIX <= STAGERS, "one pixel per staging thread and third");
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+// LDS map and arithmetic constants of the two forms: P parts per operand (3: bf16, six products; 2: fp16, three products)
+template <int P>
+struct X3Cfg {
+    static constexpr int IN_BUF = P * IN_PART;             // 58 752 / 39 168
+    static constexpr int W_STAGE = 3 * P * 2 * W_FRAG;     // [dx][part][N block]: 18 432 / 12 288
+    static constexpr int LDS_W = 2 * IN_BUF;
+    static constexpr int LDS_RED = LDS_W + 2 * W_STAGE;    // [4 MFMA waves][64 channels][2] floats
+    static constexpr int LDS_NEXT = LDS_RED + 4 * 64 * 2 * 4;
+    static constexpr int LDS_COEF = LDS_NEXT + 16;         // [tile parity 2][scale | shift][CMAX] floats
+    static constexpr int LDS_BYTES = LDS_COEF + 2 * 2 * CMAX * 4;
+    static constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;   // 16-byte pieces of a weight stage per thread
+    static constexpr int PRODUCTS = P == 3 ? 6 : 3;
+    // power-of-two operand scales of the fp16 form (exact): weights when packed, normalised activations in the folded
+    // InstanceNorm coefficients; plain activations are taken as they are
+    static constexpr float W_SCALE = P == 2 ? 1024.f : 1.f;
+    static constexpr float A_SCALE_NORM = P == 2 ? 16.f : 1.f;
+};
+static_assert(X3Cfg<3>::LDS_BYTES <= 160 * 1024 && X3Cfg<2>::LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // eight 16-bit operands (bf16 or fp16 bits)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct X3Args {
     Src a;
@@ -142,8 +161,14 @@ __device__ __forceinline__ void x3_interleave() {
     }
 }
 
-template <bool NARROW, int T, int I>
-__device__ __forceinline__ void x3_step(f32x16 (&acc)[4][2], bf16x8 (&fw)[2][3][2], bf16x8 (&fp)[2][3],
+template <int P>
+__device__ __forceinline__ f32x16 x3_mma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (P == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int P, bool NARROW, int T, int I>
+__device__ __forceinline__ void x3_step(f32x16 (&acc)[4][2], bf16x8 (&fw)[2][P][2], bf16x8 (&fp)[2][P],
                                         const unsigned char* xb, const unsigned char* wb) {
     constexpr int NMB = NARROW ? 2 : 4;
     constexpr int K = T * NMB + I;
@@ -152,54 +177,56 @@ __device__ __forceinline__ void x3_step(f32x16 (&acc)[4][2], bf16x8 (&fw)[2][3][
     if constexpr (I + 1 < NMB || T < 2) {
         constexpr int tn = I + 1 < NMB ? T : T + 1, in = I + 1 < NMB ? I + 1 : 0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < P; ++p)
             fp[(K + 1) & 1][p] =
                 *reinterpret_cast<const bf16x8*>(xb + p * IN_PART + (in * ROWSTEP * COLS + tn) * 16);
     }
-    // ... and this step's share of the next tap's weight fragments (parts 0, 1, 2 over the first steps of the tap)
+    // ... and this step's share of the next tap's weight fragments (the parts go out over the first steps of the tap)
+    constexpr int first = (NARROW && P == 3) ? (I == 0 ? 0 : 2) : I;
+    constexpr int last = (NARROW && P == 3) ? (I == 0 ? 1 : 2) : (I < P ? I : -1);
     if constexpr (T < 2) {
-        constexpr int first = NARROW ? (I == 0 ? 0 : 2) : I, last = NARROW ? (I == 0 ? 1 : 2) : (I < 3 ? I : -1);
 #pragma unroll
         for (int p = first; p <= last; ++p)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
                 fw[(T + 1) & 1][p][nb] =
-                    *reinterpret_cast<const bf16x8*>(wb + (((T + 1) * 3 + p) * 2 + nb) * W_FRAG);
+                    *reinterpret_cast<const bf16x8*>(wb + (((T + 1) * P + p) * 2 + nb) * W_FRAG);
     }
     // small partial products first
+    constexpr int NPROD = X3Cfg<P>::PRODUCTS;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const int pa = c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 1 : 0;   // pixel part
-        const int pb = c == 0 ? 2 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 1 : c == 4 ? 0 : 0;   // weight part
+    for (int c = 0; c < NPROD; ++c) {
+        // (pixel part, weight part): P = 3: (0,2) (2,0) (1,1) (0,1) (1,0) (0,0);  P = 2: (0,1) (1,0) (0,0)
+        const int pa = P == 3 ? (c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 1 : 0) : (c == 1 ? 1 : 0);
+        const int pb = P == 3 ? (c == 0 ? 2 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 1 : c == 4 ? 0 : 0) : (c == 0 ? 1 : 0);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-            acc[I][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[K & 1][pa], fw[T & 1][pb][nb], acc[I][nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[I][nb] = x3_mma<P>(fp[K & 1][pa], fw[T & 1][pb][nb], acc[I][nb]);
     }
     // the requests go out in the shadow of the first MFMAs (each on registers of the idle set), not after the last use
     // of the registers they would otherwise recycle
-    constexpr int NP = (I + 1 < NMB || T < 2) ? 3 : 0;
-    constexpr int NW = T < 2 ? (NARROW ? (I == 0 ? 4 : 2) : (I < 3 ? 2 : 0)) : 0;
+    constexpr int NP = (I + 1 < NMB || T < 2) ? P : 0;
+    constexpr int NW = (T < 2 && last >= first) ? 2 * (last - first + 1) : 0;
     x3_interleave<NP + NW>();
-    __builtin_amdgcn_sched_group_barrier(0x008, 12 - NP - NW, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPROD - NP - NW, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool NARROW>
+template <int P, bool NARROW>
 __device__ __forceinline__ void x3_mfma_stage(f32x16 (&acc)[4][2], const unsigned char* xb, const unsigned char* wb) {
-    bf16x8 fw[2][3][2], fp[2][3];
+    bf16x8 fw[2][P][2], fp[2][P];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < P; ++p) {
         fp[0][p] = *reinterpret_cast<const bf16x8*>(xb + p * IN_PART);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) fw[0][p][nb] = *reinterpret_cast<const bf16x8*>(wb + (p * 2 + nb) * W_FRAG);
     }
     __builtin_amdgcn_sched_barrier(0);
-#define PDS_X3_TAP(T)                                         \
-    x3_step<NARROW, T, 0>(acc, fw, fp, xb, wb);               \
-    x3_step<NARROW, T, 1>(acc, fw, fp, xb, wb);               \
-    if constexpr (!NARROW) {                                  \
-        x3_step<NARROW, T, 2>(acc, fw, fp, xb, wb);           \
-        x3_step<NARROW, T, 3>(acc, fw, fp, xb, wb);           \
+#define PDS_X3_TAP(T)                                            \
+    x3_step<P, NARROW, T, 0>(acc, fw, fp, xb, wb);               \
+    x3_step<P, NARROW, T, 1>(acc, fw, fp, xb, wb);               \
+    if constexpr (!NARROW) {                                     \
+        x3_step<P, NARROW, T, 2>(acc, fw, fp, xb, wb);           \
+        x3_step<P, NARROW, T, 3>(acc, fw, fp, xb, wb);           \
     }
     PDS_X3_TAP(0)
     PDS_X3_TAP(1)
@@ -260,11 +287,12 @@ struct MfmaLane {
 // One tile on an MFMA wave: all stages, then the epilogue.  The accumulators live and die inside this function, per
 // variant, so they never cross a control-flow merge (a phi of 128 registers costs copies and their live ranges).
 // Returns the id of the next tile (read at stage 1).
-template <bool NARROW>
+template <int P, bool NORM, bool NARROW>
 __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds, const MfmaLane& L, const Tile& cur,
                                             int& upar, int& wpar) {
+    using C = X3Cfg<P>;
     const int nstages = 3 * A.nks;
-    const int* next_slot = reinterpret_cast<const int*>(lds + LDS_NEXT);
+    const int* next_slot = reinterpret_cast<const int*>(lds + C::LDS_NEXT);
     int nxt_id = -1;
     f32x16 acc[4][2];
 #pragma unroll
@@ -277,13 +305,13 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
     for (int rs = 0; rs < nstages; ++rs) {
         const int dy = rs % 3;
         if (rs == 1) nxt_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
-        const unsigned char* wb = lds + LDS_W + wpar * W_STAGE + L.w_lane;
-        const unsigned char* xb = lds + upar * IN_BUF + dy * (COLS * 16) + L.x_lane;
+        const unsigned char* wb = lds + C::LDS_W + wpar * C::W_STAGE + L.w_lane;
+        const unsigned char* xb = lds + upar * C::IN_BUF + dy * (COLS * 16) + L.x_lane;
 #ifdef PDS_X3_TIMING
         const long long t_a = __builtin_readcyclecounter();
 #endif
 #ifndef PDS_X3_NOMFMA   // (PDS_X3_NO*: timing ablations, never defined in the product build)
-        x3_mfma_stage<NARROW>(acc, xb, wb);
+        x3_mfma_stage<P, NARROW>(acc, xb, wb);
 #endif
         if (dy == 2) upar ^= 1;
         wpar ^= 1;
@@ -305,13 +333,25 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
 #ifdef PDS_X3_NOEPI
     if (acc[0][0][0] != 12345.f) return nxt_id;
 #endif
-    // The epilogue is VALU-bound on the one wave a SIMD has for it (measured 13 900 cycles per tile with ~2 500
-    // instructions; re-shaping the stores into 128-byte runs changed nothing), so it is kept to five operations per
-    // value: bias, LeakyReLU as max(v, slope * v), sum, sum of squares, and one 16-byte store per four values.  Tiles that
-    // touch the image border (or rows that are not 16-byte aligned) take the masked form.
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    // The epilogue takes ~11 000 cycles per tile whatever its instruction count (measured with PDS_X3_TIMING: the scalar
+    // form with ~2 500 instructions and this packed form with ~900 take the same time): all CUs run the same schedule
+    // and store their 128 KB tiles together, so the wave waits for the memory pipeline, not for the VALU.  On the
+    // six-product form nothing recovered that time (half-cost tiles first, a start-up stagger of 4-48 us over the CUs
+    // of an XCD: the launch is power-limited, any gap is returned as clock).  Packed fp32 arithmetic (v_pk_fma /
+    // v_pk_mul / v_pk_add: two values per instruction and lane) on register pairs that stay where the MFMA left them:
+    // 3.5 instructions per value, no moves to assemble the 16-byte store operands.  Tiles that touch the image border
+    // (or rows that are not 16-byte aligned) take the masked form.
+    f32x2 s2[2][2], q2[2][2];   // [N block][register pair of the quad]: four independent chains per statistic
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) s2[nb][k] = q2[nb][k] = f32x2{0.f, 0.f};
     float* obase = A.out + (((size_t)cur.n * A.CoutStride) * A.D + cur.d) * L.plane;   // uniform
     const float slope = A.lrelu ? kLeakySlope : 1.f;
+    const f32x2 slope2 = {slope, slope};
+    // the fp16 form accumulates (2^10 w) * (2^4 x or x): one exact power of two back, in the same fma as the bias
+    constexpr float unscale = 1.f / (C::W_SCALE * (NORM ? C::A_SCALE_NORM : 1.f));
+    const f32x2 unscale2 = {unscale, unscale};
     constexpr int MBLOCKS = NARROW ? 2 : 4;
     const bool interior = (A.W & 3) == 0 && cur.y0 + TH <= A.H && cur.x0 + (NARROW ? 16 : TW) <= A.W;   // uniform
 #define PDS_X3_EPILOGUE(MASKED)                                                                                       \
@@ -322,32 +362,29 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
             const int x = cur.x0 + (NARROW ? (m0 & 15) : m0);                                                         \
             _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                        \
                 const float bv = nb ? L.bias1 : L.bias0;                                                              \
-                float t[4];                                                                                           \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
-                    const float v = acc[mb][nb][4 * g + e] + bv;                                                      \
-                    t[e] = fmaxf(v, v * slope);                                                                       \
-                }                                                                                                     \
+                const f32x2 bv2 = {bv, bv};                                                                           \
+                f32x2 ta = __builtin_elementwise_fma(f32x2{acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1]}, unscale2, bv2); \
+                f32x2 tb = __builtin_elementwise_fma(f32x2{acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]}, unscale2, \
+                                                     bv2);                                                            \
+                ta = __builtin_elementwise_max(ta, ta * slope2);                                                      \
+                tb = __builtin_elementwise_max(tb, tb * slope2);                                                      \
                 float* po = obase + (size_t)(nb * 32 + L.m32) * L.cstride + (size_t)y * A.W + x;                      \
-                float ls = 0.f, lq = 0.f;                                                                             \
                 if (!(MASKED)) {                                                                                      \
-                    *reinterpret_cast<f32x4*>(po) = f32x4{t[0], t[1], t[2], t[3]};                                    \
-                    ls = (t[0] + t[1]) + (t[2] + t[3]);                                                               \
-                    lq = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], t[3] * t[3])));                           \
-                } else if (y < A.H) {                                                                                 \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
-                        if (x + e < A.W) {                                                                            \
-                            po[e] = t[e];                                                                             \
-                            ls += t[e];                                                                               \
-                            lq = fmaf(t[e], t[e], lq);                                                                \
-                        }                                                                                             \
-                }                                                                                                     \
-                if (nb) {                                                                                             \
-                    s1 += ls;                                                                                         \
-                    q1 += lq;                                                                                         \
+                    *reinterpret_cast<f32x4*>(po) = f32x4{ta[0], ta[1], tb[0], tb[1]};                                \
                 } else {                                                                                              \
-                    s0 += ls;                                                                                         \
-                    q0 += lq;                                                                                         \
+                    const bool row = y < A.H;                                                                         \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+                        const bool in = row && x + e < A.W;                                                           \
+                        const float v = e < 2 ? ta[e] : tb[e - 2];                                                    \
+                        if (in) po[e] = v;                                                                            \
+                        if (e < 2) ta[e] = in ? v : 0.f;                                                              \
+                        else tb[e - 2] = in ? v : 0.f;                                                                \
+                    }                                                                                                 \
                 }                                                                                                     \
+                s2[nb][0] += ta;                                                                                      \
+                s2[nb][1] += tb;                                                                                      \
+                q2[nb][0] = __builtin_elementwise_fma(ta, ta, q2[nb][0]);                                             \
+                q2[nb][1] = __builtin_elementwise_fma(tb, tb, q2[nb][1]);                                             \
             }                                                                                                         \
         }                                                                                                             \
     }
@@ -357,6 +394,10 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
         PDS_X3_EPILOGUE(true)
     }
 #undef PDS_X3_EPILOGUE
+    float s0 = (s2[0][0][0] + s2[0][0][1]) + (s2[0][1][0] + s2[0][1][1]);
+    float q0 = (q2[0][0][0] + q2[0][0][1]) + (q2[0][1][0] + q2[0][1][1]);
+    float s1 = (s2[1][0][0] + s2[1][0][1]) + (s2[1][1][0] + s2[1][1][1]);
+    float q1 = (q2[1][0][0] + q2[1][0][1]) + (q2[1][1][0] + q2[1][1][1]);
     if (A.partials) {
         // the two halves of the wave hold the same channels (pixels 4 apart): one exchange, then lanes 0-31 write
         s0 += __shfl_xor(s0, 32, 64);
@@ -364,7 +405,7 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
         s1 += __shfl_xor(s1, 32, 64);
         q1 += __shfl_xor(q1, 32, 64);
         if (L.kgl == 0) {
-            float* red = reinterpret_cast<float*>(lds + LDS_RED);
+            float* red = reinterpret_cast<float*>(lds + C::LDS_RED);
             *reinterpret_cast<float2*>(red + (L.wave * 64 + L.m32) * 2) = make_float2(s0, q0);
             *reinterpret_cast<float2*>(red + (L.wave * 64 + 32 + L.m32) * 2) = make_float2(s1, q1);
         }
@@ -375,6 +416,7 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
     return nxt_id;
 }
 
+template <int P, bool NORM>
 __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* lds, int wave, int lane, int cur_id) {
     MfmaLane L;
     L.wave = wave;
@@ -397,10 +439,10 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
         const Tile cur = decode_tile(A, cur_id);
         if (cur.x0 + 16 >= A.W) {   // the right half of the tile is outside the image (uniform)
             L.x_lane = x_narrow;
-            cur_id = x3_mfma_tile<true>(A, lds, L, cur, upar, wpar);
+            cur_id = x3_mfma_tile<P, NORM, true>(A, lds, L, cur, upar, wpar);
         } else {
             L.x_lane = x_full;
-            cur_id = x3_mfma_tile<false>(A, lds, L, cur, upar, wpar);
+            cur_id = x3_mfma_tile<P, NORM, false>(A, lds, L, cur, upar, wpar);
         }
         if (cur_id < 0) break;
     }
@@ -418,8 +460,11 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
 // two whole stages to land (global latency under load is ~2 us, about one stage; with a one-stage lag every stage
 // began by waiting for the loads issued at the end of the previous one).  The stage loop is unrolled by two so that
 // the set index is a compile-time constant; a stage body is one function that also does the end-of-tile bookkeeping.
-template <bool NORM>
+template <int P, bool NORM>
 __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char* lds, int st, int cur_id) {
+    using C = X3Cfg<P>;
+    constexpr int W_ITERS = C::W_ITERS, W_STAGE = C::W_STAGE, IN_BUF = C::IN_BUF;
+    constexpr int LDS_W = C::LDS_W, LDS_RED = C::LDS_RED, LDS_NEXT = C::LDS_NEXT, LDS_COEF = C::LDS_COEF;
     const size_t plane = (size_t)A.H * A.W;
     const unsigned cstride = (unsigned)(A.D * plane);          // floats between channels
     const int nks = A.nks, nstages = 3 * nks;
@@ -460,29 +505,38 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         }
         const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
         const bool inimg = y >= 0 && y < A.H && xx >= 0 && xx < A.W;
-        // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
-        unsigned h[3][16];
+        unsigned h[P][16];   // part p of channel c: P = 3 in the high half, P = 2 in the low half of the dword
+        constexpr unsigned pack_sel = P == 3 ? 0x07060302u : 0x05040100u;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float r = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : x[c];
             r = inimg ? r : 0.f;
+            if constexpr (P == 3) {
+                // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const unsigned u = __builtin_bit_cast(unsigned, r);
-                h[p][c] = u;
-                if (p < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
+                for (int q = 0; q < 3; ++q) {
+                    const unsigned u = __builtin_bit_cast(unsigned, r);
+                    h[q][c] = u;   // (the bf16 is the high half)
+                    if (q < 2) r -= __builtin_bit_cast(float, u & 0xffff0000u);
+                }
+            } else {
+                // fp16, round to nearest: hi carries 11 bits, the remainder (exact in fp32) is rounded to 11 more
+                const _Float16 hi = (_Float16)r;
+                const _Float16 lo = (_Float16)(r - (float)hi);
+                h[0][c] = __builtin_bit_cast(unsigned short, hi);
+                h[1][c] = __builtin_bit_cast(unsigned short, lo);
             }
         }
         if (valid) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < P; ++q)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     u32x4 w;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)   // bytes [3:2] of the odd channel above bytes [3:2] of the even one
-                        w[j] = __builtin_amdgcn_perm(h[p][8 * g + 2 * j + 1], h[p][8 * g + 2 * j], 0x07060302u);
-                    *reinterpret_cast<u32x4*>(buf + (p * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = w;
+                    for (int j = 0; j < 4; ++j)   // the odd channel above the even one
+                        w[j] = __builtin_amdgcn_perm(h[q][8 * g + 2 * j + 1], h[q][8 * g + 2 * j], pack_sel);
+                    *reinterpret_cast<u32x4*>(buf + (q * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = w;
                 }
         }
     };
@@ -509,8 +563,8 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     };
     auto write_coef = [&](float cs, float ch, int table) {
         if (NORM) {
-            coef_tab[table * 2 * CMAX + coef_c] = cs;
-            coef_tab[table * 2 * CMAX + CMAX + coef_c] = ch;
+            coef_tab[table * 2 * CMAX + coef_c] = cs * C::A_SCALE_NORM;   // (exact power of two of the fp16 form)
+            coef_tab[table * 2 * CMAX + CMAX + coef_c] = ch * C::A_SCALE_NORM;
         }
     };
     // one fp64 (sum, sum of squares) record per tile and channel from the four MFMA waves' rows
@@ -612,20 +666,20 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
 
 }  // namespace
 
-template <bool NORM>
+template <int P, bool NORM>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int* next_slot = reinterpret_cast<int*>(lds + LDS_NEXT);
+    int* next_slot = reinterpret_cast<int*>(lds + X3Cfg<P>::LDS_NEXT);
     if (tid == STAGERS)
         next_slot[0] = draw_tile(A.queue, blockIdx.x & 7, A.planes, A.tiles, A.tiles_x, A.tiles_x_full,
                                  A.tiles_y * A.tiles_x_full);
     __syncthreads();
     const int cur_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
     if (cur_id < 0) return;
-    if (wave < 4) x3_mfma_waves(A, lds, wave, tid & 63, cur_id);
-    else x3_staging_waves<NORM>(A, lds, tid - STAGERS, cur_id);
+    if (wave < 4) x3_mfma_waves<P, NORM>(A, lds, wave, tid & 63, cur_id);
+    else x3_staging_waves<P, NORM>(A, lds, tid - STAGERS, cur_id);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,12 +699,39 @@ bool conv2d_x3_supported(const ConvLayer& L) {
 
 int conv2d_x3_tiles(const Geom& o) { return ((o.h + TH - 1) / TH) * ((o.w + TW - 1) / TW); }
 
-// dwords of packed weights + the eight queue counters behind them
-size_t conv2d_x3_packed_floats(int cin) { return (size_t)(cin / 16) * 3 * (W_STAGE / 4) + 64; }
+// dwords of packed weights (sized for the three-part form) + the eight queue counters behind them
+static size_t x3_weight_dwords(int cin, int parts) { return (size_t)(cin / 16) * 3 * (3 * parts * 2 * W_FRAG / 4); }
+size_t conv2d_x3_packed_floats(int cin) { return x3_weight_dwords(cin, 3) + 64; }
+
+// fp16 form (three products) when the input is O(1): behind an InstanceNorm, or marked so by the pipeline
+static bool x3_use_fp16(const ConvLayer& L) {
+    static const bool enabled = []() {  // PDS_X3_FP16=0: every launch on the range-safe bf16 form (A/B, debugging)
+        const char* e = getenv("PDS_X3_FP16");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && (L.a.scale != nullptr || L.unit_range);
+}
+
+template <int P>
+static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t s) {
+    using C = X3Cfg<P>;
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    if (first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    }
+    if (L.a.scale)
+        hipLaunchKernelGGL((conv2d_x3_kernel<P, true>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
+    else hipLaunchKernelGGL((conv2d_x3_kernel<P, false>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
+    return check_launch("conv2d_x3");
+}
 
 int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     if (!L.packed) return set_error(-1, "conv2d_x3: packed weights missing");
-    const int total = (L.in.c / 16) * 3 * (W_STAGE / 4);
+    const bool fp16 = x3_use_fp16(L);
+    const int total = (int)x3_weight_dwords(L.in.c, fp16 ? 2 : 3);
     const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
     if (phase != kPackDone) {
         PackJob j;
@@ -661,7 +742,8 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
         j.mblocks = 2;
         j.kc = 4;
         j.taps = 9;
-        j.mode = 6;   // three-way bf16 split in v_mfma_f32_32x32x16_bf16 A-fragment order
+        // 6: three-way bf16 split, 7: two-way fp16 split of 2^10 w; A-fragment order of v_mfma_f32_32x32x16_{bf16,f16}
+        j.mode = fp16 ? 7 : 6;
         j.total = total;
         if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
         if (int rc = launch_multi_pack(&j, 1, s)) return rc;
@@ -672,7 +754,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     A.bias = L.bias;
     A.out = L.out;
     A.partials = L.partials;
-    A.queue = reinterpret_cast<int*>(L.packed + total);
+    A.queue = reinterpret_cast<int*>(L.packed + x3_weight_dwords(L.in.c, 3));
     A.N = L.in.n;
     A.Cin = L.in.c;
     A.D = L.in.d;
@@ -688,15 +770,11 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     A.tiles_x_full = A.tiles_x - ((rem != 0 && rem <= 16) ? 1 : 0);
     A.planes = A.N * A.D;
     A.nks = A.Cin / 16;
-    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    static std::atomic<unsigned> cus_done{0};   // one bit per device
     static int cus[32] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (first_use_on_device(cus_done)) {
         int n = 0;
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         cus[dev & 31] = n > 0 ? n : 256;
@@ -704,9 +782,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     const long long all = (long long)A.planes * A.tiles;
     const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
     if (hipMemsetAsync(A.queue, 0, 8 * sizeof(int), s) != hipSuccess) return check_launch("conv2d_x3 queue reset");
-    if (L.a.scale) hipLaunchKernelGGL((conv2d_x3_kernel<true>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
-    else hipLaunchKernelGGL((conv2d_x3_kernel<false>), dim3(workgroups), dim3(THREADS), LDS_BYTES, s, A);
-    return check_launch("conv2d_x3");
+    return fp16 ? x3_launch<2>(L, A, workgroups, s) : x3_launch<3>(L, A, workgroups, s);
 }
 
 }  // namespace pds

@@ -11,6 +11,8 @@
 //   x3     (mode 6): conv 3x3 weights split three ways into bf16 (round-to-nearest: w = w1 + w2 + w3 exactly) in the
 //           A-fragment order of v_mfma_f32_32x32x16_bf16, for conv2d_x3.hip:
 //           [k-step of 16 channels][dy][dx][part][32-channel block][lane][8 bf16]; `total` counts dwords (2 bf16).
+//   x3 fp16 (mode 7): the same order with TWO fp16 parts of 2^10 w (round-to-nearest; 2^10 keeps the low part of
+//           |w| > 1e-4 out of the subnormal range, |w| < 64 in range), for v_mfma_f32_32x32x16_f16.
 #include "common.hpp"
 
 namespace pds {
@@ -42,6 +44,12 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float v) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// part 0, 1 of the two-way fp16 split of v (as the 16 bits of an fp16), round to nearest
+__device__ __forceinline__ unsigned fp16_split_part(float v, int part) {
+    _Float16 h = (_Float16)v;
+    if (part) h = (_Float16)(v - (float)h);
+    return __builtin_bit_cast(unsigned short, h);
+}
 // part 0, 1, 2 of the three-way bf16 split of v (as the 16 bits of a bf16)
 __device__ __forceinline__ unsigned bf16_split_part(float v, int part) {
     unsigned h = bf16_rne_bits(v);
@@ -59,24 +67,30 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const int kdn = J.mode == 1 ? 4 : 3;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
-        if (J.mode == 6) {
+        if (J.mode == 6 || J.mode == 7) {
+            const int nparts = J.mode == 6 ? 3 : 2;
             const int i2 = r % 4;
             r /= 4;
             const int ln = r % 64;
             r /= 64;
             const int mb = r % J.mblocks;
             r /= J.mblocks;
-            const int part = r % 3;
-            r /= 3;
+            const int part = r % nparts;
+            r /= nparts;
             const int dx = r % 3;
             r /= 3;
             const int dy = r % 3;
             const int kstep = r / 3;
             const int oc = mb * 32 + (ln & 31), ic = kstep * 16 + (ln >> 5) * 8 + 2 * i2;
             unsigned lo = 0, hi = 0;
-            if (oc < J.cout && ic < J.cin) lo = bf16_split_part(J.src[((size_t)oc * J.cin + ic) * 9 + dy * 3 + dx], part);
-            if (oc < J.cout && ic + 1 < J.cin)
-                hi = bf16_split_part(J.src[((size_t)oc * J.cin + ic + 1) * 9 + dy * 3 + dx], part);
+            if (oc < J.cout && ic < J.cin) {
+                const float v = J.src[((size_t)oc * J.cin + ic) * 9 + dy * 3 + dx];
+                lo = J.mode == 6 ? bf16_split_part(v, part) : fp16_split_part(v * 1024.f, part);
+            }
+            if (oc < J.cout && ic + 1 < J.cin) {
+                const float v = J.src[((size_t)oc * J.cin + ic + 1) * 9 + dy * 3 + dx];
+                hi = J.mode == 6 ? bf16_split_part(v, part) : fp16_split_part(v * 1024.f, part);
+            }
             reinterpret_cast<unsigned*>(J.dst)[e] = lo | (hi << 16);
             continue;
         }

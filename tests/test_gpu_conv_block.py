@@ -5,8 +5,10 @@ plain tensor.  The shapes walk every kernel behind the entry point: the Winograd
 (conv2d_wino.hip: even widths, partial 64-column tiles, 12 / 64 input channels, several planes and batch entries,
 per-plane and per-volume statistics, bare convolution), the direct MFMA kernel (odd widths, 8 / 16 output channels),
 the 3-D MFMA kernel (stride 1 and 2) and the VALU fallback (channel counts no MFMA tiling covers).  Since round 3 the
-Cin % 16 == 0 -> 64 layers run on conv2d_x3.hip (fp32 operands split three ways into bf16, six partial products on
-the bf16 matrix pipe): the same cases and the same tolerance, plus cases that walk its persistent tile queues.
+Cin % 16 == 0 -> 64 layers run on conv2d_x3.hip (fp32 operands split into 16-bit parts on the 16-bit matrix pipe): a
+plain input of unknown scale takes the range-safe form (three bf16 parts, six partial products), an input behind a
+deferred InstanceNorm -- pds_conv_block_chained_fwd, the way the hot path chains its blocks -- the fp16 form (two parts,
+three products).  Same cases and the same tolerance, plus cases that walk the persistent tile queues.
 Tolerance (stated): max-abs <= 2e-5 on the O(1) activations, and on the normalised output scale * raw + shift."""
 import ctypes
 
@@ -116,3 +118,50 @@ def test_conv_block_against_fp64(dev, case):
         normed = raw.double() * scale.double().view(groups) + shift.double().view(groups)
         err_n = float((normed - want_normed).abs().max())
         assert err_n <= 5 * TOL, err_n
+
+
+CHAINED = [
+    # n, cin, d, h, w, x_per_plane: conv2d_x3 in its fp16 form (the input sits behind a deferred InstanceNorm)
+    (1, 64, 48, 48, 80, 1),    # many tiles per persistent workgroup
+    (3, 64, 5, 17, 47, 1),     # uneven queues, ragged rows, right-half-empty tile column
+    (1, 48, 2, 20, 36, 0),     # three K-steps, per-volume input statistics
+    (2, 128, 1, 24, 20, 0),    # 128 input channels
+]
+
+
+@pytest.mark.parametrize('case', CHAINED, ids=lambda c: 'n%d_%dto64_d%d_%dx%d_xpp%d' % c)
+def test_chained_conv_block_against_fp64(dev, case):
+    """pds_conv_block_chained_fwd (ABI v3): the loader applies the producer's folded InstanceNorm, x^ = s * x + h.  The
+    64-output-channel layers then run the fp16 two-way-split form of conv2d_x3 (three products per multiply): same 2e-5
+    bound as the exact-fp32 kernels.  The raw producer output is deliberately far from unit scale (x 37, offset 5)."""
+    n, cin, d, h, w, xpp = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77 + cin + w)
+    x = torch.randn(n, cin, d, h, w, generator=g) * 37.0 + 5.0
+    groups_in = (n, cin, d if xpp else 1, 1, 1)
+    x_scale = (torch.rand(groups_in, generator=g) + 0.5) / 37.0
+    x_shift = torch.randn(groups_in, generator=g) * 0.2 - 5.0 * x_scale
+    weight = torch.randn(64, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(64, generator=g) * 0.1
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    tensors = [t.to(dev).contiguous() for t in (weight, bias, gamma, beta)]
+    params = _lib.ConvBlockParams()
+    params.weight, params.bias, params.gamma, params.beta = (t.data_ptr() for t in tensors)
+    raw = torch.full((n, 64, d, h, w), float('nan'), device=dev)
+    scale = torch.zeros(n * 64 * d, device=dev)
+    shift = torch.zeros(n * 64 * d, device=dev)
+    ws = torch.empty(int(lib.pds_conv_block_workspace_bytes(n, cin, 64, d, h, w, 1, 1, 1)), dtype=torch.uint8, device=dev)
+    xg, sg, hg = x.to(dev), x_scale.reshape(-1).to(dev).contiguous(), x_shift.reshape(-1).to(dev).contiguous()
+    _lib.check(lib.pds_conv_block_chained_fwd(ctypes.byref(params), _lib.ptr(xg), _lib.ptr(sg), _lib.ptr(hg), xpp,
+                                              _lib.ptr(raw), _lib.ptr(scale), _lib.ptr(shift), n, cin, 64, d, h, w, 1, 1,
+                                              1, _lib.ptr(ws), ws.numel(), _lib.stream_handle(dev)),
+               'pds_conv_block_chained_fwd')
+    torch.cuda.synchronize()
+    # the reference sees the fp32 normalised input the loader forms (one fma per element)
+    xhat = torch.addcmul(x_shift.expand_as(x), x_scale.expand_as(x), x)
+    want_raw, want_normed = reference(xhat, weight, bias, gamma, beta, 1, 1, 1)
+    err = float((raw.cpu().double() - want_raw).abs().max())
+    assert not torch.isnan(raw).any() and err <= TOL, err
+    normed = raw.cpu().double() * scale.cpu().double().view(n, 64, d, 1, 1) + shift.cpu().double().view(n, 64, d, 1, 1)
+    err_n = float((normed - want_normed).abs().max())
+    assert err_n <= 5 * TOL, err_n
