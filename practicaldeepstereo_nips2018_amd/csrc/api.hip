@@ -45,7 +45,7 @@ int conv2d_wino_tiles(const Geom& out_g);
 size_t conv2d_wino_packed_floats(int cin, int cout);
 int launch_conv2d_x3(const ConvLayer& L, hipStream_t s);          // conv2d_x3.hip (Cin -> 64, fp32 on the bf16 pipe)
 bool conv2d_x3_supported(const ConvLayer& L);
-int conv2d_x3_tiles(const Geom& out_g);
+int conv2d_x3_tiles(const ConvLayer& L);   // statistics records per plane (depends on the form chosen)
 size_t conv2d_x3_packed_floats(int cin);
 int launch_conv2d_t8(const ConvLayer& L, hipStream_t s);          // conv2d_t8.hip (64 -> 8 channels, bare)
 bool conv2d_t8_supported(const ConvLayer& L);
@@ -185,9 +185,11 @@ struct DT {
     Geom g{0, 0, 0, 0, 0};
     int per_plane = 0;
     int id = -1;
+    bool normed = false;   // a deferred InstanceNorm goes with the tensor (true in planning walks too, where scale is null)
     Src src() const {
         Src s{raw, scale, shift, per_plane, 0};
         s.id = id;
+        s.normed = normed ? 1 : 0;
         return s;
     }
 };
@@ -336,7 +338,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         // partial records: direct / 2-D kernels write [(n, c, d)][tile]; the 3-D kernel writes [(n, c)][tile]
         const int tiles = kind == 2 ? conv2d_mfma_tiles(o.g)
                                     : kind == 4 ? conv2d_wino_tiles(o.g)
-                                    : kind == 9 ? conv2d_x3_tiles(o.g)
+                                    : kind == 9 ? conv2d_x3_tiles(L)
                                     : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride)
                                     : kind == 6 ? conv3d_t8_records(o.g)
                                     : kind == 7 ? conv3d_ks_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
@@ -344,6 +346,7 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         const size_t records = (size_t)o.g.n * o.g.c * (volume_records ? 1 : o.g.d) * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);
+        o.normed = true;
         o.scale = scale_out ? scale_out : c.get<float>(groups);
         o.shift = shift_out ? shift_out : c.get<float>(groups);
         o.mean = c.get<float>(groups);
@@ -409,6 +412,7 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
         const size_t records = (size_t)o.g.n * o.g.c * per_group;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c;
+        o.normed = true;
         o.scale = c.get<float>(groups);
         o.shift = c.get<float>(groups);
         o.mean = c.get<float>(groups);
@@ -612,6 +616,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         const int tiles = l1_combine_tiles(h, w);
         double* partials = c.get<double>((size_t)batch * F * d_count * tiles * 2);
         const int groups = batch * F * d_count;
+        t1.normed = true;
         t1.scale = c.get<float>(groups);
         t1.shift = c.get<float>(groups);
         t1.mean = c.get<float>(groups);
@@ -1175,8 +1180,12 @@ size_t pds_conv_block_workspace_bytes(int n, int cin, int cout, int d, int h, in
                                       int per_plane) {
     Ctx c{nullptr, 0, true, nullptr};
     PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
-    conv_block(c, plain_src(nullptr), no_src(), Geom{n, cin, d, h, w}, dummy, cout, kd, stride, per_plane,
-               (float*)1, true, (float*)1, (float*)1);
+    // sized for the chained form (input behind a deferred InstanceNorm): it may pick a kernel with more statistics
+    // records per plane than the plain form, never fewer
+    Src src = plain_src(nullptr);
+    src.normed = 1;
+    conv_block(c, src, no_src(), Geom{n, cin, d, h, w}, dummy, cout, kd, stride, per_plane, (float*)1, true, (float*)1,
+               (float*)1);
     return c.off + 256;
 }
 
@@ -1213,7 +1222,8 @@ int pds_conv_block_chained_fwd(const PdsConvBlockParams* params, const float* x,
     const size_t need = pds_conv_block_workspace_bytes(n, cin, cout, d, h, w, kd, stride, per_plane);
     PDS_REQUIRE(workspace_bytes >= need, "conv_block_chained: workspace too small (%zu < %zu)", workspace_bytes, need);
     Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
-    const Src src{x, x_scale, x_shift, x_per_plane ? 1 : 0, 0};
+    Src src{x, x_scale, x_shift, x_per_plane ? 1 : 0, 0};
+    src.normed = 1;
     conv_block(c, src, no_src(), Geom{n, cin, d, h, w}, *params, cout, kd, stride, per_plane, raw, true, scale, shift);
     return c.err;
 }

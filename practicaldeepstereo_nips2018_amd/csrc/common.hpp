@@ -46,6 +46,7 @@ struct Src {
     int per_plane;       // statistics per (n, c, d) -- Matching's per-disparity InstanceNorm2d
     int bcast_d;         // tensor has no D axis and is broadcast along it (regularization.py:115)
     int id = -1;         // host-side only: index of the tensor on the backward tape
+    int normed = 0;      // host-side only: scale / shift are (or, in a planning walk with null pointers, will be) set
 };
 
 inline Src plain_src(const float* p) { return Src{p, nullptr, nullptr, 0, 0}; }

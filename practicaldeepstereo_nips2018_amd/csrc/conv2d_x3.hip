@@ -697,7 +697,11 @@ bool conv2d_x3_supported(const ConvLayer& L) {
     return true;
 }
 
-int conv2d_x3_tiles(const Geom& o) { return ((o.h + TH - 1) / TH) * ((o.w + TW - 1) / TW); }
+// statistics records per output plane
+int conv2d_x3_tiles(const ConvLayer& L) {
+    const Geom& o = L.out_g;
+    return ((o.h + TH - 1) / TH) * ((o.w + TW - 1) / TW);
+}
 
 // dwords of packed weights (sized for the three-part form) + the eight queue counters behind them
 static size_t x3_weight_dwords(int cin, int parts) { return (size_t)(cin / 16) * 3 * (3 * parts * 2 * W_FRAG / 4); }
@@ -709,7 +713,7 @@ static bool x3_use_fp16(const ConvLayer& L) {
         const char* e = getenv("PDS_X3_FP16");
         return !(e && e[0] == '0');
     }();
-    return enabled && (L.a.scale != nullptr || L.unit_range);
+    return enabled && (L.a.normed || L.a.scale != nullptr || L.unit_range);
 }
 
 template <int P>
