@@ -79,6 +79,10 @@ def build_library(force=False, verbose=False):
     compiled in parallel, then one link.  The library is rebuilt when the digest of flags + sources recorded next to
     it differs from the tree's (a shipped .so with a stale or missing stamp is rebuilt, not trusted), or on ``force``."""
     from concurrent.futures import ThreadPoolExecutor
+    if os.environ.get('PDS_HIP_LIB'):
+        # an alternative build selected for an A/B run is used as it is: rebuilding it from the tree's sources would
+        # silently turn the experiment into "tree vs tree"
+        return LIB_PATH
     srcs = sources()
     stamp = LIB_PATH + '.sha256'
     digest = _source_digest()

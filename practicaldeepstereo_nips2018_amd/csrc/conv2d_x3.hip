@@ -455,6 +455,15 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
 }
 
 // ---- waves 4-7 -----------------------------------------------------------------------------------------------------
+// Measured and not kept (round 3, PDS_X3_TIMING): the compiler's wait before the first use of a request set is
+// vmcnt(20) -- it cannot order the two sets across the loop's merge points and also waits for the loads issued ONE stage
+// ago, so a request has one stage to land, not two.  Issuing the staged loads from inline assembly with an explicit
+// vmcnt(21) halves the MFMA waves' barrier waits (1 186 -> 670 cycles per stage) -- and the launch takes the same time
+// (0.43-0.45 ms, 364 pairs/s either way): the chip is at its power limit, the cycles gained come back as a lower clock
+// (763 000 cycles at 1.70 GHz before, 650 000 at 1.46 GHz after).  Same outcome as every other issue-efficiency change on
+// this kernel; only work removed from the launch (the three-product form: -50 % matrix work) has moved it.  (The
+// assembly form also has a trap: the hazard recogniser does not see a VMEM read of an SGPR that a v_readlane spill
+// reload has just written -- wild base addresses in some builds -- so the base has to travel through an s_mov.)
 // All four waves work at every stage, on a two-deep ring of request registers: at stage s a thread writes what it
 // requested at stage s - 2 (set s & 1) and re-uses that set for the requests of stage s + 2.  A request therefore has
 // two whole stages to land (global latency under load is ~2 us, about one stage; with a one-stage lag every stage
