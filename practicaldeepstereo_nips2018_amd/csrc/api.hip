@@ -786,6 +786,7 @@ static void embedding_pipeline(Ctx& c, const PdsEmbeddingParams& P, const float*
     ConvExtra e2;
     e2.weight_used = w2;
     e2.s2d_cin = F;
+    e2.unit_range = 1;   // space-to-depth of a normalised tensor: plain O(1) values (conv2d_x3: fp16 form)
     DT t2 = conv_block(c, s1.src(), no_src(), s1.g, P.downsampling[1], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e2);
     // residual blocks (embedding.py:38-41); the last sum is the descriptor
     const Geom g = t2.g;

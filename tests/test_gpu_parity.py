@@ -612,3 +612,22 @@ def test_unpad_is_folded_into_the_estimator_store(dev):
             padded = net._regularization.forward_with_estimator(signatures, shortcut, net._estimator)
         assert out.shape == (1, height, width) and out.is_contiguous()
         assert torch.equal(out, padded[..., top:, lft:]), (height, width)
+
+
+@pytest.mark.parametrize('scale', [0.03, 30.0])
+def test_fused_matching_descriptor_scale(dev, scale):
+    """The 64-channel layers split their fp32 operands into two fp16 parts (conv2d_x3.hip).  Behind an InstanceNorm the
+    inputs are O(1) by construction; the first residual sum x1 = norm(t2) + x0 is a PLAIN tensor that carries the scale of
+    the descriptors (x0 is linear in them), taken as it is (|x| < 65 504).  Descriptors 30x larger / smaller than a
+    normalised tensor must still match the oracle to the signature tolerance, relative to the signatures' own scale."""
+    op = helpers.seeded(pds.MatchingOperation, seed=11)
+    p = helpers.prefixed(op.state_dict(), '_m._operation')
+    g = torch.Generator().manual_seed(12)
+    left = torch.randn(1, 64, 24, 40, generator=g) * scale
+    right = torch.randn(1, 64, 24, 40, generator=g) * scale
+    ref = oracle.matching_with_operation(p, '_m', left, right, 7)
+    net = pds.Matching(7, op).to(dev)
+    with torch.no_grad():
+        out = net(left.to(dev), right.to(dev))
+    assert torch.isfinite(out).all()
+    assert helpers.maxdiff(out, ref) <= TOL_SIGNATURES * max(1.0, float(ref.abs().max()) / 4.0)
