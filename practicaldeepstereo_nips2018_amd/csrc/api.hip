@@ -71,9 +71,10 @@ int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s);    // deconv3d_ce
 bool deconv3d_cell_supported(const DeconvLayer& L);
 int deconv3d_cell_records(const Geom& in_g, int cout);
 bool upsample_estimator_supported(int cin, int lo, int hi);       // upsample_estimator.hip
-int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w,
+int launch_upsample_estimator(const float* in, const float* scale, const float* shift, const float* w_pairs,
                               const float* bias, float* disp, int batch, int cin, int d, int hi_, int wi, int lo,
                               int hi, int step, int crop_top, int crop_left, hipStream_t s);
+int launch_upsample_weight_pairs(const float* w, float* w_pairs, int cin, hipStream_t s);   // kw order 1, 2, 3, 0
 
 // ---- backward tape ---------------------------------------------------------------------------------
 // Recorded while a pipeline is (re-)walked over the forward workspace; the arena is deterministic, so the
@@ -698,8 +699,10 @@ static void regularization_pipeline(Ctx& c, const PdsRegularizationParams& P, co
     DT half = regularization_trunk(c, P, ms, left, batch, d, h, w);
     if (upsample_full_valu_supported(half.g.c)) {
         // 4 -> 1 channels: the plane-sweeping VALU kernel beats the MFMA path (which wastes 12 of 16 rows)
+        float* w_pairs = c.get<float>((size_t)half.g.c * 48);   // weight-derived: written in the packing walk only
+        if (c.before_packing()) c.run(launch_upsample_weight_pairs(P.upsample_full.weight, w_pairs, half.g.c, c.s));
         if (!c.plan)
-            c.run(launch_upsample_full(half.raw, half.scale, half.shift, P.upsample_full.weight, P.upsample_full.bias,
+            c.run(launch_upsample_full(half.raw, half.scale, half.shift, w_pairs, P.upsample_full.bias,
                                        cost, batch, half.g.c, half.g.d, half.g.h, half.g.w, c.s));
         DT full;
         full.raw = cost;
@@ -1158,11 +1161,16 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
     if (upsample_estimator_supported(params->features / 2, lo, hi)) {
         // fused: the full-resolution cost volume is never materialised
         DT half;
+        float* w_pairs = nullptr;
         if (int rc = run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& cc) {
                 half = regularization_trunk(cc, *params, signatures, left_shortcut, batch, d, h, w);
+                // (the same carve as regularization_pipeline, which sized the workspace)
+                w_pairs = cc.get<float>((size_t)half.g.c * 48);
+                if (cc.before_packing())
+                    cc.run(launch_upsample_weight_pairs(params->upsample_full.weight, w_pairs, half.g.c, cc.s));
             }, weights_resident != 0))
             return rc;
-        return launch_upsample_estimator(half.raw, half.scale, half.shift, params->upsample_full.weight,
+        return launch_upsample_estimator(half.raw, half.scale, half.shift, w_pairs,
                                          params->upsample_full.bias, disparities, batch, half.g.c, half.g.d, half.g.h,
                                          half.g.w, lo, hi, disparity_step, crop_top, crop_left, (hipStream_t)stream);
     }

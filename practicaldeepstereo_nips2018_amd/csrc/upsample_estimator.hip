@@ -25,12 +25,13 @@ constexpr int HR = TR + 2, HC = TC + 2;   // halo tile
 constexpr int NPOS = HR * HC;             // 204
 constexpr int POS = (NPOS + 63) / 64;     // 4
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct FusedArgs {
     const float* __restrict__ in;     // raw upsample_half output [B, C, D, Hi, Wi]
     const float* __restrict__ scale;  // [B*C] folded InstanceNorm
     const float* __restrict__ shift;
-    const float* __restrict__ w;      // [C, 1, 3, 4, 4]
+    const float* __restrict__ w;      // [C][3][4 kh][kw order 1, 2, 3, 0]: the layer's weights, see upsample_weight_pairs_kernel
     const float* __restrict__ bias;   // [1]
     float* __restrict__ disp;         // [B, 2Hi, 2Wi]
     float* __restrict__ cost;         // WRITE_COST variant: [B, D, 2Hi, 2Wi] instead of the disparity
@@ -103,9 +104,10 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
         for (int t = 0; t < 2 * T + 1; ++t) win[o][t] = -INFINITY;
     }
     // accumulators: [0] -> output plane p-1, [1] -> p, [2] -> p+1 ; pixel index q (four consecutive output columns)
-    float acc[3][4];
+    // (register pairs: the transposed convolution runs on packed fp32 FMAs, two output columns per instruction)
+    f32x2 acc[3][2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) acc[0][o] = acc[1][o] = acc[2][o] = bias;
+    for (int o = 0; o < 2; ++o) acc[0][o] = acc[1][o] = acc[2][o] = f32x2{bias, bias};
 
     PDS_FETCHP(0)
     PDS_STASHP(0)
@@ -118,21 +120,23 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
             if (p + 1 < A.D) PDS_FETCHP(p + 1)
 #pragma nounroll
             for (int c = 0; c < CIN; ++c) {  // not unrolled: keeps only 3 x 16 weight SGPRs live
-                // the two halo rows this output-row parity uses: vr = 1 (tap kh = 1 / 2) and vr = 0 / 2 (kh = 3 / 0)
-                float v[2][4];
+                // the two halo rows this output-row parity uses: vr = 1 (tap kh = 1 / 2) and vr = 0 / 2 (kh = 3 / 0).  The four
+                // input columns v0 .. v3 of a row arrive as the pairs (v0, v2) and (v1, v3) (ds_read2_b32 with offsets 0 / 2
+                // and 1 / 3), which are the second operands of the packed FMAs below as they stand.
+                f32x2 r02[2], r13[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int vr = (a == 0) ? 1 : (PY == 0 ? 0 : 2);
-                    const float2 lo2 = *reinterpret_cast<const float2*>(&tile[cur][c][lbase + vr * HC]);
-                    const float2 hi2 = *reinterpret_cast<const float2*>(&tile[cur][c][lbase + vr * HC + 2]);
-                    v[a][0] = lo2.x;
-                    v[a][1] = lo2.y;
-                    v[a][2] = hi2.x;
-                    v[a][3] = hi2.y;
+                    const float* row = &tile[cur][c][lbase + vr * HC];
+                    r02[a] = f32x2{row[0], row[2]};
+                    r13[a] = f32x2{row[1], row[3]};
                 }
                 // the 3 x 16 taps of channel c as SGPR operands: explicit s_load_dwordx16 (hipcc turns plain reads of
                 // the weight pointer into vector loads parked in VGPRs, which spills this kernel); the three loads
-                // are issued back to back and share one wait
+                // are issued back to back and share one wait.  The table is stored with the kw taps of a kernel row in
+                // the order 1, 2, 3, 0, so that the pairs a packed FMA needs -- (w1, w2) and (w3, w0) -- are aligned
+                // SGPR pairs (taken from the natural order they cost 24 s_mov per channel and plane: the loop was bound
+                // by instruction issue, 470 instructions per plane for 192 FMAs; rocprofv3: 2 waves per SIMD, both busy).
                 f32x16 wk[3];
                 asm volatile(
                     "s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\t"
@@ -140,22 +144,19 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
                     : "=&s"(wk[0]), "=&s"(wk[1]), "=&s"(wk[2])
                     : "s"(A.w), "s"((c * 3 + 0) * 64), "s"((c * 3 + 1) * 64), "s"((c * 3 + 2) * 64)
                     : "memory");
+                // out column 2j + px reads in(j) with kw = 1 + px and in(j - 1 + 2 px) with kw = 3 - 3 px:
+                //   columns (0, 1): (w1, w2) * v1 + (w3, w0) * (v0, v2)      columns (2, 3): (w1, w2) * v2 + (w3, w0) * (v1, v3)
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd) {
                     const f32x16 wp = wk[kd];
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         const int kh = (PY == 0) ? (a == 0 ? 1 : 3) : (a == 0 ? 2 : 0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int px = q & 1, jc = 1 + (q >> 1);
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int vc = (e == 0) ? jc : (px == 0 ? jc - 1 : jc + 1);
-                                const int kw = (px == 0) ? (e == 0 ? 1 : 3) : (e == 0 ? 2 : 0);
-                                acc[kd][q] = fmaf(wp[kh * 4 + kw], v[a][vc], acc[kd][q]);
-                            }
-                        }
+                        const f32x2 w12 = {wp[kh * 4 + 0], wp[kh * 4 + 1]}, w30 = {wp[kh * 4 + 2], wp[kh * 4 + 3]};
+                        acc[kd][0] = __builtin_elementwise_fma(w12, f32x2{r13[a][0], r13[a][0]}, acc[kd][0]);
+                        acc[kd][0] = __builtin_elementwise_fma(w30, r02[a], acc[kd][0]);
+                        acc[kd][1] = __builtin_elementwise_fma(w12, f32x2{r02[a][1], r02[a][1]}, acc[kd][1]);
+                        acc[kd][1] = __builtin_elementwise_fma(w30, r13[a], acc[kd][1]);
                     }
                 }
             }
@@ -169,10 +170,10 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
                     const int Wo = 2 * A.Wi;
                     float* dst = A.cost + (((size_t)b * A.D + (p - 1)) * 2 * A.Hi + 2 * i + PY) * Wo + 2 * j;
                     if (j + 1 < A.Wi) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0][0], acc[0][0][1], acc[0][1][0], acc[0][1][1]);
                     } else {
-                        dst[0] = acc[0][0];
-                        dst[1] = acc[0][1];
+                        dst[0] = acc[0][0][0];
+                        dst[1] = acc[0][0][1];
                     }
                 }
             }
@@ -183,7 +184,7 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
             for (int o = 0; o < 4; ++o) {
 #pragma unroll
                 for (int t = 0; t < 2 * T; ++t) win[o][t] = win[o][t + 1];
-                win[o][2 * T] = k < A.D ? acc[0][o] : -INFINITY;
+                win[o][2 * T] = k < A.D ? acc[0][o >> 1][o & 1] : -INFINITY;
                 const bool up = centre >= 0 && win[o][T] > best[o];  // strict: first occurrence wins
                 best[o] = up ? win[o][T] : best[o];
                 bi[o] = up ? centre : bi[o];
@@ -195,10 +196,10 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < 2; ++o) {
             acc[0][o] = acc[1][o];
             acc[1][o] = acc[2][o];
-            acc[2][o] = bias;
+            acc[2][o] = f32x2{bias, bias};
         }
     }
 #undef PDS_FETCHP
@@ -254,6 +255,19 @@ __global__ __launch_bounds__(UTHREADS) void upsample_full_subpixel_kernel(const 
         upsample_sweep<CIN, T, WRITE_COST, 0>(A, tile);
     else
         upsample_sweep<CIN, T, WRITE_COST, 1>(A, tile);
+}
+
+// [C][3][4][4] weights of the (3, 4, 4) transposed convolution -> the same table with the four kw taps of every kernel
+// row stored in the order 1, 2, 3, 0 (see the sweep); w_pairs has C * 48 floats
+__global__ void upsample_weight_pairs_kernel(const float* __restrict__ w, float* __restrict__ w_pairs, int total) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) w_pairs[e] = w[(e & ~3) + ((e + 1) & 3)];
+}
+
+int launch_upsample_weight_pairs(const float* w, float* w_pairs, int cin, hipStream_t s) {
+    const int total = cin * 48;
+    hipLaunchKernelGGL(upsample_weight_pairs_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, w_pairs, total);
+    return check_launch("upsample_weight_pairs");
 }
 
 bool upsample_estimator_supported(int cin, int lo, int hi) {
