@@ -436,11 +436,13 @@ static void operation_tail(Ctx& c, const PdsMatchingParams& P, const Src& x0, co
     const int F = P.features;
     Src cur = x0;
     DT t2;
-    ConvExtra unit;   // x0 (a convolution of descriptors) and the residual sums are plain tensors of O(1) values
+    // A residual sum norm(t2) + x is a plain tensor dominated by its O(1) normalised term: the fp16-split kernels apply
+    // (conv2d_x3, conv2d_t8).  x0 itself -- a convolution of the caller's tensor, of unknown scale -- does not qualify.
+    ConvExtra unit;
     unit.unit_range = 1;
     for (int r = 0; r < P.residual_blocks; ++r) {
         DT t1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1, nullptr, true, nullptr, nullptr,
-                           cur.scale ? nullptr : &unit);
+                           (r > 0 && !cur.scale) ? &unit : nullptr);
         t2 = conv_block(c, t1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
         if (r + 1 < P.residual_blocks) {
             DT nxt;  // plain residual sum  x_{r+1} = norm(t2) + x_r
@@ -452,7 +454,7 @@ static void operation_tail(Ctx& c, const PdsMatchingParams& P, const Src& x0, co
         }
     }
     if (P.residual_blocks > 0)
-        conv_block(c, t2.src(), cur, g, P.last, P.signature_features, 1, 1, 1, signature);
+        conv_block(c, t2.src(), cur, g, P.last, P.signature_features, 1, 1, 1, signature, true, nullptr, nullptr, &unit);
     else
         conv_block(c, cur, no_src(), g, P.last, P.signature_features, 1, 1, 1, signature);
 }
@@ -653,7 +655,8 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
             cur = nxt;
         }
     }
-    conv_block(c, t2.src(), plain_src(cur), g, P.last, P.signature_features, 1, 1, 1, signatures);
+    conv_block(c, t2.src(), plain_src(cur), g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr,
+               &unit);   // (the residual sum is a plain tensor of O(1) values: conv2d_t8's fp16-split form)
 }
 
 static void operation_pipeline(Ctx& c, const PdsMatchingParams& P, const float* concatenated, float* signature,

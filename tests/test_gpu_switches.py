@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
-    {'PDS_X3': '0'},                         # exact-fp32 MFMA kernels (Winograd domain) instead of the bf16-split kernel
+    {'PDS_X3_FP16': '0'},                    # conv2d_x3 on its range-safe form everywhere (three bf16 parts, six products)
+    {'PDS_X3': '0'},                         # exact-fp32 MFMA kernels (Winograd domain) instead of the split-operand kernel
     {'PDS_X3': '0', 'PDS_WINOGRAD': '0'},    # ... and the direct exact-fp32 MFMA kernel
     {'PDS_X3': '0', 'PDS_WINO_TILE16': '0'},   # ... with wide (4 x 64) Winograd tiles everywhere
     {'PDS_MATCHING_FUSED': '0'},    # Matching without the factorisation glue
@@ -20,6 +21,7 @@ SWITCHES = [
     {'PDS_CONV3D_XCD_MAP': '0'},
     {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0', 'PDS_CONV3D_KS': '0'},   # generic MFMA kernels for all hourglass layers
     {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
+    {'PDS_CONV2D_T8W': '0'},        # ... its 16 x 32-tile form instead of the full-width one
 ]
 
 
