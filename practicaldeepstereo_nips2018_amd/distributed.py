@@ -39,15 +39,28 @@ def _gather_planes_raw(local_planes, group):
     batch, channels, d_local, h, w = local_planes.shape
     out = local_planes.new_empty((batch, channels, world_size * d_local, h, w))
     pairs = [(out[b, c].view(-1), local_planes[b, c].view(-1)) for b in range(batch) for c in range(channels)]
-    if local_planes.is_cuda and dist.get_backend(group) == 'nccl' and len(pairs) > 1:
-        from torch.distributed.distributed_c10d import _coalescing_manager
-        with _coalescing_manager(group=group, device=local_planes.device, async_ops=False):
-            for whole, mine in pairs:
-                dist.all_gather_into_tensor(whole, mine, group=group)
-    else:
-        for whole, mine in pairs:
-            dist.all_gather_into_tensor(whole, mine, group=group)
+    global _COALESCE_OK
+    if local_planes.is_cuda and dist.get_backend(group) == 'nccl' and len(pairs) > 1 and _COALESCE_OK:
+        # (RCCL has never run this code in the build container -- one GPU at most -- so the grouped form is guarded: an
+        # API error of the coalescing manager is the same on every rank, and every rank then takes the plain form below,
+        # which re-issues all of the collectives)
+        try:
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            with _coalescing_manager(group=group, device=local_planes.device, async_ops=False):
+                for whole, mine in pairs:
+                    dist.all_gather_into_tensor(whole, mine, group=group)
+            return out
+        except (ImportError, TypeError, AttributeError, NotImplementedError) as error:
+            _COALESCE_OK = False
+            import warnings
+            warnings.warn('grouped all-gather unavailable (%s: %s); using %d separate collectives per pair'
+                          % (type(error).__name__, error, len(pairs)))
+    for whole, mine in pairs:
+        dist.all_gather_into_tensor(whole, mine, group=group)
     return out
+
+
+_COALESCE_OK = True
 
 
 def gather_description(group=None):
