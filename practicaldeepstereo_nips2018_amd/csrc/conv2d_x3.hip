@@ -605,9 +605,9 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     }
 #pragma unroll
     for (int set = 0; set < 2; ++set) {   // stage `set` writes third `set` of K-step 1 and weight stage `set` + 1
+        request_coef(coef_s[set], coef_h[set], cur);
         request_weights(win[set], 1 + set);
         request_inputs(xin[set], cur, 1, set);
-        request_coef(coef_s[set], coef_h[set], cur);
     }
     int upar = 0, wpar = 0;   // LDS buffer of the K-step / weight stage being consumed
     int rs = 0;               // stage within the current tile
@@ -641,11 +641,14 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
             const int q = rs + 5;
             const int ksl = q / 3, third = q - 3 * ksl;
             const bool into_next = ksl >= nks;
+            // (the two coefficient loads go out FIRST: vector-memory results return in order, so the wait for them two
+            // stages from now is then satisfied by the time the first input of the set is -- issued last, that wait
+            // was a vmcnt(0) that also drained the younger set: 9 % on a launch with a normalised input)
+            request_coef(coef_s[SET], coef_h[SET], nxt);
             request_inputs(xin[SET], pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
             int ws = rs + 3;
             if (ws >= nstages) ws -= nstages;
             request_weights(win[SET], ws);
-            request_coef(coef_s[SET], coef_h[SET], nxt);
         }
 #endif
         // -- housekeeping with the staging waves' spare time
