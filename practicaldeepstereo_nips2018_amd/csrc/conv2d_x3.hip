@@ -455,15 +455,6 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
 }
 
 // ---- waves 4-7 -----------------------------------------------------------------------------------------------------
-// Measured and not kept (round 3, PDS_X3_TIMING): the compiler's wait before the first use of a request set is
-// vmcnt(20) -- it cannot order the two sets across the loop's merge points and also waits for the loads issued ONE stage
-// ago, so a request has one stage to land, not two.  Issuing the staged loads from inline assembly with an explicit
-// vmcnt(21) halves the MFMA waves' barrier waits (1 186 -> 670 cycles per stage) -- and the launch takes the same time
-// (0.43-0.45 ms, 364 pairs/s either way): the chip is at its power limit, the cycles gained come back as a lower clock
-// (763 000 cycles at 1.70 GHz before, 650 000 at 1.46 GHz after).  Same outcome as every other issue-efficiency change on
-// this kernel; only work removed from the launch (the three-product form: -50 % matrix work) has moved it.  (The
-// assembly form also has a trap: the hazard recogniser does not see a VMEM read of an SGPR that a v_readlane spill
-// reload has just written -- wild base addresses in some builds -- so the base has to travel through an s_mov.)
 // All four waves work at every stage, on a two-deep ring of request registers: at stage s a thread writes what it
 // requested at stage s - 2 (set s & 1) and re-uses that set for the requests of stage s + 2.  A request therefore has
 // two whole stages to land (global latency under load is ~2 us, about one stage; with a one-stage lag every stage
@@ -492,13 +483,50 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     const int coef_c = min(st, A.Cin - 1);
     float* coef_tab = reinterpret_cast<float*>(lds + LDS_COEF);
 
+    // The staged loads are issued from inline assembly and waited for with an explicit count.  Left to the compiler,
+    // the waits of a stage count down to vmcnt(0): it cannot order the two request sets across the loop's merge points
+    // and waits for the YOUNGER set as well -- the loads issued one stage ago -- so a request had one stage to land, not
+    // two, and the MFMA waves waited 1 186 cycles per stage at the barrier (PDS_X3_TIMING).  With the explicit count:
+    // 670 cycles, and +2.0 % pairs/s in a same-box A/B of the whole benchmark (384.6 / 387.3 / 386.1 against 378.4 /
+    // 378.6 / 378.8; the isolated launch is power-limited and barely moves: the cycles saved come back as clock).
+    // kSetLoads = loads every stage issues: 2 coefficients (NORM), 16 inputs, W_ITERS weight pieces; a wait for "at most
+    // kSetLoads outstanding" therefore covers the whole older set (vector-memory results return in order; other
+    // memory operations in between only make the wait stricter).
+    constexpr int kSetLoads = 16 + W_ITERS + (NORM ? 2 : 0);
     auto request_inputs = [&](float (&x)[16], const Tile& tl, int ks, int third) {
         const float* src = A.a.p + ((size_t)(tl.n * A.Cin + ks * 16) * A.D + tl.d) * plane;   // uniform
         const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
         const int yc = min(max(y, 0), A.H - 1), xc = min(max(xx, 0), A.W - 1);
-        const unsigned off = (unsigned)(yc * A.W + xc);
+        const unsigned boff = (unsigned)(yc * A.W + xc) * 4u;   // (a channel plane is far below 4 GB)
+        // One statement for the sixteen loads: the channel base walks in s[60:61] (scalar adds) and the lane offset is
+        // one VGPR.  The base arrives through s_mov: an SGPR that the compiler has just re-loaded from a spill lane
+        // (v_readlane) must not be read by a VMEM instruction within five wait states -- a hazard its recogniser does
+        // not see through inline assembly (it produced wild base addresses, i.e. memory faults, in some builds).
+        const unsigned long long base = reinterpret_cast<unsigned long long>(src);
+        const unsigned base_lo = (unsigned)base, base_hi = (unsigned)(base >> 32), step = cstride * 4u;
+#define PDS_X3_LD(I) "global_load_dword %" #I ", %16, s[60:61]\n\ts_add_u32 s60, s60, %19\n\ts_addc_u32 s61, s61, 0\n\t"
+        asm volatile("s_mov_b32 s60, %17\n\ts_mov_b32 s61, %18\n\t" PDS_X3_LD(0) PDS_X3_LD(1) PDS_X3_LD(2) PDS_X3_LD(3)
+                         PDS_X3_LD(4) PDS_X3_LD(5) PDS_X3_LD(6) PDS_X3_LD(7) PDS_X3_LD(8) PDS_X3_LD(9) PDS_X3_LD(10)
+                             PDS_X3_LD(11) PDS_X3_LD(12) PDS_X3_LD(13) PDS_X3_LD(14) "global_load_dword %15, %16, s[60:61]"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]),
+                       "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]),
+                       "=&v"(x[14]), "=&v"(x[15])
+                     : "v"(boff), "s"(base_lo), "s"(base_hi), "s"(step)
+                     : "memory", "s60", "s61", "scc");
+#undef PDS_X3_LD
+    };
+    // every value of a set passes through this statement before its first use: the wait cannot be scheduled after a
+    // consumer, and no consumer before it
+    auto await_set = [&](float (&x)[16], u32x4 (&w)[W_ITERS], float& cs, float& ch) {
+        asm volatile("s_waitcnt vmcnt(%16)"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                       "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]),
+                       "+v"(x[15])
+                     : "n"(kSetLoads)
+                     : "memory");
 #pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = (src + (size_t)c * cstride)[off];   // uniform channel base + one lane offset
+        for (int it = 0; it < W_ITERS; ++it) asm volatile("" : "+v"(w[it]) : : "memory");
+        asm volatile("" : "+v"(cs), "+v"(ch) : : "memory");
     };
     auto write_inputs = [&](const float (&x)[16], const Tile& tl, int ks, int third, unsigned char* buf,
                             const float* coef) {
@@ -549,10 +577,28 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
                 }
         }
     };
-    auto request_weights = [&](u32x4 (&w)[W_ITERS], int stage) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(A.wpk + (size_t)stage * W_STAGE);
+    unsigned woff[W_ITERS];   // byte offsets of the thread's pieces of a weight stage (the surplus ones repeat the last)
 #pragma unroll
-        for (int it = 0; it < W_ITERS; ++it) w[it] = src[min(it * STAGERS + st, wlast)];
+    for (int it = 0; it < W_ITERS; ++it) woff[it] = (unsigned)min(it * STAGERS + st, wlast) * 16u;
+    auto request_weights = [&](u32x4 (&w)[W_ITERS], int stage) {
+        const unsigned char* src = A.wpk + (size_t)stage * W_STAGE;   // uniform
+        const unsigned long long base = reinterpret_cast<unsigned long long>(src);
+        const unsigned base_lo = (unsigned)base, base_hi = (unsigned)(base >> 32);
+        static_assert(W_ITERS == 3 || W_ITERS == 5, "one statement per weight stage");
+        if constexpr (W_ITERS == 3)
+            asm volatile("s_mov_b32 s60, %6\n\ts_mov_b32 s61, %7\n\tglobal_load_dwordx4 %0, %3, s[60:61]\n\t"
+                         "global_load_dwordx4 %1, %4, s[60:61]\n\tglobal_load_dwordx4 %2, %5, s[60:61]"
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+                         : "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "s"(base_lo), "s"(base_hi)
+                         : "memory", "s60", "s61");
+        else
+            asm volatile("s_mov_b32 s60, %10\n\ts_mov_b32 s61, %11\n\tglobal_load_dwordx4 %0, %5, s[60:61]\n\t"
+                         "global_load_dwordx4 %1, %6, s[60:61]\n\tglobal_load_dwordx4 %2, %7, s[60:61]\n\t"
+                         "global_load_dwordx4 %3, %8, s[60:61]\n\tglobal_load_dwordx4 %4, %9, s[60:61]"
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[W_ITERS > 3 ? 3 : 0]), "=&v"(w[W_ITERS > 4 ? 4 : 0])
+                         : "v"(woff[0]), "v"(woff[1]), "v"(woff[2]), "v"(woff[W_ITERS > 3 ? 3 : 0]),
+                           "v"(woff[W_ITERS > 4 ? 4 : 0]), "s"(base_lo), "s"(base_hi)
+                         : "memory", "s60", "s61");
     };
     auto write_weights = [&](const u32x4 (&w)[W_ITERS], unsigned char* buf) {
         u32x4* dst = reinterpret_cast<u32x4*>(buf);
@@ -563,11 +609,18 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     // stage's requests / writes, branch-free -- a load inside a branch merges with "no load" in a phi and the compiler
     // then drains ALL outstanding loads at the merge.  The writes of the first stages carry the placeholder tile's
     // values and are overwritten by the later ones well before the table is first read (stage 3 * nks - 3 >= 6).
+    const unsigned coef_lane = (unsigned)coef_c * (A.a.per_plane ? (unsigned)A.D : 1u) * 4u;
     auto request_coef = [&](float& cs, float& ch, const Tile& tl) {
         if (NORM) {
-            const size_t g = A.a.per_plane ? ((size_t)(tl.n * A.Cin + coef_c) * A.D + tl.d) : (size_t)(tl.n * A.Cin + coef_c);
-            cs = A.a.scale[g];
-            ch = A.a.shift[g];
+            const size_t g0 = A.a.per_plane ? ((size_t)(tl.n * A.Cin) * A.D + tl.d) : (size_t)(tl.n * A.Cin);   // uniform
+            const float *ps = A.a.scale + g0, *ph = A.a.shift + g0;
+            const unsigned long long bs = reinterpret_cast<unsigned long long>(ps), bh = reinterpret_cast<unsigned long long>(ph);
+            const unsigned s_lo = (unsigned)bs, s_hi = (unsigned)(bs >> 32), h_lo = (unsigned)bh, h_hi = (unsigned)(bh >> 32);
+            asm volatile("s_mov_b32 s60, %2\n\ts_mov_b32 s61, %3\n\tglobal_load_dword %0, %6, s[60:61]\n\t"
+                         "s_mov_b32 s60, %4\n\ts_mov_b32 s61, %5\n\tglobal_load_dword %1, %6, s[60:61]"
+                         : "=&v"(cs), "=&v"(ch)
+                         : "s"(s_lo), "s"(s_hi), "s"(h_lo), "s"(h_hi), "v"(coef_lane)
+                         : "memory", "s60", "s61");
         }
     };
     auto write_coef = [&](float cs, float ch, int table) {
@@ -594,13 +647,33 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     Tile nxt = cur, done = cur;
     int nxt_id = -1;
     int tpar = 0;             // coefficient table of the current tile
+    auto await_all = [&](float (&x)[16], u32x4 (&w)[W_ITERS], float& cs, float& ch) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                       "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]),
+                       "+v"(x[15])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) asm volatile("" : "+v"(w[it]) : : "memory");
+        asm volatile("" : "+v"(cs), "+v"(ch) : : "memory");
+    };
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) xin[set][c] = 0.f;
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) win[set][it] = u32x4{0u, 0u, 0u, 0u};
+    }
     request_coef(coef_s[0], coef_h[0], cur);
-    write_coef(coef_s[0], coef_h[0], 0);
     request_weights(win[0], 0);
+    await_all(xin[0], win[0], coef_s[0], coef_h[0]);
+    write_coef(coef_s[0], coef_h[0], 0);
     write_weights(win[0], lds + LDS_W);
     x3_barrier();
     for (int third = 0; third < 3; ++third) {
         request_inputs(xin[0], cur, 0, third);
+        await_all(xin[0], win[0], coef_s[0], coef_h[0]);
         write_inputs(xin[0], cur, 0, third, lds, coef_tab);
     }
 #pragma unroll
@@ -630,6 +703,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         // branch stands between a request and its use (see request_coef): past the last tile the sequence re-stages
         // the current tile into the idle buffer, which nobody reads.
         {
+            await_set(xin[SET], win[SET], coef_s[SET], coef_h[SET]);
             const bool into_next = ks + 1 >= nks;
             write_inputs(xin[SET], pick_tile(into_next, nxt, cur), into_next ? 0 : ks + 1, dy,
                          lds + (upar ^ 1) * IN_BUF, coef_tab + ((into_next ? tpar ^ 1 : tpar) * 2 * CMAX));
@@ -641,9 +715,6 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
             const int q = rs + 5;
             const int ksl = q / 3, third = q - 3 * ksl;
             const bool into_next = ksl >= nks;
-            // (the two coefficient loads go out FIRST: vector-memory results return in order, so the wait for them two
-            // stages from now is then satisfied by the time the first input of the set is -- issued last, that wait
-            // was a vmcnt(0) that also drained the younger set: 9 % on a launch with a normalised input)
             request_coef(coef_s[SET], coef_h[SET], nxt);
             request_inputs(xin[SET], pick_tile(into_next, nxt, cur), into_next ? ksl - nks : ksl, third);
             int ws = rs + 3;
@@ -672,6 +743,9 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         if (stage(std::integral_constant<int, 0>{})) break;
         if (stage(std::integral_constant<int, 1>{})) break;
     }
+    // the requests of the last stages are never consumed: they must not outlive the wave (their late writes would land
+    // in registers that belong to another wave by then)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     x3_barrier();
     fold_statistics(done);
 }
