@@ -44,8 +44,11 @@
 //   staging     one stage ahead: what was requested during stage s-1 is converted and written during stage s (inputs
 //               of the next K-step by thirds, weights of stage s+1), then the next requests are issued; the sequence
 //               runs across tile boundaries (the next tile is drawn at stage 0), so a CU never drains between tiles.
-//   epilogue    bias, LeakyReLU, float4 stores, per-(plane, channel) sum / sum of squares -> one fp64 record per tile
-//               (the deferred InstanceNorm of common.hpp), folded by the staging waves during the next tile.
+//   epilogue    bias, LeakyReLU, per-(plane, channel) sum / sum of squares -> one fp64 record per tile (the deferred
+//               InstanceNorm of common.hpp), folded by the staging waves during the next tile.  Stores: the fp16 form
+//               transposes every M block through a wave-private LDS area so that a store instruction writes 8 channels x
+//               128 contiguous bytes (PDS_X3_EPI_LDS=0 and the bf16 form: 16 bytes per lane straight from the D fragment,
+//               i.e. 32-byte pieces in 32 channel planes per instruction -- 10 400 against 7 100 cycles per tile).
 #include <type_traits>
 
 #include "common.hpp"
@@ -71,7 +74,11 @@ struct X3Cfg {
     static constexpr int LDS_RED = LDS_W + 2 * W_STAGE;    // [4 MFMA waves][64 channels][2] floats
     static constexpr int LDS_NEXT = LDS_RED + 4 * 64 * 2 * 4;
     static constexpr int LDS_COEF = LDS_NEXT + 16;         // [tile parity 2][scale | shift][CMAX] floats
-    static constexpr int LDS_BYTES = LDS_COEF + 2 * 2 * CMAX * 4;
+    // fp16 form only (the bf16 form fills the LDS): per MFMA wave a [64 channels][32 pixels] fp32 staging area of one M block,
+    // rows padded to 144 bytes (conflict-free 16-byte writes of 8 consecutive channels), for the epilogue's transposition
+    static constexpr int EPI_ROW = 144, EPI_WAVE = 64 * EPI_ROW;
+    static constexpr int LDS_EPI = LDS_COEF + 2 * 2 * CMAX * 4;
+    static constexpr int LDS_BYTES = LDS_EPI + (P == 2 ? 4 * EPI_WAVE : 0);
     static constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;   // 16-byte pieces of a weight stage per thread
     static constexpr int PRODUCTS = P == 3 ? 6 : 3;
     // power-of-two operand scales of the fp16 form (exact): weights when packed, normalised activations in the folded
@@ -103,6 +110,7 @@ struct X3Args {
     int tiles_x_full;                         // tile columns whose right half is inside the image
     int planes;                               // N * D
     int nks;                                  // Cin / 16
+    int epi_lds;                              // fp16 form: stores of interior tiles go through the LDS transposition
 };
 
 struct Tile {
@@ -388,10 +396,55 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
             }                                                                                                         \
         }                                                                                                             \
     }
-    if (interior) {
-        PDS_X3_EPILOGUE(false)
-    } else {
-        PDS_X3_EPILOGUE(true)
+    bool done = false;
+    if constexpr (P == 2) {
+        if (interior && A.epi_lds) {
+            // Transposed stores.  In the D fragment a lane holds ONE channel and four consecutive pixels, so a direct
+            // 16-byte store scatters 32-byte pieces over 32 channel planes per instruction: the per-CU store path
+            // sustains ~12 bytes per cycle for that (9 000 cycles per 128 KB tile, tools/ubench/store_patterns.hip)
+            // and the MFMA wave sits in its epilogue for 11 000.  Through a wave-private LDS area every store
+            // instruction writes 8 channels x 128 contiguous bytes instead (2 500 cycles per tile in the probe):
+            // lane -> (quad q = lane & 7 of the 32 pixels, channel 8 j + (lane >> 3)).
+            unsigned char* epi = lds + C::LDS_EPI + L.wave * C::EPI_WAVE;
+            unsigned char* wr = epi + L.m32 * C::EPI_ROW + L.kgl * 16;       // + nb * 32 rows, + g * 32 bytes
+            const int q = (L.m32 & 7), cg = ((L.kgl << 5) | L.m32) >> 3;      // lane = kgl * 32 + m32
+            const unsigned char* rd = epi + cg * C::EPI_ROW + q * 16;        // + j * 8 rows
+#pragma unroll
+            for (int mb = 0; mb < MBLOCKS; ++mb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const float bv = nb ? L.bias1 : L.bias0;
+                        const f32x2 bv2 = {bv, bv};
+                        f32x2 ta = __builtin_elementwise_fma(f32x2{acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1]}, unscale2, bv2);
+                        f32x2 tb = __builtin_elementwise_fma(f32x2{acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]}, unscale2, bv2);
+                        ta = __builtin_elementwise_max(ta, ta * slope2);
+                        tb = __builtin_elementwise_max(tb, tb * slope2);
+                        *reinterpret_cast<f32x4*>(wr + nb * 32 * C::EPI_ROW + g * 32) = f32x4{ta[0], ta[1], tb[0], tb[1]};
+                        s2[nb][0] += ta;
+                        s2[nb][1] += tb;
+                        q2[nb][0] = __builtin_elementwise_fma(ta, ta, q2[nb][0]);
+                        q2[nb][1] = __builtin_elementwise_fma(tb, tb, q2[nb][1]);
+                    }
+                // pixel quad q of the M block: wide = one row of 32 columns; narrow = two rows of 16
+                const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (q >> 2) : mb);
+                const int x = cur.x0 + (NARROW ? 4 * (q & 3) : 4 * q);
+                float* po = obase + (size_t)cg * L.cstride + (size_t)y * A.W + x;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<f32x4*>(po + (size_t)(8 * j) * L.cstride) =
+                        *reinterpret_cast<const f32x4*>(rd + j * 8 * C::EPI_ROW);
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+        if (interior) {
+            PDS_X3_EPILOGUE(false)
+        } else {
+            PDS_X3_EPILOGUE(true)
+        }
     }
 #undef PDS_X3_EPILOGUE
     float s0 = (s2[0][0][0] + s2[0][0][1]) + (s2[0][1][0] + s2[0][1][1]);
@@ -860,6 +913,11 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     A.tiles_x_full = A.tiles_x - ((rem != 0 && rem <= 16) ? 1 : 0);
     A.planes = A.N * A.D;
     A.nks = A.Cin / 16;
+    static const bool epi_lds = []() {   // PDS_X3_EPI_LDS=0: direct 16-byte stores from the D fragment (A/B)
+        const char* e = getenv("PDS_X3_EPI_LDS");
+        return !(e && e[0] == '0');
+    }();
+    A.epi_lds = epi_lds ? 1 : 0;
     static std::atomic<unsigned> cus_done{0};   // one bit per device
     static int cus[32] = {0};
     int dev = 0;

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
+    {'PDS_X3_EPI_LDS': '0'},                 # conv2d_x3 (fp16 form): direct stores from the D fragment
     {'PDS_X3_FP16': '0'},                    # conv2d_x3 on its range-safe form everywhere (three bf16 parts, six products)
     {'PDS_X3': '0'},                         # exact-fp32 MFMA kernels (Winograd domain) instead of the split-operand kernel
     {'PDS_X3': '0', 'PDS_WINOGRAD': '0'},    # ... and the direct exact-fp32 MFMA kernel
