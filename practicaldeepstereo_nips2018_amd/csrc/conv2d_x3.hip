@@ -102,7 +102,8 @@ struct X3Args {
     const float* __restrict__ bias;
     float* __restrict__ out;
     double* __restrict__ partials;
-    int* __restrict__ queue;                  // 8 counters, zeroed before the launch
+    int* __restrict__ queue;                  // 8 counters + a count of finished workgroups; zero at launch: written by the
+                                              // weight packing, then re-zeroed by the last workgroup of every launch
     int N, Cin, D, H, W, Cout;
     int CoutStride;                           // channels per batch entry of the output tensor (>= Cout)
     int lrelu;
@@ -816,9 +817,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A) {
                                  A.tiles_y * A.tiles_x_full);
     __syncthreads();
     const int cur_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
-    if (cur_id < 0) return;
-    if (wave < 4) x3_mfma_waves<P, NORM>(A, lds, wave, tid & 63, cur_id);
-    else x3_staging_waves<P, NORM>(A, lds, tid - STAGERS, cur_id);
+    if (cur_id >= 0) {
+        if (wave < 4) x3_mfma_waves<P, NORM>(A, lds, wave, tid & 63, cur_id);
+        else x3_staging_waves<P, NORM>(A, lds, tid - STAGERS, cur_id);
+    }
+    // A workgroup leaves only after it has found every queue empty, so the last one to leave may reset the counters
+    // for the next launch on this workspace (no memset launch per layer; the packing launch zeroes them the first time).
+    __syncthreads();
+    if (tid == 0) {
+        if (atomicAdd(A.queue + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) atomicExch(A.queue + q, 0);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -887,7 +898,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
         j.taps = 9;
         // 6: three-way bf16 split, 7: two-way fp16 split of 2^10 w; A-fragment order of v_mfma_f32_32x32x16_{bf16,f16}
         j.mode = fp16 ? 7 : 6;
-        j.total = total;
+        j.total = total + 16;   // + the queue counters (zeroed by the packing launch)
         if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
         if (int rc = launch_multi_pack(&j, 1, s)) return rc;
     }
@@ -897,7 +908,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     A.bias = L.bias;
     A.out = L.out;
     A.partials = L.partials;
-    A.queue = reinterpret_cast<int*>(L.packed + x3_weight_dwords(L.in.c, 3));
+    A.queue = reinterpret_cast<int*>(L.packed + total);
     A.N = L.in.n;
     A.Cin = L.in.c;
     A.D = L.in.d;
@@ -929,7 +940,6 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     }
     const long long all = (long long)A.planes * A.tiles;
     const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
-    if (hipMemsetAsync(A.queue, 0, 8 * sizeof(int), s) != hipSuccess) return check_launch("conv2d_x3 queue reset");
     return fp16 ? x3_launch<2>(L, A, workgroups, s) : x3_launch<3>(L, A, workgroups, s);
 }
 

@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
         if (J.mode == 6 || J.mode == 7) {
+            if (e >= J.total - 16) {   // the tile-queue counters of conv2d_x3 sit behind its weights: zeroed with them
+                reinterpret_cast<unsigned*>(J.dst)[e] = 0u;
+                continue;
+            }
             const int nparts = J.mode == 6 ? 3 : 2;
             const int i2 = r % 4;
             r /= 4;
