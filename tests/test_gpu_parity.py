@@ -631,3 +631,24 @@ def test_fused_matching_descriptor_scale(dev, scale):
         out = net(left.to(dev), right.to(dev))
     assert torch.isfinite(out).all()
     assert helpers.maxdiff(out, ref) <= TOL_SIGNATURES * max(1.0, float(ref.abs().max()) / 4.0)
+
+
+def test_frozen_network_alternating_shapes_is_repeatable(dev):
+    """A frozen network re-uses its workspaces: the tile-queue counters of conv2d_x3 live behind the packed weights and
+    are re-zeroed by the last workgroup of every launch (no memset per layer).  Alternating between two input shapes
+    (different arena layouts over the same buffers) and repeating each several times must reproduce the first result of
+    that shape bit for bit -- a counter left dirty would skip or repeat tiles."""
+    torch.manual_seed(0)
+    net = pds.PdsNetwork.default(63).eval().to(dev).freeze_weights()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1, 128, 256), (1, 192, 320), (2, 128, 256)]
+    inputs = [(torch.rand(b, 3, h, w, generator=g).to(dev) * 255, torch.rand(b, 3, h, w, generator=g).to(dev) * 255)
+              for b, h, w in shapes]
+    with torch.no_grad():
+        first = [net(left, right).clone() for left, right in inputs]
+        for _ in range(3):
+            for i in (2, 0, 1, 1, 0, 2):
+                again = net(*inputs[i])
+                assert torch.equal(again, first[i]), 'shape %s changed on re-use' % (shapes[i],)
+    for out in first:
+        assert torch.isfinite(out).all()
