@@ -582,12 +582,12 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         for (int it = 0; it < W_ITERS; ++it) asm volatile("" : "+v"(w[it]) : : "memory");
         asm volatile("" : "+v"(cs), "+v"(ch) : : "memory");
     };
+    f32x4 cs[4], ch[4];   // the sixteen (scale, shift) pairs of the K-step being written: read at its first third only
     auto write_inputs = [&](const float (&x)[16], const Tile& tl, int ks, int third, unsigned char* buf,
                             const float* coef) {
         // the producer's folded InstanceNorm of this (batch entry, plane): table of the tile in LDS, one address per
-        // wave (broadcast reads), all sixteen channels up front (one LDS round trip per stage)
-        f32x4 cs[4], ch[4];
-        if (NORM) {
+        // wave (broadcast reads), all sixteen channels up front; the three thirds of a K-step share them
+        if (NORM && third == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 cs[j] = *reinterpret_cast<const f32x4*>(coef + ks * 16 + 4 * j);
