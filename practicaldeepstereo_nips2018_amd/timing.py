@@ -48,6 +48,8 @@ def time_per_image(network, examples, device, warmup=2):
                 times_with_copy.append(with_copy)
     result = {'time_per_image_ms': 1e3 * sum(times) / max(len(times), 1),
               'time_per_image_with_host_copy_ms': 1e3 * sum(times_with_copy) / max(len(times_with_copy), 1),
+              'time_per_image_median_ms': 1e3 * sorted(times)[len(times) // 2] if times else 0.0,
+              'per_example_ms': [round(1e3 * t, 3) for t in times],
               'examples': len(times),
               'protocol': 'trainer.py:141-148,241-242: host tensors -> .cuda() -> synchronize, time, network(left, right) '
                           '[pad, descriptor network x2, Matching, Regularization, SubpixelMap, crop], synchronize; one '
