@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDS_ABI_VERSION 3
+#define PDS_ABI_VERSION 4
 
 typedef void* pds_stream_t; /* hipStream_t */
 
@@ -263,7 +263,9 @@ int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_ri
  * SubpixelCrossEntropy.forward and its gradient      reference loss.py:16-78
  * similarities [n, planes, h, w]; ground_truth [n, h, w] (inf = unknown); weights [n, h, w] or NULL.
  * fwd writes loss[1], lse[n*h*w] (log-sum-exp per pixel, kept for bwd) and stats[2] = {sum w*entropy,
- * denominator}; bwd writes d loss / d similarities scaled by the device scalar grad_loss[1].
+ * denominator}; bwd writes d loss / d similarities scaled by the device scalar grad_loss[1];
+ * weights_bwd (ABI v4) writes d loss / d weights [n, h, w] = grad_loss * (entropy - loss) / denominator at known
+ * pixels, 0 elsewhere (loss.py:74-77 under autograd; only meaningful when fwd ran with weights).
  * ---------------------------------------------------------------------------------- */
 size_t pds_subpixel_cross_entropy_workspace_bytes(int n, int h, int w);
 int pds_subpixel_cross_entropy_fwd(const float* similarities, const float* ground_truth, const float* weights,
@@ -274,6 +276,10 @@ int pds_subpixel_cross_entropy_bwd(const float* similarities, const float* groun
                                    const float* lse, const float* stats, const float* grad_loss,
                                    float* grad_similarities, int n, int planes, int h, int w, float diversity,
                                    int disparity_step, pds_stream_t stream);
+int pds_subpixel_cross_entropy_weights_bwd(const float* similarities, const float* ground_truth, const float* lse,
+                                           const float* stats, const float* grad_loss, float* grad_weights, int n,
+                                           int planes, int h, int w, float diversity, int disparity_step,
+                                           pds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Evaluation metrics                         reference errors.py:9-74 (pds_trainer.py:48-58)

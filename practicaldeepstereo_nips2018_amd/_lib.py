@@ -181,6 +181,8 @@ SIGNATURES = {
                                             _VP, _SZ, _VP]),
     'pds_subpixel_cross_entropy_bwd': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, ctypes.c_float, _I,
                                             _VP]),
+    'pds_subpixel_cross_entropy_weights_bwd': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, ctypes.c_float, _I,
+                                                    _VP]),
     'pds_shift_concat_bwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_contraction_block_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
     'pds_contraction_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), ctypes.POINTER(ConvBlockParams),
@@ -191,7 +193,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
+ABI_VERSION = 4   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
 
 
 def load():

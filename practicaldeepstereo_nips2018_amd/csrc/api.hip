@@ -1656,6 +1656,17 @@ int pds_subpixel_cross_entropy_bwd(const float* similarities, const float* groun
                           w, diversity, disparity_step, (hipStream_t)stream);
 }
 
+int pds_subpixel_cross_entropy_weights_bwd(const float* similarities, const float* ground_truth, const float* lse,
+                                           const float* stats, const float* grad_loss, float* grad_weights, int n,
+                                           int planes, int h, int w, float diversity, int disparity_step,
+                                           pds_stream_t stream) {
+    PDS_REQUIRE(similarities && ground_truth && lse && stats && grad_loss && grad_weights,
+                "subpixel_cross_entropy_weights_bwd: null pointer");
+    PDS_REQUIRE(n > 0 && planes > 0 && h > 0 && w > 0, "subpixel_cross_entropy_weights_bwd: bad shape");
+    return launch_sce_weights_bwd(similarities, ground_truth, lse, stats, grad_loss, grad_weights, n, planes, h, w,
+                                  diversity, disparity_step, (hipStream_t)stream);
+}
+
 int pds_shift_concat_bwd(const float* grad_out, float* grad_left, float* grad_right, int batch, int channels, int h,
                          int w, int d_begin, int d_count, pds_stream_t stream) {
     PDS_REQUIRE(grad_out && grad_left && grad_right, "shift_concat_bwd: null pointer");

@@ -253,6 +253,9 @@ int launch_sce_fwd(const float* sim, const float* gt, const float* weights, floa
 int launch_sce_bwd(const float* sim, const float* gt, const float* weights, const float* lse, const float* stats,
                    const float* grad_loss, float* gsim, int n, int planes, int h, int w, float diversity, int step,
                    hipStream_t s);
+int launch_sce_weights_bwd(const float* sim, const float* gt, const float* lse, const float* stats,
+                           const float* grad_loss, float* gweights, int n, int planes, int h, int w, float diversity,
+                           int step, hipStream_t s);
 
 // ---- wave helpers ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {

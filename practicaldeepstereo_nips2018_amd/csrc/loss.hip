@@ -5,6 +5,7 @@
 //   loss = mean of entropy over pixels with known ground truth (gt != inf), or, with weights,
 //          sum(w * entropy) / (sum(w) + 1e-15) over those pixels.
 //   d loss / d sim_k = coef * (softmax_k - T_k / S),  coef = grad * (w or 1) / (sum(w) + 1e-15 or count)
+//   d loss / d w_i   = grad * (entropy_i - loss) / (sum(w) + 1e-15)   for known pixels, 0 otherwise (loss.py:74-77)
 //
 // Forward: ONE pass over the similarity volume with an online log-sum-exp (the reference makes a log-softmax
 // copy of the volume and then loops over the planes in Python: > 4 full passes); it keeps lse per pixel.
@@ -117,6 +118,34 @@ __global__ __launch_bounds__(256) void sce_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Gradient of the weighted loss with respect to the per-pixel weights (loss.py:74-77 under autograd): one more read of the
+// volume, entropy re-formed from the kept log-sum-exp.
+__global__ __launch_bounds__(256) void sce_weights_bwd_kernel(const float* __restrict__ sim, const float* __restrict__ gt,
+                                                              const float* __restrict__ lse_in,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ grad_loss,
+                                                              float* __restrict__ gweights, int planes, size_t plane_px,
+                                                              size_t total_px, float step, float diversity) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total_px) return;
+    const float g = gt[p];
+    if (g == INFINITY) {
+        gweights[p] = 0.f;
+        return;
+    }
+    const size_t b = p / plane_px, i = p - b * plane_px;
+    const float* src = sim + b * planes * plane_px + i;
+    const float inv_div = 1.f / diversity, norm = 0.5f / diversity;
+    float S = 0.f, A = 0.f;
+    for (int k = 0; k < planes; ++k) {
+        const float t = laplace_target(g, k, step, inv_div, norm);
+        S += t;
+        A = fmaf(t, src[(size_t)k * plane_px], A);
+    }
+    const float entropy = lse_in[p] - A / S;
+    gweights[p] = grad_loss[0] * (entropy - stats[0] / stats[1]) / stats[1];
+}
+
 size_t sce_partial_doubles(size_t total_px) { return ((total_px + 255) / 256) * 2; }
 
 int launch_sce_fwd(const float* sim, const float* gt, const float* weights, float* loss, float* lse, float* stats,
@@ -137,6 +166,16 @@ int launch_sce_bwd(const float* sim, const float* gt, const float* weights, cons
     hipLaunchKernelGGL(sce_bwd_kernel, dim3(blocks), dim3(256), 0, s, sim, gt, weights, lse, stats, grad_loss, gsim,
                        planes, plane_px, total, (float)step, diversity);
     return check_launch("subpixel_cross_entropy_bwd");
+}
+
+int launch_sce_weights_bwd(const float* sim, const float* gt, const float* lse, const float* stats,
+                           const float* grad_loss, float* gweights, int n, int planes, int h, int w, float diversity,
+                           int step, hipStream_t s) {
+    const size_t plane_px = (size_t)h * w, total = plane_px * n;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(sce_weights_bwd_kernel, dim3(blocks), dim3(256), 0, s, sim, gt, lse, stats, grad_loss, gweights,
+                       planes, plane_px, total, (float)step, diversity);
+    return check_launch("subpixel_cross_entropy_weights_bwd");
 }
 
 }  // namespace pds

@@ -5,7 +5,9 @@ Drop-in mirror of reference practical_deep_stereo/loss.py:16-78 (``SubpixelCross
 ground truth ``inf`` marks unknown pixels.  Value and gradient come from two streaming HIP kernels
 (``pds_subpixel_cross_entropy_fwd`` / ``_bwd``): one pass over the similarity volume forward, one read + one
 write backward, instead of the reference's log-softmax copy plus a Python loop over the planes.
-The gradient flows to ``similarities`` only (``weights`` is treated as a constant).
+The gradient flows to ``similarities`` and, when ``weights`` requires it, to ``weights``
+(``pds_subpixel_cross_entropy_weights_bwd``: d loss / d w = (entropy - loss) / (sum w + 1e-15) at known pixels,
+loss.py:74-77 under autograd); the ground truth is a constant, as in the reference (its ``.data`` mask, loss.py:52).
 """
 import ctypes
 
@@ -30,10 +32,7 @@ class SubpixelCrossEntropy(nn.Module):
                              (tuple(gt.shape), tuple(sim.shape)))
         w = None
         if weights is not None:
-            if torch.is_grad_enabled() and weights.requires_grad:
-                raise NotImplementedError('SubpixelCrossEntropy: the gradient with respect to `weights` is not '
-                                          'implemented (pass weights.detach())')
-            w = _lib.require_gpu_tensor(weights.detach(), 'weights', 3)
+            w = _lib.require_gpu_tensor(weights, 'weights', 3)
             if w.shape != gt.shape:
                 raise ValueError('weights of shape %s do not match the ground truth %s' %
                                  (tuple(w.shape), tuple(gt.shape)))
@@ -56,7 +55,7 @@ class _SubpixelCrossEntropyFunction(torch.autograd.Function):
                 _lib.ptr(loss), _lib.ptr(lse), _lib.ptr(stats), n, planes, h, w, diversity, step,
                 _lib.ptr(ws), ws.numel(), _lib.stream_handle(sim.device)), 'pds_subpixel_cross_entropy_fwd')
         ctx.save_for_backward(sim, gt, lse, stats)
-        ctx.weights = weights
+        ctx.weights = weights.detach() if weights is not None else None
         ctx.config = (diversity, step)
         return loss
 
@@ -75,4 +74,12 @@ class _SubpixelCrossEntropyFunction(torch.autograd.Function):
                 _lib.ptr(lse), _lib.ptr(stats), _lib.ptr(grad_loss), _lib.ptr(grad_sim),
                 n, planes, h, w, diversity, step, _lib.stream_handle(sim.device)),
                 'pds_subpixel_cross_entropy_bwd')
-        return grad_sim, None, None, None, None
+        grad_weights = None
+        if weights is not None and ctx.needs_input_grad[2]:
+            grad_weights = torch.empty_like(weights)
+            with torch.cuda.device(sim.device):
+                _lib.check(lib.pds_subpixel_cross_entropy_weights_bwd(
+                    _lib.ptr(sim), _lib.ptr(gt), _lib.ptr(lse), _lib.ptr(stats), _lib.ptr(grad_loss),
+                    _lib.ptr(grad_weights), n, planes, h, w, diversity, step, _lib.stream_handle(sim.device)),
+                    'pds_subpixel_cross_entropy_weights_bwd')
+        return grad_sim, None, grad_weights, None, None

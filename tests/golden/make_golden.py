@@ -196,14 +196,16 @@ def g8_loss():
     sim = torch.tensor([[0.1, 0.3, 0.2, 0.05], [0.2, 0.1, 0.4, 0.0], [0.2, 0.1, 0.4, 0.0]])
     sim = sim.t().contiguous().view(1, 4, 3, 1).requires_grad_(True)
     gt = torch.tensor([[1.3], [float('inf')], [1.9]]).view(1, 3, 1)
-    w = torch.tensor([[0.9], [0.0], [0.01]]).view(1, 3, 1)
+    w = torch.tensor([[0.9], [0.0], [0.01]]).view(1, 3, 1).requires_grad_(True)
     value = ref_loss.SubpixelCrossEntropy(diversity=2.0, disparity_step=1)(sim, gt, w)
     value.backward()
     assert abs(value.item() - 1.3654) < 1e-3
     sim_o = sim.detach().clone().requires_grad_(True)
-    value_o = oracle.subpixel_cross_entropy(sim_o, gt, w, 2.0, 1)
+    w_o = w.detach().clone().requires_grad_(True)
+    value_o = oracle.subpixel_cross_entropy(sim_o, gt, w_o, 2.0, 1)
     value_o.backward()
     assert abs(value_o.item() - value.item()) < 1e-6 and maxdiff(sim_o.grad, sim.grad) < 1e-7
+    assert maxdiff(w_o.grad, w.grad) < 1e-7
     g = torch.Generator().manual_seed(21)
     sim2 = (torch.randn(2, 32, 9, 13, generator=g) * 0.6).requires_grad_(True)
     gt2 = torch.rand(2, 9, 13, generator=g) * 62
@@ -212,15 +214,21 @@ def g8_loss():
     out = {}
     for name, weights in (('plain', None), ('weighted', w2)):
         s_ref = sim2.detach().clone().requires_grad_(True)
+        if weights is not None:
+            weights = weights.clone().requires_grad_(True)   # loss.py:73-77: the weights receive a gradient too
         v = ref_loss.SubpixelCrossEntropy()(s_ref, gt2, weights)
         v.backward()
+        if weights is not None:
+            out['random_weighted_weights_grad'] = weights.grad
+            weights = weights.detach()
         s_or = sim2.detach().clone().requires_grad_(True)
         vo = oracle.subpixel_cross_entropy(s_or, gt2, weights)
         vo.backward()
         assert abs(v.item() - vo.item()) < 1e-5 and maxdiff(s_ref.grad, s_or.grad) < 1e-7, name
         out['random_' + name + '_value'] = v.detach()
         out['random_' + name + '_grad'] = s_ref.grad
-    save('g8_loss', ref_sim=sim.detach(), ref_gt=gt, ref_weights=w, ref_value=value.detach(), ref_grad=sim.grad,
+    save('g8_loss', ref_sim=sim.detach(), ref_gt=gt, ref_weights=w.detach(), ref_weights_grad=w.grad,
+         ref_value=value.detach(), ref_grad=sim.grad,
          random_sim=sim2.detach(), random_gt=gt2, random_weights=w2, **out)
     REPORT['g8_loss'] = {'reference_value': value.item()}
 

@@ -331,8 +331,8 @@ def test_training_step_against_reference_fixture(dev):
 
 
 def test_unsupported_autograd_uses_fail_loudly(dev):
-    """A second backward through a node, a gradient for the image and one for the loss weights are refused with
-    a message instead of crashing or silently returning nothing."""
+    """A second backward through a node and a gradient for the image are refused with a message instead of
+    crashing or silently returning nothing."""
     op = helpers.seeded(pds.MatchingOperation, seed=3).to(dev)
     x = torch.randn(1, 128, 8, 12, generator=torch.Generator().manual_seed(0)).to(dev).requires_grad_(True)
     out = op(x).sum()
@@ -345,13 +345,32 @@ def test_unsupported_autograd_uses_fail_loudly(dev):
     with pytest.raises(NotImplementedError, match='image'):
         emb(image)
 
-    crit = pds.SubpixelCrossEntropy()
-    sim = torch.randn(1, 8, 4, 6, device=dev, requires_grad=True)
-    gt = torch.rand(1, 4, 6, device=dev) * 10
-    weights = torch.ones(1, 4, 6, device=dev, requires_grad=True)
-    with pytest.raises(NotImplementedError, match='weights'):
-        crit(sim, gt, weights)
-    crit(sim, gt, weights.detach()).backward()   # the supported form
+
+def test_subpixel_cross_entropy_weight_gradient(dev):
+    """loss.py:73-77 under autograd: the gradient reaching ``weights`` -- the reference's own known-answer case and the
+    seeded random case of G8 (reference autograd), then a larger case against the fp64 oracle."""
+    g = helpers.golden('g8_loss')
+    sim = g['ref_sim'].to(dev).requires_grad_(True)
+    w = g['ref_weights'].to(dev).requires_grad_(True)
+    pds.SubpixelCrossEntropy(diversity=2.0, disparity_step=1)(sim, g['ref_gt'].to(dev), w).backward()
+    assert helpers.maxdiff(w.grad, g['ref_weights_grad']) <= 1e-6
+    assert helpers.maxdiff(sim.grad, g['ref_grad']) <= 1e-6
+    sim = g['random_sim'].to(dev).requires_grad_(True)
+    w = g['random_weights'].to(dev).requires_grad_(True)
+    (3.0 * pds.SubpixelCrossEntropy()(sim, g['random_gt'].to(dev), w)).backward()
+    assert helpers.maxdiff(w.grad, 3.0 * g['random_weighted_weights_grad']) <= 1e-6
+    assert helpers.maxdiff(sim.grad, 3.0 * g['random_weighted_grad']) <= 1e-6
+    assert float(w.grad[:, 2:4].abs().max()) == 0.0      # unknown ground truth: no gradient
+    gen = torch.Generator().manual_seed(5)
+    sim = torch.randn(2, 24, 33, 47, generator=gen)
+    gt = torch.rand(2, 33, 47, generator=gen) * 46
+    gt[0, :5] = float('inf')
+    weights = torch.rand(2, 33, 47, generator=gen) + 0.1
+    w64 = weights.double().requires_grad_(True)
+    oracle.subpixel_cross_entropy(sim.double(), gt.double(), w64).backward()
+    wd = weights.to(dev).requires_grad_(True)
+    pds.SubpixelCrossEntropy()(sim.to(dev), gt.to(dev), wd).backward()
+    assert helpers.maxdiff(wd.grad, w64.grad.float()) <= 1e-7 + 1e-5 * float(w64.grad.abs().max())
 
 
 def test_eval_mode_with_gradients_warns_once(dev):

@@ -147,12 +147,14 @@ def test_subpixel_cross_entropy_golden():
                              [0.0011, -0.0002, -0.0007, -0.0002]]).t().reshape(1, 4, 3, 1)
     assert torch.allclose(sim.grad, expected, atol=1e-3)
     assert helpers.maxdiff(sim.grad, g['ref_grad']) <= 1e-7
-    for name, weights in (('plain', None), ('weighted', g['random_weights'])):
+    for name, weights in (('plain', None), ('weighted', g['random_weights'].clone().requires_grad_(True))):
         s2 = g['random_sim'].clone().requires_grad_(True)
         v = oracle.subpixel_cross_entropy(s2, g['random_gt'], weights)
         v.backward()
         assert abs(v.item() - g['random_%s_value' % name].item()) < 1e-5
         assert helpers.maxdiff(s2.grad, g['random_%s_grad' % name]) <= 1e-7
+        if weights is not None:   # loss.py:73-77: the weights receive a gradient from the reference's autograd
+            assert helpers.maxdiff(weights.grad, g['random_weighted_weights_grad']) <= 1e-7
 
 
 def test_errors_golden():
