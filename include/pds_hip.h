@@ -238,6 +238,15 @@ int pds_embedding_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams
                       const float* descriptor, float* grad_descriptor, const float* grad_shortcut, int batch, int h,
                       int w, int pad_top, int pad_left, void* fwd_workspace, size_t fwd_workspace_bytes, void* workspace,
                       size_t workspace_bytes, pds_stream_t stream);
+/* ABI v4.  The same backward pass continued to the image (embedding.py:32,46-65 under autograd): grad_image
+ * [batch, input_features, h, w] = d loss / d image through the first convolution and the parameter-free
+ * InstanceNorm2d of the padded image (the virtual pad pixels take part in its statistics and receive no gradient). */
+size_t pds_embedding_image_bwd_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,
+                                               int pad_left);
+int pds_embedding_image_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads, const float* image,
+                            const float* descriptor, float* grad_descriptor, const float* grad_shortcut,
+                            float* grad_image, int batch, int h, int w, int pad_top, int pad_left, void* fwd_workspace,
+                            size_t fwd_workspace_bytes, void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
 /* backward of the stand-alone blocks (regularization.py:28-31, 54-57 under autograd); grad_* param structs hold
  * the gradient buffers of the two conv blocks, written */

@@ -174,6 +174,9 @@ SIGNATURES = {
     'pds_embedding_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(EmbeddingParams), _I, _I, _I, _I, _I]),
     'pds_embedding_bwd': (_I, [ctypes.POINTER(EmbeddingParams)] * 2 + [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I,
                                _VP, _SZ, _VP, _SZ, _VP]),
+    'pds_embedding_image_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(EmbeddingParams), _I, _I, _I, _I, _I]),
+    'pds_embedding_image_bwd': (_I, [ctypes.POINTER(EmbeddingParams)] * 2 + [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I,
+                                     _VP, _SZ, _VP, _SZ, _VP]),
     'pds_disparity_errors_workspace_bytes': (_SZ, [_SZ]),
     'pds_disparity_errors_fwd': (_I, [_VP, _VP, _SZ, ctypes.c_float, _VP, _VP, _VP, _VP, _SZ, _VP]),
     'pds_subpixel_cross_entropy_workspace_bytes': (_SZ, [_I, _I, _I]),

@@ -757,9 +757,18 @@ static void expansion_pipeline(Ctx& c, const PdsConvBlockParams* pp, const float
 // ---- Embedding (reference embedding.py:46-65) over a virtually padded image (size_adapter.py:29-43) --------
 // image [batch, C0, h, w]; descriptor [batch, F, H4, W4]; shortcut [batch, S, H4, W4] with
 // H2 = ceil((h + top) / 2), H4 = ceil(H2 / 2) (same for the width).
+// the image head as the backward pass needs it: folded InstanceNorm coefficients of the image and the tape id of the
+// space-to-depth tensor (which receives a gradient only when the caller wants d loss / d image)
+struct ImageHead {
+    bool want_grad = false;
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int id = -1;
+};
+
 static void embedding_pipeline(Ctx& c, const PdsEmbeddingParams& P, const float* image, float* descriptor,
                                float* shortcut, int batch, int h, int w, int top, int left, int* id_descriptor = nullptr,
-                               int* id_shortcut = nullptr) {
+                               int* id_shortcut = nullptr, ImageHead* head = nullptr) {
     const int C0 = P.input_features, F = P.features;
     // parameter-free InstanceNorm2d of the padded image (embedding.py:32), folded into the re-layout below
     const int chunks = image_stats_chunks(h, w);
@@ -774,7 +783,12 @@ static void embedding_pipeline(Ctx& c, const PdsEmbeddingParams& P, const float*
                                  scale0, shift0, nullptr, nullptr, c.s));
         c.run(launch_space_to_depth(Src{image, scale0, shift0, 0, 0}, batch, C0, h, w, top, left, s0, c.s));
     }
-    const Src s0_src = external_src(c, s0, g1, 0, false);  // tape id 0: no gradient wanted
+    const Src s0_src = external_src(c, s0, g1, 0, head && head->want_grad);  // tape id 0: a gradient only for d image
+    if (head) {
+        head->scale = scale0;
+        head->shift = shift0;
+        head->id = s0_src.id;
+    }
     // convolutional_block_5x5_stride_2 twice (embedding.py:33-36), each as k3 s1 over space-to-depth input
     float* w1 = c.get<float>((size_t)F * 4 * C0 * 9);
     if (c.before_packing()) c.run(launch_s2d_weights(P.downsampling[0].weight, w1, F, C0, c.s));
@@ -1554,15 +1568,17 @@ int pds_embedding_fwd(const PdsEmbeddingParams* params, const float* image, floa
 
 static int embedding_backward(bool plan, size_t* bytes, const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads,
                               const float* image, const float* descriptor, float* grad_descriptor,
-                              const float* grad_shortcut, int batch, int h, int w, int top, int left,
+                              const float* grad_shortcut, float* grad_image, int batch, int h, int w, int top, int left,
                               void* fwd_workspace, void* workspace, hipStream_t stream) {
     Tape tape;
+    ImageHead head;
+    head.want_grad = grad_image != nullptr;   // (a planning walk passes a non-null mark)
     Ctx re{plan ? nullptr : (char*)fwd_workspace, 0, true, stream};
     re.tape = &tape;
     int id_d = -1, id_s = -1;
     // the descriptor feeds the shortcut block, so its forward values are needed; the shortcut output is not
     embedding_pipeline(re, *params, image, const_cast<float*>(descriptor), const_cast<float*>(grad_shortcut), batch, h,
-                       w, top, left, &id_d, &id_s);
+                       w, top, left, &id_d, &id_s, &head);
     if (re.err) return re.err;
     std::vector<float*> dhat(tape.tensors.size(), nullptr);
     std::vector<char> written(tape.tensors.size(), 0);
@@ -1577,6 +1593,13 @@ static int embedding_backward(bool plan, size_t* bytes, const PdsEmbeddingParams
     Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
     if (!plan) c.limit = g_backward_arena_bytes;
     backward_walk(c, tape, M, dhat, written);
+    if (head.want_grad && !c.err) {
+        // embedding.py:32 under autograd: depth-to-space + the parameter-free InstanceNorm2d of the padded image
+        if (!written[head.id]) return set_error(-1, "embedding_bwd: no gradient reached the image head");
+        if (!plan)
+            c.run(launch_image_grad(dhat[head.id], image, head.scale, head.shift, batch, params->input_features, h, w,
+                                    top, left, grad_image, stream));
+    }
     if (bytes) *bytes = c.off;
     return c.err;
 }
@@ -1588,8 +1611,21 @@ size_t pds_embedding_bwd_workspace_bytes(const PdsEmbeddingParams* params, int b
     const PdsEmbeddingParams q = plan_embedding_params(params, blocks);
     const PdsEmbeddingParams gq = plan_embedding_params(params, gblocks);
     size_t bytes = 0;
-    if (embedding_backward(true, &bytes, &q, &gq, nullptr, nullptr, nullptr, nullptr, batch, h, w, pad_top, pad_left,
-                           nullptr, nullptr, nullptr))
+    if (embedding_backward(true, &bytes, &q, &gq, nullptr, nullptr, nullptr, nullptr, nullptr, batch, h, w, pad_top,
+                           pad_left, nullptr, nullptr, nullptr))
+        return 0;
+    return bytes + 256;
+}
+
+size_t pds_embedding_image_bwd_workspace_bytes(const PdsEmbeddingParams* params, int batch, int h, int w, int pad_top,
+                                               int pad_left) {
+    if (check_embedding(params, batch, h, w, pad_top, pad_left)) return 0;
+    std::vector<PdsConvBlockParams> blocks, gblocks;
+    const PdsEmbeddingParams q = plan_embedding_params(params, blocks);
+    const PdsEmbeddingParams gq = plan_embedding_params(params, gblocks);
+    size_t bytes = 0;
+    if (embedding_backward(true, &bytes, &q, &gq, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<float*>(8), batch,
+                           h, w, pad_top, pad_left, nullptr, nullptr, nullptr))
         return 0;
     return bytes + 256;
 }
@@ -1608,8 +1644,27 @@ int pds_embedding_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams
     PDS_REQUIRE(workspace_bytes >= pds_embedding_bwd_workspace_bytes(params, batch, h, w, pad_top, pad_left),
                 "embedding_bwd: workspace too small");
     ArenaLimit limit(workspace_bytes);
-    return embedding_backward(false, nullptr, params, grads, image, descriptor, grad_descriptor, grad_shortcut, batch, h,
-                              w, pad_top, pad_left, fwd_workspace, workspace, (hipStream_t)stream);
+    return embedding_backward(false, nullptr, params, grads, image, descriptor, grad_descriptor, grad_shortcut, nullptr,
+                              batch, h, w, pad_top, pad_left, fwd_workspace, workspace, (hipStream_t)stream);
+}
+
+int pds_embedding_image_bwd(const PdsEmbeddingParams* params, const PdsEmbeddingParams* grads, const float* image,
+                            const float* descriptor, float* grad_descriptor, const float* grad_shortcut,
+                            float* grad_image, int batch, int h, int w, int pad_top, int pad_left, void* fwd_workspace,
+                            size_t fwd_workspace_bytes, void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_embedding(params, batch, h, w, pad_top, pad_left)) return rc;
+    PDS_REQUIRE(grads && image && descriptor && grad_descriptor && grad_shortcut && grad_image && fwd_workspace &&
+                    workspace,
+                "embedding_image_bwd: null pointer");
+    PDS_REQUIRE(params->residual_blocks == 0 || grads->blocks, "embedding_image_bwd: gradient blocks missing");
+    if (int rc = check_embedding_blocks(params)) return rc;
+    PDS_REQUIRE(fwd_workspace_bytes >= pds_embedding_workspace_bytes(params, batch, h, w, pad_top, pad_left),
+                "embedding_image_bwd: forward workspace too small");
+    PDS_REQUIRE(workspace_bytes >= pds_embedding_image_bwd_workspace_bytes(params, batch, h, w, pad_top, pad_left),
+                "embedding_image_bwd: workspace too small");
+    ArenaLimit limit(workspace_bytes);
+    return embedding_backward(false, nullptr, params, grads, image, descriptor, grad_descriptor, grad_shortcut,
+                              grad_image, batch, h, w, pad_top, pad_left, fwd_workspace, workspace, (hipStream_t)stream);
 }
 
 // ---- evaluation metrics (errors.py:9-74) ---------------------------------------------------------------

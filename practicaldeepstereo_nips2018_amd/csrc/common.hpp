@@ -238,6 +238,9 @@ int launch_image_stats(const float* img, int nc, int h, int w, double* partials,
 // [N, C, H, W] (virtually zero-padded by top rows / left columns) -> [N, 4C, ceil((H+top)/2), ceil((W+left)/2)]
 int launch_space_to_depth(const Src& a, int n, int c, int h, int w, int top, int left, float* out, hipStream_t s);
 int launch_depth_to_space(const float* g, int n, int c, int h, int w, float* out, hipStream_t s);
+// d image from the gradient of the space-to-depth tensor: depth-to-space + InstanceNorm2d (no affine) backward over the padded plane
+int launch_image_grad(const float* g, const float* img, const float* scale, const float* shift, int n, int c, int h,
+                      int w, int top, int left, float* out, hipStream_t s);
 int launch_s2d_weights(const float* w5, float* w3, int cout, int cin, hipStream_t s);
 int launch_s2d_weights_bwd(const float* g3, float* g5, int cout, int cin, int accumulate, hipStream_t s);
 

@@ -92,6 +92,56 @@ __global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __rest
     }
 }
 
+// Adjoint of the image head (embedding.py:32 under autograd): g [N, 4C, h2, w2], the gradient of the space-to-depth
+// tensor, goes back through depth-to-space and the parameter-free InstanceNorm2d of the PADDED image to
+// d image [N, C, H, W].  With xh = (x - mean) * rstd over the Hp x Wp padded plane (pad pixels are ordinary members
+// of the statistics, x = 0) :  dx_i = rstd * (g_i - mean_j(g_j) - xh_i * mean_j(g_j xh_j)), j over the padded plane.
+// One workgroup per (n, c): both plane sums in fp64, then the apply pass over the real pixels.
+__global__ __launch_bounds__(1024) void image_grad_kernel(const float* __restrict__ g, const float* __restrict__ img,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int C, int H, int W, int top,
+                                                          int left, int h2, int w2, float* __restrict__ out) {
+    const int nc = blockIdx.x;
+    const int n = nc / C, c = nc % C;
+    const float sc = scale[nc], sh = shift[nc];   // no affine: scale = rstd, shift = -mean * rstd
+    const int Hp = H + top, Wp = W + left;
+    const size_t plane2 = (size_t)h2 * w2, padded = (size_t)Hp * Wp;
+    const float* gp = g + (size_t)n * 4 * C * plane2;
+    const float* p = img + (size_t)nc * H * W;
+    auto grad_at = [&](int y, int x) {
+        return gp[(size_t)(((y & 1) * 2 + (x & 1)) * C + c) * plane2 + (size_t)(y >> 1) * w2 + (x >> 1)];
+    };
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = threadIdx.x; i < padded; i += 1024) {
+        const int y = (int)(i / Wp), x = (int)(i % Wp);
+        const int yy = y - top, xx = x - left;
+        const float raw = (yy >= 0 && xx >= 0) ? p[(size_t)yy * W + xx] : 0.f;
+        const float gv = grad_at(y, x);
+        s1 += (double)gv;
+        s2 += (double)gv * (double)fmaf(sc, raw, sh);
+    }
+    __shared__ double red[16][2];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < 16; ++i) {
+        t1 += red[i][0];
+        t2 += red[i][1];
+    }
+    const float m1 = (float)(t1 / (double)padded), m2 = (float)(t2 / (double)padded);
+    for (size_t i = threadIdx.x; i < (size_t)H * W; i += 1024) {
+        const int yy = (int)(i / W), xx = (int)(i % W);
+        const float xh = fmaf(sc, p[i], sh);
+        out[(size_t)nc * H * W + i] = sc * (grad_at(yy + top, xx + left) - m1 - xh * m2);
+    }
+}
+
 // w5 [K, C, 5, 5] -> w3 [K, 4C, 3, 3]
 __global__ void s2d_weights_kernel(const float* __restrict__ w5, float* __restrict__ w3, int K, int C) {
     const int total = K * 4 * C * 9;
@@ -140,6 +190,14 @@ int launch_depth_to_space(const float* g, int n, int c, int h, int w, float* out
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(depth_to_space_kernel, dim3((unsigned)bx, n * c), dim3(256), 0, s, g, c, h, w, h2, w2, out);
     return check_launch("depth_to_space");
+}
+
+int launch_image_grad(const float* g, const float* img, const float* scale, const float* shift, int n, int c, int h,
+                      int w, int top, int left, float* out, hipStream_t s) {
+    const int h2 = (h + top + 1) / 2, w2 = (w + left + 1) / 2;
+    hipLaunchKernelGGL(image_grad_kernel, dim3(n * c), dim3(1024), 0, s, g, img, scale, shift, c, h, w, top, left, h2, w2,
+                       out);
+    return check_launch("image_grad");
 }
 
 int launch_s2d_weights(const float* w5, float* w3, int cout, int cin, hipStream_t s) {

@@ -63,13 +63,8 @@ class Embedding(_lib.FrozenWeightsMixin, nn.Module):
         if x.size(1) != self._embedding_modules[1].conv.in_channels:
             raise ValueError('expected %d image channels, got %d' %
                              (self._embedding_modules[1].conv.in_channels, x.size(1)))
-        if torch.is_grad_enabled():
-            if x.requires_grad:
-                # the reference propagates through the first InstanceNorm to the image; this path does not
-                raise NotImplementedError('Embedding: the gradient with respect to the image is not implemented '
-                                          '(detach the image, or use the reference module for saliency-type uses)')
-            if any(p.requires_grad for p in self.parameters()):
-                _lib.warn_eval_with_grad(self)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            _lib.warn_eval_with_grad(self)
         return _EmbeddingFunction.apply(self, x, int(pad_top), int(pad_left), *self.parameters())
 
     def forward(self, image):
@@ -83,7 +78,8 @@ def _quarter(size):
 
 
 class _EmbeddingFunction(torch.autograd.Function):
-    """pds_embedding_fwd / _bwd; the image itself never receives a gradient."""
+    """pds_embedding_fwd / _bwd; an image that requires a gradient gets one through pds_embedding_image_bwd
+    (embedding.py:32: the first InstanceNorm2d under autograd)."""
 
     @staticmethod
     def forward(ctx, module, image, pad_top, pad_left, *unused_parameters):
@@ -136,15 +132,25 @@ class _EmbeddingFunction(torch.autograd.Function):
         params, keep = module.native_params()
         grads, tensor_of = _lib.gradient_buffers(module)
         grad_params, keep_grads = module.native_params(tensor_of)
-        nbytes = lib.pds_embedding_bwd_workspace_bytes(ctypes.byref(params), batch, h, w, pad_top, pad_left)
+        want_image = ctx.needs_input_grad[1]
+        sizer = lib.pds_embedding_image_bwd_workspace_bytes if want_image else lib.pds_embedding_bwd_workspace_bytes
+        nbytes = sizer(ctypes.byref(params), batch, h, w, pad_top, pad_left)
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=image.device)
         fws = _lib.saved_workspace(ctx, 'embedding')
+        grad_image = torch.empty_like(image) if want_image else None
         with torch.cuda.device(image.device):
-            _lib.check(lib.pds_embedding_bwd(
-                ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(image), _lib.ptr(descriptor),
-                _lib.ptr(grad_descriptor), _lib.ptr(grad_shortcut), batch, h, w, pad_top, pad_left,
-                _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_handle(image.device)),
-                'pds_embedding_bwd')
+            if want_image:
+                _lib.check(lib.pds_embedding_image_bwd(
+                    ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(image), _lib.ptr(descriptor),
+                    _lib.ptr(grad_descriptor), _lib.ptr(grad_shortcut), _lib.ptr(grad_image), batch, h, w, pad_top,
+                    pad_left, _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(),
+                    _lib.stream_handle(image.device)), 'pds_embedding_image_bwd')
+            else:
+                _lib.check(lib.pds_embedding_bwd(
+                    ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(image), _lib.ptr(descriptor),
+                    _lib.ptr(grad_descriptor), _lib.ptr(grad_shortcut), batch, h, w, pad_top, pad_left,
+                    _lib.ptr(fws), fws.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_handle(image.device)),
+                    'pds_embedding_bwd')
         del keep, keep_grads
         ctx.forward_workspace = None
-        return (None, None, None, None) + tuple(grads[id(p)] for p in module.parameters())
+        return (None, grad_image, None, None) + tuple(grads[id(p)] for p in module.parameters())

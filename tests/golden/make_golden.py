@@ -259,6 +259,42 @@ def g9_embedding():
     REPORT['g9_embedding'] = rep
 
 
+def g12_image_gradient():
+    """The gradient the reference's autograd delivers to the IMAGE (embedding.py:32,46-65 behind SizeAdapter.pad,
+    size_adapter.py:29-43): d/d image of sum(descriptor * wd) + sum(shortcut * ws) in the reference's own fp64 run
+    (the fp32 run rides along as the noise floor), on an image whose size needs padding on top and on the left."""
+    torch.manual_seed(0)
+    emb = ref_embedding.Embedding()
+    g = torch.Generator().manual_seed(12)
+    image = torch.rand(1, 3, 37, 51, generator=g) * 255
+    adapter = ref_size_adapter.SizeAdapter()
+    wd = ws = None
+    grads = {}
+    for dtype in (torch.float64, torch.float32):
+        net = ref_embedding.Embedding().to(dtype)
+        net.load_state_dict({k: v.to(dtype) for k, v in emb.state_dict().items()})
+        leaf = image.clone().to(dtype).requires_grad_(True)
+        descriptor, shortcut = net(adapter.pad(leaf))
+        if wd is None:
+            wd = torch.randn(descriptor.shape, generator=g)
+            ws = torch.randn(shortcut.shape, generator=g)
+        ((descriptor * wd.to(dtype)).sum() + (shortcut * ws.to(dtype)).sum()).backward()
+        grads[dtype] = leaf.grad
+    p = {k: v.double() for k, v in prefixed(emb.state_dict(), '_embedding').items()}
+    leaf = image.clone().double().requires_grad_(True)
+    padded, rows, columns = oracle.pad_to_multiple(leaf)
+    d_o, s_o = oracle.embedding(p, '_embedding', padded)
+    ((d_o * wd.double()).sum() + (s_o * ws.double()).sum()).backward()
+    scale = float(grads[torch.float64].abs().max())
+    rep = {'oracle_vs_reference_fp64_rel': maxdiff(leaf.grad, grads[torch.float64]) / scale,
+           'reference_fp32_vs_fp64_rel': maxdiff(grads[torch.float32], grads[torch.float64]) / scale,
+           'pad': [rows, columns]}
+    assert rep['oracle_vs_reference_fp64_rel'] <= 1e-9, rep
+    save('g12_image_gradient', image=image, wd=wd, ws=ws, grad_image_fp64=grads[torch.float64],
+         grad_image_fp32=grads[torch.float32], weight_checksum=checksum(emb.state_dict()))
+    REPORT['g12_image_gradient'] = rep
+
+
 def g10_errors():
     """errors.py:9-74: the reference's own known answers (test/test_errors.py:13-66) and a seeded random case with
     an inf band; pixel-wise maps, mean / median absolute error and n-pixels error."""
@@ -451,6 +487,7 @@ if __name__ == '__main__':
     g9_embedding()
     g10_errors()
     g11_training_step()
+    g12_image_gradient()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
     REPORT['torch'] = torch.__version__

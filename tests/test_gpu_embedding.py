@@ -57,6 +57,21 @@ def test_embedding_rejects_cpu_and_wrong_channels(dev):
         emb(torch.zeros(1, 4, 8, 8, device=dev))
 
 
+def test_image_gradient_golden(dev):
+    """G12: the gradient the reference's own autograd (fp64) delivers to a 37x51 image padded by 27 rows / 13 columns;
+    the HIP path (virtual pad folded into the first layer's loader) within 2e-3 of it relative to the largest entry."""
+    g = helpers.golden('g12_image_gradient')
+    emb = helpers.seeded(pds.Embedding).to(dev)
+    assert abs(helpers.checksum(emb.state_dict()) - g['weight_checksum'].item()) < 1e-6
+    image = g['image'].to(dev).requires_grad_(True)
+    descriptor, shortcut = emb.forward_padded(image, 27, 13)
+    ((descriptor * g['wd'].to(dev)).sum() + (shortcut * g['ws'].to(dev)).sum()).backward()
+    err = relative_error(image.grad, g['grad_image_fp64'])
+    print('image gradient vs the reference fp64 run: %.3g (reference fp32: %.3g)'
+          % (err, relative_error(g['grad_image_fp32'], g['grad_image_fp64'])))
+    assert err <= 2e-3, err
+
+
 @pytest.mark.parametrize('shape,pad,blocks', [((2, 3, 40, 56), (0, 0), 2), ((1, 3, 37, 51), (27, 13), 1),
                                               ((1, 1, 32, 32), (0, 0), 0)])
 def test_embedding_backward(dev, shape, pad, blocks):
@@ -65,7 +80,8 @@ def test_embedding_backward(dev, shape, pad, blocks):
                                                number_of_embedding_features=16 if blocks != 2 else 64,
                                                number_of_residual_blocks=blocks), seed=6).to(dev)
     image = (torch.rand(*shape, generator=g) * 255)
-    descriptor, shortcut = emb.forward_padded(image.to(dev), pad[0], pad[1])
+    image_dev = image.to(dev).requires_grad_(True)   # embedding.py:32,46-65 under autograd: the image gets a gradient too
+    descriptor, shortcut = emb.forward_padded(image_dev, pad[0], pad[1])
     wd = torch.randn(descriptor.shape, generator=g)
     wsh = torch.randn(shortcut.shape, generator=g)
     ((descriptor * wd.to(dev)).sum() + (shortcut * wsh.to(dev)).sum()).backward()
@@ -74,12 +90,17 @@ def test_embedding_backward(dev, shape, pad, blocks):
 
     def run(dtype):
         p = {k: v.to(dtype).requires_grad_(True) for k, v in params.items()}
-        padded = torch.nn.functional.pad(image.to(dtype), (pad[1], 0, pad[0], 0))
+        leaf = image.to(dtype).requires_grad_(True)
+        padded = torch.nn.functional.pad(leaf, (pad[1], 0, pad[0], 0))
         d, s = oracle.embedding(p, '_e', padded, number_of_residual_blocks=blocks)
         ((d * wd.to(dtype)).sum() + (s * wsh.to(dtype)).sum()).backward()
-        return d.detach(), s.detach(), {k: v.grad for k, v in p.items()}
+        return d.detach(), s.detach(), {k: v.grad for k, v in p.items()}, leaf.grad
 
-    d64, s64, g64 = run(torch.float64)
-    _, _, g32 = run(torch.float32)
-    assert relative_error(descriptor, d64) <= 1e-4 and relative_error(shortcut, s64) <= 1e-4
+    d64, s64, g64, gi64 = run(torch.float64)
+    _, _, g32, gi32 = run(torch.float32)
+    assert relative_error(descriptor.detach(), d64) <= 1e-4 and relative_error(shortcut.detach(), s64) <= 1e-4
     check_param_grads(emb, '_e', g64, noise_floor=g32)
+    assert image_dev.grad is not None and image_dev.grad.shape == image.shape
+    err, floor = relative_error(image_dev.grad, gi64), relative_error(gi32, gi64)
+    print('image gradient: error %.3g (fp32 CPU oracle: %.3g) relative to the largest entry' % (err, floor))
+    assert err <= max(2e-3, 3.0 * floor), (err, floor)

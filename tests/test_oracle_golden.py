@@ -157,6 +157,25 @@ def test_subpixel_cross_entropy_golden():
             assert helpers.maxdiff(weights.grad, g['random_weighted_weights_grad']) <= 1e-7
 
 
+def test_image_gradient_golden():
+    """embedding.py:32,46-65 behind size_adapter.py:29-43 under autograd: the oracle's fp32 image gradient against the
+    reference's fp64 one (G12), no further away than the reference's own fp32 run."""
+    g = helpers.golden('g12_image_gradient')
+    torch.manual_seed(0)
+    import practicaldeepstereo_nips2018_amd as pds
+    emb = pds.Embedding()
+    assert abs(float(sum(v.double().sum() for v in emb.state_dict().values())) - g['weight_checksum'].item()) < 1e-9
+    p = helpers.prefixed(emb.state_dict(), '_embedding')
+    leaf = g['image'].clone().requires_grad_(True)
+    padded, rows, columns = oracle.pad_to_multiple(leaf)
+    assert (rows, columns) == (27, 13)
+    d, s = oracle.embedding(p, '_embedding', padded)
+    ((d * g['wd']).sum() + (s * g['ws']).sum()).backward()
+    scale = float(g['grad_image_fp64'].abs().max())
+    floor = helpers.maxdiff(g['grad_image_fp32'], g['grad_image_fp64']) / scale
+    assert helpers.maxdiff(leaf.grad, g['grad_image_fp64']) / scale <= max(1e-5, 3.0 * floor)
+
+
 def test_errors_golden():
     """reference test/test_errors.py:13-66 known answers and a seeded case with an inf band (errors.py:9-74)."""
     g = helpers.golden('g10_errors')
