@@ -81,13 +81,16 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
     }
     const float bias = A.bias ? A.bias[0] : 0.f;
 
-    float st[CIN][UPOS];
-#define PDS_FETCHP(p_)                                                             \
+    // Two register stages: plane p + 2 is requested while plane p is consumed and is stashed one iteration later, so a
+    // request has a whole plane step (~1 500 cycles) to land; with one stage (request at the top of a step, stash at its
+    // end) every step waited for HBM.  The two stages swap roles from step to step (plane loop unrolled by two).
+    float stA[CIN][UPOS], stB[CIN][UPOS];
+#define PDS_FETCHP(st_, p_)                                                        \
     _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < UPOS; ++k) \
-        st[c][k] = src[c * cstride + (size_t)(p_) * plane + goff[k]];
-#define PDS_STASHP(buf_)                                                           \
+        st_[c][k] = src[c * cstride + (size_t)(p_) * plane + goff[k]];
+#define PDS_STASHP(st_, buf_)                                                      \
     _Pragma("unroll") for (int c = 0; c < CIN; ++c) _Pragma("unroll") for (int k = 0; k < UPOS; ++k) \
-        tile[buf_][c][loff[k]] = inside[k] ? fmaf(sc[c], st[c][k], sh[c]) : 0.f;
+        tile[buf_][c][loff[k]] = inside[k] ? fmaf(sc[c], st_[c][k], sh[c]) : 0.f;
 
     // estimator state for the 4 pixels of this lane (output row 2 i + PY): a delayed window win[0..2T] of the last
     // finished planes (win[2T] newest).  When the centre win[T] (plane k - T) beats the running maximum, its T
@@ -109,15 +112,17 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
 #pragma unroll
     for (int o = 0; o < 2; ++o) acc[0][o] = acc[1][o] = acc[2][o] = f32x2{bias, bias};
 
-    PDS_FETCHP(0)
-    PDS_STASHP(0)
+    PDS_FETCHP(stB, 0)
+    if (1 < A.D) PDS_FETCHP(stA, 1)
+    PDS_STASHP(stB, 0)
     __syncthreads();
 
     const int lbase = r * HC + 2 * cp;  // halo row r, halo column 2cp  (input column j0 + 2cp - 1)
-    for (int p = 0; p <= A.D + (WRITE_COST ? 0 : T); ++p) {  // + T flush steps that only drain the window
+    // one plane step: sx holds plane p + 1 (requested a step ago), sy receives plane p + 2
+    auto plane_step = [&](const int p, float (&sx)[CIN][UPOS], float (&sy)[CIN][UPOS]) __attribute__((always_inline)) {
         if (p < A.D) {
             const int cur = p & 1;
-            if (p + 1 < A.D) PDS_FETCHP(p + 1)
+            if (p + 2 < A.D) PDS_FETCHP(sy, p + 2)
 #pragma nounroll
             for (int c = 0; c < CIN; ++c) {  // not unrolled: keeps only 3 x 16 weight SGPRs live
                 // the two halo rows this output-row parity uses: vr = 1 (tap kh = 1 / 2) and vr = 0 / 2 (kh = 3 / 0).  The four
@@ -160,7 +165,7 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
                     }
                 }
             }
-            if (p + 1 < A.D) PDS_STASHP(cur ^ 1)
+            if (p + 1 < A.D) PDS_STASHP(sx, cur ^ 1)
             __syncthreads();
         }
         if (WRITE_COST) {
@@ -201,6 +206,11 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
             acc[1][o] = acc[2][o];
             acc[2][o] = f32x2{bias, bias};
         }
+    };
+    const int last = A.D + (WRITE_COST ? 0 : T);   // + T flush steps that only drain the window
+    for (int p = 0; p <= last; p += 2) {
+        plane_step(p, stA, stB);
+        if (p + 1 <= last) plane_step(p + 1, stB, stA);
     }
 #undef PDS_FETCHP
 #undef PDS_STASHP
