@@ -342,6 +342,10 @@ Plan3 choose_plan(const Geom& o, int cin, int stride) {
         if (o.w > 16) return Plan3{4, 1, 2, 2, 2, 16};
         return Plan3{5, 1, 2, 2, 1, 16};
     }
+    // large stride-2 layers (c0.down: 8 -> 16 from the full-resolution volume): the 129-column halo tile of the 64-wide
+    // plan takes 117 KB of LDS -- one workgroup, one wave per SIMD on a CU, nothing to hide the staging behind.  16-wide
+    // tiles (40 KB, three workgroups per CU): 64 -> 45 us at 24 x 72 x 120 (32-wide: 48)
+    if (o.w > 32 && (size_t)o.d * o.h * o.w >= 100000) return Plan3{9, 1, 2, 2, 1, 4};
     if (o.w > 32) return Plan3{6, 1, 2, 2, 4, 4};
     if (o.w > 16) return Plan3{7, 1, 2, 2, 2, 8};
     return Plan3{8, 1, 2, 2, 1, 8};
@@ -447,6 +451,7 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s) {
         case 6: return launch3<0, 2, 1, 2, 2, 4, 4>(A, s);
         case 7: return launch3<0, 2, 1, 2, 2, 2, 8>(A, s);
         case 8: return launch3<0, 2, 1, 2, 2, 1, 8>(A, s);
+        case 9: return launch3<0, 2, 1, 2, 2, 1, 4>(A, s);
     }
     return set_error(-1, "conv3d_mfma: no configuration");
 }
