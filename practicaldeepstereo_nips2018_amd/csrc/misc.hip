@@ -571,7 +571,9 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
         if (active) {
             float* o = t1 + ((size_t)nc * d_count + dl) * px + (size_t)y * w + xb;
             if (vec) {
-                *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+                // non-temporal: a write-only stream of 418 MB (125 -> 109 us; the consuming conv2d_x3 launch is unchanged)
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(nt4{r[0], r[1], r[2], r[3]}, reinterpret_cast<nt4*>(o));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
