@@ -229,6 +229,34 @@ def test_network_image_gradients(dev):
         print('%s image gradient: error %.3g of the largest entry (fp32 CPU oracle %.3g), mean error %.3g of the mean '
               'magnitude' % (name, err, floor, mean_err))
         assert err <= 5e-2 and mean_err <= 1e-2, (name, err, mean_err, floor)
+    # The gradient is the gradient of the HIP path's OWN loss: a central difference of that loss along the gradient
+    # direction reproduces |g|^2 as far as the function is linear.  It hardly is: on the exact fp64 oracle the slope
+    # is 0.965 |g|^2 when the largest pixel moves by +-0.02 grey levels and 0.36 |g|^2 at +-2 (random weights, ~50
+    # normalised layers).  That curvature -- 3.5 % of the gradient per 0.02 grey levels -- is also what turns the
+    # 1e-5 difference between two fp32 forward passes into the ~2e-3 mean gradient difference gated above.
+    # Gates: the HIP slope equals the fp64 oracle's slope at the same steps, and approaches |g|^2 at the small one.
+    gl, gr = left_dev.grad, right_dev.grad
+    squared = float((gl.double() ** 2).sum() + (gr.double() ** 2).sum())
+    peak = float(max(gl.abs().max(), gr.abs().max()))
+    criterion = pds.SubpixelCrossEntropy()
+    p64 = oracle.cast_params(params, torch.float64)
+
+    def oracle_loss(l, r):
+        return oracle.subpixel_cross_entropy(oracle.network_training_output(p64, l, r, 63), gt.double()).item()
+
+    for move, slack in ((2.0, 0.01), (0.02, 0.05)):
+        t = move / peak
+        with torch.no_grad():
+            up = criterion(net(left_dev + t * gl, right_dev + t * gr), gt.to(dev)).item()
+            down = criterion(net(left_dev - t * gl, right_dev - t * gr), gt.to(dev)).item()
+            dl, dr = (t * gl).double().cpu(), (t * gr).double().cpu()
+            up64 = oracle_loss(left.double() + dl, right.double() + dr)
+            down64 = oracle_loss(left.double() - dl, right.double() - dr)
+        slope, slope64 = (up - down) / (2.0 * t), (up64 - down64) / (2.0 * t)
+        print('largest pixel +-%.2f: finite-difference slope %.5g (fp64 oracle %.5g), |g|^2 %.5g'
+              % (move, slope, slope64, squared))
+        assert abs(slope - slope64) <= slack * squared, (move, slope, slope64, squared)
+    assert 0.9 * squared <= slope <= 1.03 * squared, (slope, squared)
 
 
 def test_standalone_blocks_backward(dev):
