@@ -200,9 +200,10 @@ def test_network_image_gradients(dev):
     Tolerance (stated): the image gradient is a tiny, sign-cancelling quantity (largest entry ~1e-5) behind ~50 normalised
     layers.  The descriptor network alone, driven by identical upstream gradients, reproduces the fp64 image gradient to
     8e-7 of its largest entry (tools/diag_image_grad.py; tests/test_gpu_embedding.py holds it to 2e-3 with random upstream
-    gradients and against the reference's own run, G12); end to end, the gradients ARRIVING at the descriptors carry
-    ~2e-3 of fp32 noise (HIP path and fp32 CPU oracle alike) which the descriptor network's backward amplifies: measured
-    1.2e-2 (left) / 2.0e-2 (right) of the largest entry, mean error 1.7e-3 of the mean magnitude.  Gates: 5e-2 / 1e-2."""
+    gradients and against the reference's own run, G12); end to end, the gradients ARRIVING at the descriptors differ
+    from fp64 by ~1.5e-3 mean-relative (fp32 CPU oracle: 1.0e-3) and the image gradient by 1.2e-2 (left) / 2.0e-2
+    (right) of the largest entry, mean error 1.7e-3 / 2.4e-3 of the mean magnitude.  Gates: 5e-2 / 1e-2, plus the
+    finite-difference gates below, which are the tight ones."""
     net = helpers.seeded(lambda: pds.PdsNetwork.default(63)).to(dev).train()
     left, right = helpers.images(1, 100, 150)       # padded by 28 rows / 42 columns inside the network
     gt = torch.rand(1, 100, 150, generator=torch.Generator().manual_seed(6)) * 60
