@@ -13,7 +13,7 @@
 //               K = 4 = the (yi, xi) corners of one (input channel, zi): v_mfma_f32_16x16x4_f32, exact fp32.
 //               B[k][n] = in[ic][cz + zi][cy + yi][cx0 + n + xi]: the two k of a 32-lane LDS read group differ by one
 //               float, so the reads are conflict-free for any row stride.
-//   workgroup   4 waves, PERSISTENT (2 per CU), static tile lists in contiguous runs per XCD.  A tile is TZ x TY rows
+//   workgroup   4 waves, PERSISTENT (2 or 4 per CU), static tile lists in contiguous runs per XCD.  A tile is TZ x TY rows
 //               of 16*NB cells; a wave owns RW rows and MBW of the M blocks: every B operand read from LDS feeds MBW
 //               MFMAs; its A fragments (MBW x Cin x 2) are gathered once per workgroup straight from the
 //               [Cin, Cout, 4, 4, 4] tensor (no packing launch) and stay in registers.
@@ -345,8 +345,11 @@ struct CellPlan {
 };
 
 // configurations: (Cin, Cout) = (8, 4): id 0; (16, 8): id 1
+// (8, 4) runs 32-cell-wide tiles on FOUR workgroups per CU: with 64-cell tiles the kernel needed 251 VGPRs (two waves per
+// SIMD, two workgroups per CU) -- 112 -> 102 us at 48 x 144 x 240; half-height tiles instead: 105-107; (16, 8) on 32-cell
+// tiles: 66 -> 82, it keeps 64.
 CellPlan cell_plan(int cin, int cout) {
-    if (cin == 8 && cout == 4) return CellPlan{0, 2, 4, 4};
+    if (cin == 8 && cout == 4) return CellPlan{0, 2, 4, 2};
     if (cin == 16 && cout == 8) return CellPlan{1, 2, 2, 4};
     return CellPlan{-1, 0, 0, 0};
 }
@@ -387,7 +390,7 @@ bool deconv3d_cell_supported(const DeconvLayer& L) {
 int deconv3d_cell_records(const Geom& in, int cout) {
     const CellPlan p = cell_plan(in.c, cout);
     const int tiles = cell_tiles(in, p);
-    int per_n = 512 / (in.n > 0 ? in.n : 1);
+    int per_n = (p.id == 0 ? 1024 : 512) / (in.n > 0 ? in.n : 1);   // persistent workgroups: 4 resp. 2 per CU
     if (per_n > tiles) per_n = tiles;
     per_n = (per_n + 7) / 8 * 8;
     return per_n < 8 ? 8 : per_n;
@@ -411,7 +414,7 @@ int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s) {
     A.records = deconv3d_cell_records(L.in, L.out_g.c);
     const bool norm = L.a.scale != nullptr;
     if (p.id == 0)
-        return norm ? launch_cell<8, 4, 2, 2, 4, 4, true>(A, L.in.n, s) : launch_cell<8, 4, 2, 2, 4, 4, false>(A, L.in.n, s);
+        return norm ? launch_cell<8, 4, 2, 2, 4, 2, true>(A, L.in.n, s) : launch_cell<8, 4, 2, 2, 4, 2, false>(A, L.in.n, s);
     if (p.id == 1)
         return norm ? launch_cell<16, 8, 2, 2, 2, 4, true>(A, L.in.n, s) : launch_cell<16, 8, 2, 2, 2, 4, false>(A, L.in.n, s);
     return set_error(-1, "deconv3d_cell: no configuration");
