@@ -1,0 +1,36 @@
+"""Copies the summaries tools/collect_profiles.sh left under gpurun_out/profiles_rNN/ into profiles/ (tracked) and refreshes
+the conv64 counter record bench.py reads its `roofline.traffic` from:   python tools/install_profiles.py [r03]"""
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+src = os.path.join(ROOT, 'gpurun_out', 'profiles_' + tag)
+dst = os.path.join(ROOT, 'profiles')
+for a, b in (('bench_line.json', 'bench_line.json'), ('kernels_seq.txt', 'kernels_sequential.txt'),
+             ('kernels_3streams.txt', 'kernels_three_streams.txt'), ('pmc.txt', 'pmc_all_kernels.txt'),
+             ('train_step_kernels.txt', 'train_step_kernels.txt')):
+    shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
+blocks = re.split(r'\n(?=\S)', open(os.path.join(dst, tag + '_pmc_all_kernels.txt')).read())
+block = [b for b in blocks if 'conv2d_x3_kernel<2, true>' in b.split('\n')[0] and '131072' in b.split('\n')[0]][0]
+values = {m.group(1): float(m.group(2)) for m in re.finditer(r'^\s+(\w+)\s+([\d.e+]+)\s*$', block, re.M)}
+path = os.path.join(dst, tag + '_conv64_pmc.json')
+record = json.load(open(path))
+record['kernel'] = block.split('\n')[0].strip()
+for key in ('TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES',
+            'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'):
+    if key in values:
+        record[key] = values[key]
+record['FETCH_SIZE_KB'], record['WRITE_SIZE_KB'] = values['FETCH_SIZE'], values['WRITE_SIZE']
+record['hbm_bytes_per_launch'] = (values['FETCH_SIZE'] * record['fetch_correction'] + values['WRITE_SIZE']) * 1e3
+record['l2_requests_per_launch'] = values['TCC_HIT_sum'] + values['TCC_MISS_sum']
+record['mfma_pipe_busy'] = record['SQ_VALU_MFMA_BUSY_CYCLES'] / (record['GRBM_GUI_ACTIVE'] / 8 * 1024)
+json.dump(record, open(path, 'w'), indent=1)
+line = json.loads(open(os.path.join(dst, tag + '_bench_line.json')).read())
+print('pairs/s %.1f (windows %s), sequential %.3f ms, whole network %.3f ms, time_per_image %s' % (
+    line['value'], line['windows'], line['ms_per_frame'], line['full_forward_ms'], line['time_per_image']['per_example_ms']))
+print('conv64: %.3f ms isolated, frac %.3f, traffic %.0f MB' % (
+    line['roofline']['launch_ms'], line['roofline']['frac'], record['hbm_bytes_per_launch'] / 1e6))
