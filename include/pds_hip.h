@@ -34,12 +34,20 @@
 extern "C" {
 #endif
 
-#define PDS_ABI_VERSION 4
+#define PDS_ABI_VERSION 5
 
 typedef void* pds_stream_t; /* hipStream_t */
 
 int pds_abi_version(void);
 const char* pds_last_error(void);
+
+/* ABI v5.  Non-finite InstanceNorm statistics.  The reference propagates NaN / inf silently (network_blocks.py:47-85
+ * have no checks); here every statistics kernel that finds a group whose mean or variance is not finite (a NaN / inf
+ * in the caller's tensors or parameters, or an overflow) bumps a counter in host-mapped memory, so a caller can
+ * tell "garbage in" from a number WITHOUT a device synchronisation in the hot path.  Returns the count reported by
+ * kernels that have completed so far (all devices of the process; synchronise the stream first for an exact answer)
+ * and resets it when `reset` is non-zero; -1 when the counter could not be set up. */
+long long pds_nonfinite_statistics(int reset);
 
 /* ------------------------------------------------------------------------------------
  * Layer parameters in the reference's own (PyTorch) layouts.
@@ -176,15 +184,19 @@ size_t pds_conv_block_workspace_bytes(int n, int cin, int cout, int d, int h, in
 int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* raw, float* scale,
                        float* shift, int n, int cin, int cout, int d, int h, int w, int kd, int stride,
                        int per_plane, void* workspace, size_t workspace_bytes, pds_stream_t stream);
-/* ABI v3.  The same block chained behind another one, as inside the modules (network_blocks.py:47-72: Conv ->
- * LeakyReLU -> InstanceNorm, then the next Conv): x is the producer's RAW output and the loader applies the producer's
- * folded InstanceNorm, x^ = x_scale * x + x_shift ([n*cin], or [n*cin*d] when x_per_plane).  Same workspace size as
- * pds_conv_block_fwd.  This is the form in which the 64 -> 64 layers of MatchingOperation (matching.py:85-88) run in
- * the hot path, and the launch bench.py times for the roofline of the dominant kernel. */
+/* ABI v3 (x_bound: v5).  The same block chained behind another one, as inside the modules (network_blocks.py:47-72:
+ * Conv -> LeakyReLU -> InstanceNorm, then the next Conv): x is the producer's RAW output and the loader applies the
+ * producer's folded InstanceNorm, x^ = x_scale * x + x_shift ([n*cin], or [n*cin*d] when x_per_plane).  Same workspace
+ * size as pds_conv_block_fwd.  This is the form in which the 64 -> 64 layers of MatchingOperation (matching.py:85-88)
+ * run in the hot path, and the launch bench.py times for the roofline of the dominant kernel.
+ * x_bound: device pointer to ONE float that bounds |x^| (inside the modules in_finalize writes
+ * max_c |gamma_c| sqrt(group size) + |beta_c|, which is rigorous), or NULL.  The fp16-split kernels scale their
+ * operands by a power of two derived from it, so the bound may be loose by orders of magnitude but must hold; with NULL
+ * nothing is assumed about the range and the range-safe forms run (three-way bf16 split / exact fp32). */
 int pds_conv_block_chained_fwd(const PdsConvBlockParams* params, const float* x, const float* x_scale,
-                               const float* x_shift, int x_per_plane, float* raw, float* scale, float* shift,
-                               int n, int cin, int cout, int d, int h, int w, int kd, int stride, int per_plane,
-                               void* workspace, size_t workspace_bytes, pds_stream_t stream);
+                               const float* x_shift, int x_per_plane, const float* x_bound, float* raw, float* scale,
+                               float* shift, int n, int cin, int cout, int d, int h, int w, int kd, int stride,
+                               int per_plane, void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward (training: loss.backward() in reference pds_trainer.py:40-46 reaches these modules through

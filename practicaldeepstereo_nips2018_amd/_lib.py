@@ -138,6 +138,7 @@ _SZ = ctypes.c_size_t
 SIGNATURES = {
     'pds_abi_version': (_I, []),
     'pds_last_error': (ctypes.c_char_p, []),
+    'pds_nonfinite_statistics': (ctypes.c_longlong, [_I]),
     'pds_subpixel_map_fwd': (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_shift_concat_fwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_matching_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
@@ -154,7 +155,7 @@ SIGNATURES = {
     'pds_conv_block_workspace_bytes': (_SZ, [_I] * 9),
     'pds_conv_block_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _VP,
                                 _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
-    'pds_conv_block_chained_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _I, _VP, _VP, _VP,
+    'pds_conv_block_chained_fwd': (_I, [ctypes.POINTER(ConvBlockParams), _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP,
                                         _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
     'pds_regularization_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(RegularizationParams), _I, _I, _I, _I]),
     'pds_regularization_bwd': (_I, [ctypes.POINTER(RegularizationParams), ctypes.POINTER(RegularizationParams),
@@ -196,7 +197,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 4   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
+ABI_VERSION = 5   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
 
 
 def load():

@@ -187,13 +187,28 @@ struct DT {
     int per_plane = 0;
     int id = -1;
     bool normed = false;   // a deferred InstanceNorm goes with the tensor (true in planning walks too, where scale is null)
+    // range certificate (common.hpp Src::bound): written by in_finalize for a normalised tensor, by the producing
+    // kernel (per-workgroup maxima) for a plain one
+    float* bound = nullptr;
+    int bound_n = 0;
+    bool bounded = false;
     Src src() const {
         Src s{raw, scale, shift, per_plane, 0};
         s.id = id;
         s.normed = normed ? 1 : 0;
+        s.bound = bound;
+        s.bound_n = bound_n;
+        s.bounded = bounded ? 1 : 0;
         return s;
     }
 };
+
+// a plain tensor whose producer writes `records` per-workgroup maxima of |value|
+static void carve_amax(Ctx& c, DT& t, int records) {
+    t.bound = c.get<float>((size_t)records);
+    t.bound_n = records;
+    t.bounded = true;
+}
 
 // a caller-provided plain tensor as a source, registered on the tape when one is being recorded
 static Src external_src(Ctx& c, const float* p, const Geom& g, int bcast_d = 0, bool needs_grad = true) {
@@ -260,7 +275,6 @@ struct ConvExtra {
     // a k5 s2 layer evaluated as k3 s1 over space-to-depth input (any kernel): weights to use instead of P.weight
     const float* weight_used = nullptr;
     int s2d_cin = 0;
-    int unit_range = 0;   // conv2d_x3: the plain input is O(1) (a residual sum of normalised tensors)
     bool matching_extras() const { return l0A || side_out || plane_weight_sets > 0; }
 };
 
@@ -298,7 +312,6 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.d_begin = extra->d_begin;
         L.side_out = extra->side_out;
         L.plane_weight_sets = extra->plane_weight_sets;
-        L.unit_range = extra->unit_range;
     }
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
     // Winograd domain (plain single-source Cin -> 64 layers), 9 = conv2d on the bf16 pipe with three-way split operands
@@ -352,12 +365,15 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         o.shift = shift_out ? shift_out : c.get<float>(groups);
         o.mean = c.get<float>(groups);
         o.rstd = c.get<float>(groups);
+        o.bound = c.get<float>(1);
+        o.bound_n = 1;
+        o.bounded = true;
         if (!c.plan) {
             c.run(launch());
             const int per_group = volume_records ? tiles : tiles * (per_plane ? 1 : o.g.d);
             const double count = (double)o.g.h * o.g.w * (per_plane ? 1 : o.g.d);
             c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
-                                     per_plane ? o.g.d : 1, o.scale, o.shift, o.mean, o.rstd, c.s));
+                                     per_plane ? o.g.d : 1, o.scale, o.shift, o.mean, o.rstd, c.s, o.bound));
         }
     } else if (!c.plan) {
         c.run(launch());
@@ -418,10 +434,13 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
         o.shift = c.get<float>(groups);
         o.mean = c.get<float>(groups);
         o.rstd = c.get<float>(groups);
+        o.bound = c.get<float>(1);
+        o.bound_n = 1;
+        o.bounded = true;
         if (!c.plan) {
             c.run(launch());
             c.run(launch_in_finalize(L.partials, groups, per_group, (double)o.g.volume(), P.gamma, P.beta,
-                                     o.g.c, 1, o.scale, o.shift, o.mean, o.rstd, c.s));
+                                     o.g.c, 1, o.scale, o.shift, o.mean, o.rstd, c.s, o.bound));
         }
     } else if (!c.plan) {
         c.run(launch());
@@ -436,25 +455,24 @@ static void operation_tail(Ctx& c, const PdsMatchingParams& P, const Src& x0, co
     const int F = P.features;
     Src cur = x0;
     DT t2;
-    // A residual sum norm(t2) + x is a plain tensor dominated by its O(1) normalised term: the fp16-split kernels apply
-    // (conv2d_x3, conv2d_t8).  x0 itself -- a convolution of the caller's tensor, of unknown scale -- does not qualify.
-    ConvExtra unit;
-    unit.unit_range = 1;
+    // A residual sum norm(t2) + x is a plain tensor; the kernel that forms it records its largest magnitude (the range
+    // certificate the fp16-split kernels conv2d_x3 / conv2d_t8 scale by).  x0 itself -- a convolution of the caller's
+    // tensor, of unknown scale -- carries none: its consumer takes the range-safe form.
     for (int r = 0; r < P.residual_blocks; ++r) {
-        DT t1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1, nullptr, true, nullptr, nullptr,
-                           (r > 0 && !cur.scale) ? &unit : nullptr);
+        DT t1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
         t2 = conv_block(c, t1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
         if (r + 1 < P.residual_blocks) {
             DT nxt;  // plain residual sum  x_{r+1} = norm(t2) + x_r
             nxt.raw = c.get<float>(g.numel());
             nxt.g = g;
-            if (!c.plan) c.run(launch_materialize(t2.src(), cur, g, nxt.raw, c.s));
+            carve_amax(c, nxt, materialize_records(g));
+            if (!c.plan) c.run(launch_materialize(t2.src(), cur, g, nxt.raw, c.s, nxt.bound));
             tape_layer(c, 2, 0, 0, t2.src(), cur, g, nxt, nullptr, false);
             cur = nxt.src();
         }
     }
     if (P.residual_blocks > 0)
-        conv_block(c, t2.src(), cur, g, P.last, P.signature_features, 1, 1, 1, signature, true, nullptr, nullptr, &unit);
+        conv_block(c, t2.src(), cur, g, P.last, P.signature_features, 1, 1, 1, signature);
     else
         conv_block(c, cur, no_src(), g, P.last, P.signature_features, 1, 1, 1, signature);
 }
@@ -624,10 +642,13 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         t1.shift = c.get<float>(groups);
         t1.mean = c.get<float>(groups);
         t1.rstd = c.get<float>(groups);
+        t1.bound = c.get<float>(1);
+        t1.bound_n = 1;
+        t1.bounded = true;
         if (!c.plan) {
             c.run(launch_l1_combine(y4.raw, corr, corr0, t1.raw, partials, batch, F, h, w, d_begin, d_count, c.s));
             c.run(launch_in_finalize(partials, groups, tiles, (double)h * w, P.blocks[0].gamma, P.blocks[0].beta, F,
-                                     d_count, t1.scale, t1.shift, t1.mean, t1.rstd, c.s));
+                                     d_count, t1.scale, t1.shift, t1.mean, t1.rstd, c.s, t1.bound));
         }
     }
     DT t2 = conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1);
@@ -639,24 +660,30 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     // This walk is inference-only (no tape), so the [B, 64, D', h, w] activations rotate through THREE buffers (the
     // most that are live at once: a block's input, its first and its second layer) instead of one per layer: t1's
     // buffer is dead once t2 exists, t2's once the residual sum is formed.
-    float* cur = t1.raw;   // x1 = norm(t2) + x0 overwrites t1
-    if (!c.plan) c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur, c.s));
+    // x_r = norm(t2) + x_{r-1} is a plain tensor: the kernel that forms it records its largest magnitudes, the range
+    // certificate of the fp16-split kernels behind it (conv2d_x3, conv2d_t8)
+    DT cur;
+    cur.g = g;
+    cur.raw = t1.raw;   // x1 = norm(t2) + x0 overwrites t1
+    carve_amax(c, cur, materialize_l0_records(g));
+    if (!c.plan)
+        c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur.raw, c.s, cur.bound));
     float* spare_a = t2.raw;                        // free from here on
     float* spare_b = c.get<float>(g.numel());
-    ConvExtra unit;          // x_r = norm(t2) + x_{r-1}: a plain tensor of O(1) values
-    unit.unit_range = 1;
     for (int r = 1; r < P.residual_blocks; ++r) {
-        t1 = conv_block(c, plain_src(cur), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a, true, nullptr, nullptr, &unit);
+        t1 = conv_block(c, cur.src(), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a);
         t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1, spare_b);
         if (r + 1 < P.residual_blocks) {
-            float* nxt = spare_a;                   // t1 is dead: x_{r+1} = norm(t2) + x_r goes there
-            if (!c.plan) c.run(launch_materialize(t2.src(), plain_src(cur), g, nxt, c.s));
-            spare_a = cur;
+            DT nxt;                                 // t1 is dead: x_{r+1} = norm(t2) + x_r goes there
+            nxt.g = g;
+            nxt.raw = spare_a;
+            carve_amax(c, nxt, materialize_records(g));
+            if (!c.plan) c.run(launch_materialize(t2.src(), cur.src(), g, nxt.raw, c.s, nxt.bound));
+            spare_a = cur.raw;
             cur = nxt;
         }
     }
-    conv_block(c, t2.src(), plain_src(cur), g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr,
-               &unit);   // (the residual sum is a plain tensor of O(1) values: conv2d_t8's fp16-split form)
+    conv_block(c, t2.src(), cur.src(), g, P.last, P.signature_features, 1, 1, 1, signatures);
 }
 
 static void operation_pipeline(Ctx& c, const PdsMatchingParams& P, const float* concatenated, float* signature,
@@ -799,28 +826,29 @@ static void embedding_pipeline(Ctx& c, const PdsEmbeddingParams& P, const float*
     DT s1;
     s1.g = Geom{batch, 4 * F, 1, (t1.g.h + 1) / 2, (t1.g.w + 1) / 2};
     s1.raw = c.get<float>(s1.g.numel());
-    if (!c.plan) c.run(launch_space_to_depth(t1.src(), batch, F, t1.g.h, t1.g.w, 0, 0, s1.raw, c.s));
+    // the re-layout of a normalised tensor is a plain tensor with the same range certificate (conv2d_x3: fp16 form)
+    s1.bound = c.get<float>(1);
+    s1.bound_n = 1;
+    s1.bounded = true;
+    if (!c.plan) c.run(launch_space_to_depth(t1.src(), batch, F, t1.g.h, t1.g.w, 0, 0, s1.raw, c.s, s1.bound));
     tape_layer(c, 3, 0, 0, t1.src(), no_src(), t1.g, s1, nullptr, false);
     float* w2 = c.get<float>((size_t)F * 4 * F * 9);
     if (c.before_packing()) c.run(launch_s2d_weights(P.downsampling[1].weight, w2, F, F, c.s));
     ConvExtra e2;
     e2.weight_used = w2;
     e2.s2d_cin = F;
-    e2.unit_range = 1;   // space-to-depth of a normalised tensor: plain O(1) values (conv2d_x3: fp16 form)
     DT t2 = conv_block(c, s1.src(), no_src(), s1.g, P.downsampling[1], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e2);
     // residual blocks (embedding.py:38-41); the last sum is the descriptor
     const Geom g = t2.g;
     Src cur = t2.src();
-    ConvExtra unit;   // a residual sum of normalised tensors is a plain tensor of O(1) values (conv2d_x3: fp16 form)
-    unit.unit_range = 1;
     for (int r = 0; r < P.residual_blocks; ++r) {
-        DT u1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1, nullptr, true, nullptr, nullptr,
-                           cur.scale ? nullptr : &unit);
+        DT u1 = conv_block(c, cur, no_src(), g, P.blocks[2 * r], F, 1, 1, 1);
         DT u2 = conv_block(c, u1.src(), no_src(), g, P.blocks[2 * r + 1], F, 1, 1, 1);
-        DT nxt;
+        DT nxt;   // a residual sum is a plain tensor: the kernel that forms it records its largest magnitudes (Src::bound)
         nxt.g = g;
         nxt.raw = (r + 1 == P.residual_blocks) ? descriptor : c.get<float>(g.numel());
-        if (!c.plan) c.run(launch_materialize(u2.src(), cur, g, nxt.raw, c.s));
+        carve_amax(c, nxt, materialize_records(g));
+        if (!c.plan) c.run(launch_materialize(u2.src(), cur, g, nxt.raw, c.s, nxt.bound));
         tape_layer(c, 2, 0, 0, u2.src(), cur, g, nxt, nullptr, false);
         cur = nxt.src();
     }
@@ -1040,6 +1068,7 @@ using namespace pds;
 extern "C" {
 
 int pds_abi_version(void) { return PDS_ABI_VERSION; }
+long long pds_nonfinite_statistics(int reset) { return nonfinite_statistics(reset); }
 const char* pds_last_error(void) { return g_error; }
 
 int pds_subpixel_map_fwd(const float* similarities, float* disparities, int batch, int planes, int height,
@@ -1204,15 +1233,21 @@ int pds_regularization_subpixel_map_fwd(const PdsRegularizationParams* params, c
 
 size_t pds_conv_block_workspace_bytes(int n, int cin, int cout, int d, int h, int w, int kd, int stride,
                                       int per_plane) {
-    Ctx c{nullptr, 0, true, nullptr};
     PdsConvBlockParams dummy{nullptr, nullptr, (const float*)1, (const float*)1};
     // sized for the chained form (input behind a deferred InstanceNorm): it may pick a kernel with more statistics
-    // records per plane than the plain form, never fewer
-    Src src = plain_src(nullptr);
-    src.normed = 1;
-    conv_block(c, src, no_src(), Geom{n, cin, d, h, w}, dummy, cout, kd, stride, per_plane, (float*)1, true, (float*)1,
-               (float*)1);
-    return c.off + 256;
+    // records per plane than the plain form, never fewer; with and without a range bound (the kernel choice -- and with
+    // it the packed-weight scratch -- depends on it): the larger of the two
+    size_t need = 0;
+    for (int bounded = 0; bounded < 2; ++bounded) {
+        Ctx c{nullptr, 0, true, nullptr};
+        Src src = plain_src(nullptr);
+        src.normed = 1;
+        src.bounded = bounded;
+        conv_block(c, src, no_src(), Geom{n, cin, d, h, w}, dummy, cout, kd, stride, per_plane, (float*)1, true,
+                   (float*)1, (float*)1);
+        if (c.off > need) need = c.off;
+    }
+    return need + 256;
 }
 
 int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* raw, float* scale, float* shift,
@@ -1234,11 +1269,12 @@ int pds_conv_block_fwd(const PdsConvBlockParams* params, const float* x, float* 
 
 // The same block behind another block: x is the producer's RAW output and the loader applies the producer's folded
 // InstanceNorm, x^ = x_scale * x + x_shift (per (n, c), or per (n, c, d) when x_per_plane) -- how the blocks of
-// MatchingOperation / Regularization are chained inside the modules (no normalised tensor is ever stored).
+// MatchingOperation / Regularization are chained inside the modules (no normalised tensor is ever stored).  x_bound
+// (one device float bounding |x^|, or null) is the range certificate of common.hpp Src::bound.
 int pds_conv_block_chained_fwd(const PdsConvBlockParams* params, const float* x, const float* x_scale,
-                               const float* x_shift, int x_per_plane, float* raw, float* scale, float* shift, int n,
-                               int cin, int cout, int d, int h, int w, int kd, int stride, int per_plane,
-                               void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+                               const float* x_shift, int x_per_plane, const float* x_bound, float* raw, float* scale,
+                               float* shift, int n, int cin, int cout, int d, int h, int w, int kd, int stride,
+                               int per_plane, void* workspace, size_t workspace_bytes, pds_stream_t stream) {
     PDS_REQUIRE(params && x && x_scale && x_shift && raw && workspace, "conv_block_chained: null pointer");
     PDS_REQUIRE(params->weight && params->bias, "conv_block_chained: null weight/bias");
     PDS_REQUIRE(n > 0 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, "conv_block_chained: bad shape");
@@ -1250,6 +1286,11 @@ int pds_conv_block_chained_fwd(const PdsConvBlockParams* params, const float* x,
     Ctx c{(char*)workspace, 0, false, (hipStream_t)stream};
     Src src{x, x_scale, x_shift, x_per_plane ? 1 : 0, 0};
     src.normed = 1;
+    if (x_bound) {
+        src.bound = x_bound;
+        src.bound_n = 1;
+        src.bounded = 1;
+    }
     conv_block(c, src, no_src(), Geom{n, cin, d, h, w}, *params, cout, kd, stride, per_plane, raw, true, scale, shift);
     return c.err;
 }

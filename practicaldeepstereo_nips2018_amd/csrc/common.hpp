@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
@@ -17,17 +18,44 @@ constexpr double kInEps = 1e-5;      // torch InstanceNorm default eps
 // ---- error reporting across the C ABI ------------------------------------------------
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+long long nonfinite_statistics(int reset);   // conv_direct.hip: the host-mapped counter behind pds_nonfinite_statistics
 
-// Per-function attributes (hipFuncSetAttribute) are per DEVICE: a launcher keeps one bit per device in a
-// function-local static and applies the attribute the first time it runs on each device of the process.
-inline bool first_use_on_device(std::atomic<unsigned>& done) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned bit = 1u << (dev & 31);
-    if (done.load(std::memory_order_relaxed) & bit) return false;
-    done.fetch_or(bit);
-    return true;
-}
+// Per-function attributes (hipFuncSetAttribute) and per-device launch data are set up once per DEVICE of the process:
+//     static std::atomic<unsigned> done{0};          // one bit per device
+//     if (DeviceOnce once{done}) { ... set up ... }
+// The first caller on a device runs the body holding a mutex and publishes the bit (release) when the guard leaves
+// the if statement; a concurrent first caller (nn.DataParallel threads, a threaded server) waits on the mutex and
+// then sees the bit, so nobody launches before the set-up is complete.
+struct DeviceOnce {
+    std::atomic<unsigned>& done;
+    unsigned bit = 0;
+    bool first = false;
+    explicit DeviceOnce(std::atomic<unsigned>& d) : done(d) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bit = 1u << (dev & 31);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        mutex().lock();
+        if (done.load(std::memory_order_relaxed) & bit) {
+            mutex().unlock();
+            return;
+        }
+        first = true;
+    }
+    ~DeviceOnce() {
+        if (first) {
+            done.fetch_or(bit, std::memory_order_release);
+            mutex().unlock();
+        }
+    }
+    DeviceOnce(const DeviceOnce&) = delete;
+    DeviceOnce& operator=(const DeviceOnce&) = delete;
+    explicit operator bool() const { return first; }
+    static std::mutex& mutex() {
+        static std::mutex m;
+        return m;
+    }
+};
 
 #define PDS_REQUIRE(cond, ...)                       \
     do {                                             \
@@ -47,6 +75,14 @@ struct Src {
     int bcast_d;         // tensor has no D axis and is broadcast along it (regularization.py:115)
     int id = -1;         // host-side only: index of the tensor on the backward tape
     int normed = 0;      // host-side only: scale / shift are (or, in a planning walk with null pointers, will be) set
+    // Range certificate for the fp16-split kernels (conv2d_x3 P = 2, conv2d_t8): device floats whose maximum bounds
+    // |value as the consumer reads it| -- the NORMALISED value of a deferred InstanceNorm (written by in_finalize from
+    // gamma, beta and the group size: |gamma| sqrt(count) + |beta| is rigorous), the raw value of a plain tensor
+    // (per-workgroup maxima written by the kernel that produced it).  nullptr: nothing is known about the range and
+    // the consumer takes a range-safe form (three-way bf16 split / exact fp32).
+    const float* bound = nullptr;
+    int bound_n = 0;
+    int bounded = 0;     // host-side only: a bound goes with the tensor (true in planning walks too, where bound is null)
 };
 
 inline Src plain_src(const float* p) { return Src{p, nullptr, nullptr, 0, 0}; }
@@ -118,9 +154,6 @@ struct ConvLayer {
     float* side_out = nullptr;
     // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)
     int plane_weight_sets = 0;
-    // conv2d_x3 only: the (plain) input is known to be O(1) -- a residual sum of InstanceNorm'ed tensors -- so the
-    // fp16 split form applies (inputs behind a deferred InstanceNorm always qualify)
-    int unit_range = 0;
     PackSink* sink = nullptr;  // nullptr: pack inline
 };
 
@@ -146,9 +179,10 @@ int deconv_direct_tiles(const Geom& out_g);
 
 // partial sums -> (scale, shift).  groups = N*C*(per_plane ? D : 1); each group reduces
 // `per_group` consecutive partial records of (sum, sumsq); count = elements per group.
+// bound (may be null): one float, max over channels of |gamma| sqrt(count) + |beta| -- a rigorous bound of the normalised values
 int launch_in_finalize(const double* partials, int groups, int per_group, double count,
                        const float* gamma, const float* beta, int channels, int groups_per_channel_block,
-                       float* scale, float* shift, float* mean, float* rstd, hipStream_t s);
+                       float* scale, float* shift, float* mean, float* rstd, hipStream_t s, float* bound = nullptr);
 
 // ---- backward (backward.hip) ------------------------------------------------------------------------
 size_t in_bwd_scratch_doubles(const Geom& g);
@@ -187,11 +221,13 @@ int launch_grad_reduce_d(float* dst, const float* src, const Geom& g, int accumu
 int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int batch, int channels, int h, int w,
                             int d_begin, int d_count, hipStream_t s);
 
-// out = a (+ b), both deferred-normalised
-int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s);
-// out = norm(a) + (A + shift_d(G)): the first residual sum of the fused Matching path
+// out = a (+ b), both deferred-normalised; amax (may be null): materialize_records(g) floats, the maximum |out| of every workgroup
+int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s, float* amax = nullptr);
+int materialize_records(const Geom& g);
+// out = norm(a) + (A + shift_d(G)): the first residual sum of the fused Matching path; amax as above (materialize_l0_records)
 int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
-                          size_t l0_cstride, int l0_rs, int d_begin, float* out, hipStream_t s);
+                          size_t l0_cstride, int l0_rs, int d_begin, float* out, hipStream_t s, float* amax = nullptr);
+int materialize_l0_records(const Geom& g);
 
 int launch_subpixel_map(const float* sim, float* disp, int batch, int planes, int height, int width,
                         int taps_lo, int taps_hi, int step, hipStream_t s);
@@ -236,7 +272,9 @@ int launch_split_first_weights(const float* w0, const float* b0, float* wl, floa
 int image_stats_chunks(int h, int w);
 int launch_image_stats(const float* img, int nc, int h, int w, double* partials, hipStream_t s);
 // [N, C, H, W] (virtually zero-padded by top rows / left columns) -> [N, 4C, ceil((H+top)/2), ceil((W+left)/2)]
-int launch_space_to_depth(const Src& a, int n, int c, int h, int w, int top, int left, float* out, hipStream_t s);
+// bound_out (may be null): one float, the bound of `a` carried over (a re-layout changes no value; pad zeros are inside any bound)
+int launch_space_to_depth(const Src& a, int n, int c, int h, int w, int top, int left, float* out, hipStream_t s,
+                          float* bound_out = nullptr);
 int launch_depth_to_space(const float* g, int n, int c, int h, int w, float* out, hipStream_t s);
 // d image from the gradient of the space-to-depth tensor: depth-to-space + InstanceNorm2d (no affine) backward over the padded plane
 int launch_image_grad(const float* g, const float* img, const float* scale, const float* shift, int n, int c, int h,
@@ -260,11 +298,68 @@ int launch_sce_weights_bwd(const float* sim, const float* gt, const float* lse, 
                            const float* grad_loss, float* gweights, int n, int planes, int h, int w, float diversity,
                            int step, hipStream_t s);
 
+// ---- power-of-two operand scales of the fp16-split kernels -----------------------------------------
+// Largest power of two s with s * bound <= target (exact to apply and to undo); 1 when the bound is zero, negative
+// or not finite (the result is then as meaningless as the reference's own for such an input, but never a trap).
+__host__ __device__ inline float pow2_scale(float bound, float target) {
+    if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+    float f = target / bound;
+    f = f < 0x1p-60f ? 0x1p-60f : (f > 0x1p60f ? 0x1p60f : f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) & 0x7f800000u);
+#else
+    union { float f; unsigned u; } v;
+    v.f = f;
+    v.u &= 0x7f800000u;
+    return v.f;
+#endif
+}
+constexpr float kHalfTarget = 16384.f;   // scaled operands stay below 2^14 (fp16 overflows at 65 504)
+
 // ---- wave helpers ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+__device__ __forceinline__ float wave_max(float v) {   // every lane receives the maximum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// Maximum of one value per thread, for every thread of the workgroup (call it from ALL threads, before any divergence;
+// red = 16 floats of LDS; a NaN counts as +inf).
+__device__ __forceinline__ float block_max(float v, float* red) {
+    float mm = wave_max(v == v ? v : __builtin_inff());
+    const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = mm;
+    __syncthreads();
+    float r = 0.f;
+    for (int k = 0; k < waves; ++k) r = fmaxf(r, red[k]);
+    __syncthreads();
+    return r;
+}
+// Maximum of the n bound records of a source (Src::bound), same calling convention.
+__device__ __forceinline__ float block_bound(const float* __restrict__ b, int n, float* red) {
+    float mm = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = fabsf(b[i]);
+        mm = fmaxf(mm, v == v ? v : __builtin_inff());   // (fmaxf alone would drop a NaN record)
+    }
+    return block_max(mm, red);
+}
+// one record per workgroup of a producer: the maximum |v| its threads have seen (NaN / inf -> +inf)
+__device__ __forceinline__ void block_amax_record(float m, float* __restrict__ rec, float* red) {
+    float mm = (m == m) ? m : __builtin_inff();
+    mm = wave_max(mm);
+    const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = mm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        for (int k = 0; k < waves; ++k) r = fmaxf(r, red[k]);
+        *rec = r;
+    }
 }
 
 }  // namespace pds

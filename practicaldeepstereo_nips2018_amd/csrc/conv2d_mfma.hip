@@ -365,7 +365,7 @@ static int launch_cfg(const MfmaArgs& A, hipStream_t s) {
     using C = Cfg<MB, KCT>;
     const size_t lds_bytes = (size_t)(2 * C::BUF) * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<MB, SRC, PAIR, KCT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }

@@ -5,15 +5,17 @@
 //
 // Arithmetic (round 3).  The layer moves 850 MB for 15 GFLOP, but on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of
 // the 16-bit rate) its matrix work alone took 160 of the kernel's 295 us (rocprofv3: 10.6 M MFMAs, pipe busy 55 %).  As in
-// conv2d_x3.hip every fp32 operand is therefore split into two fp16 parts (weights x 2^10, exact) and a product is
+// conv2d_x3.hip every fp32 operand is therefore split into two fp16 parts and a product is
 // hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x16_f16 with fp32 accumulation -- measured more accurate than the fp32 fma
-// chain (tools/ubench/fp16x2_probe.hip); inputs must be O(1) (|x| < 65 504): sources behind an InstanceNorm or marked so
-// by the pipeline (ConvLayer::unit_range), anything else keeps the exact-fp32 kernel of conv2d_mfma.hip.
+// chain (tools/ubench/fp16x2_probe.hip).  Both operands are pre-scaled by exact powers of two derived from the data
+// (round 4): ws from max|w| (every workgroup reduces the 4 608 weights while it gathers them), as from the range
+// certificates of the sources (common.hpp Src::bound; the sum of the two when the residual sum is formed here), so any
+// finite input is in range; a source without a certificate keeps the exact-fp32 kernel of conv2d_mfma.hip.
 //
 // With 8 output channels an M = 16 tile would idle half of its rows; here (as in conv3d_t8.hip, along y instead of z)
 // the M side is (output channel, parity of the output row): one MFMA makes 8 channels x 2 consecutive rows y, y+1 for 16
 // pixels, and its K = 16 is FOUR input channels x the four input rows y-1 .. y+2 they touch:
-//     A[(oc, py)][(yi, ic)] = 2^10 W[oc][ic][dy = yi - py][dx]   (0 when dy is outside 0..2)
+//     A[(oc, py)][(yi, ic)] = ws W[oc][ic][dy = yi - py][dx]   (0 when dy is outside 0..2)
 //     B[(yi, ic)][n]        = in[ic][y - 1 + yi][x + n + dx - 1]
 // i.e. 9 MFMAs x 3 products per (4 channels x 8 channels x 2 rows x 16 pixels).
 //
@@ -28,7 +30,7 @@
 //               positions and all four channels of the chunk; chunk g + 4 is being loaded (buffer loads, zero padding
 //               from the range check), chunk g + 1 is normalised / summed / split / written in the shadow of the MFMAs
 //               of chunk g (sched_group_barrier interleave); one barrier per chunk, the stream runs on across tiles.
-//   epilogue    accumulators start at 2^10 bias; 2^-10, optional LeakyReLU; 64-byte row segments.
+//   epilogue    accumulators start at ws as bias; 1 / (ws as), optional LeakyReLU; 64-byte row segments.
 #include <atomic>
 #include <type_traits>
 
@@ -48,7 +50,6 @@ constexpr int C2_AFRAGS = C2_CHUNKS * 3 * 2;               // (chunk, dx, part):
 constexpr int C2_ABYTES = C2_AFRAGS * 64 * 8;
 constexpr int C2_NPOS = C2_YT * C2_XT;                     // halo positions of a tile: 612
 constexpr int C2_POS = (C2_NPOS + C2_THREADS - 1) / C2_THREADS;   // positions per thread: 3
-constexpr float C2_WSCALE = 1024.f;
 static_assert(C2_RS >= C2_XT, "LDS row");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -70,6 +71,46 @@ __device__ __forceinline__ void c2_split(const float (&v)[4], f16x4& hi, f16x4& 
         hi[i] = (_Float16)v[i];
         lo[i] = (_Float16)(v[i] - (float)hi[i]);
     }
+}
+
+// power-of-two operand scales of a launch (header comment), wave-uniform; called by ALL threads before anything else
+// touches the LDS scratch `red`
+struct C2Scales {
+    float ws, as, unscale;
+};
+__device__ __forceinline__ float c2_uniform(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ C2Scales c2_scales(const C2Args& A, bool two, float* red) {
+    // three maxima (weights, bound records of a, of b) in ONE pass: all loads go out together, one barrier pair
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < C2_COUT * C2_CIN * 9; i += blockDim.x) m[0] = fmaxf(m[0], fabsf(A.w[i]));
+    for (int i = threadIdx.x; i < A.a.bound_n; i += blockDim.x) {
+        const float v = fabsf(A.a.bound[i]);
+        m[1] = fmaxf(m[1], v == v ? v : __builtin_inff());
+    }
+    if (two)
+        for (int i = threadIdx.x; i < A.b.bound_n; i += blockDim.x) {
+            const float v = fabsf(A.b.bound[i]);
+            m[2] = fmaxf(m[2], v == v ? v : __builtin_inff());
+        }
+    const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m[k] = wave_max(m[k]);
+        if ((threadIdx.x & 63) == 0) red[wave * 3 + k] = m[k];
+    }
+    __syncthreads();
+    float r[3] = {0.f, 0.f, 0.f};
+    for (int w = 0; w < waves; ++w)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[k] = fmaxf(r[k], red[w * 3 + k]);
+    __syncthreads();
+    C2Scales S;
+    S.ws = c2_uniform(pow2_scale(r[0], kHalfTarget));
+    S.as = c2_uniform(pow2_scale(r[1] + r[2], kHalfTarget));
+    S.unscale = c2_uniform((1.f / S.ws) * (1.f / S.as));
+    return S;
 }
 
 }  // namespace
@@ -96,6 +137,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void conv2d_t8_kernel(const C2Args A
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         A.out, 0, (int)((size_t)A.N * C2_COUT * cstride * sizeof(float)), 0x00020000);
 
+    const C2Scales SC = c2_scales(A, TWO, reinterpret_cast<float*>(ibuf));
     // ---- A fragments -> LDS: lane (m = lane & 15 -> oc = m >> 1, py = m & 1 ; yi = lane >> 4), four channels each ----
     for (int e = tid; e < C2_CHUNKS * 3 * 64; e += C2_THREADS) {
         const int l = e & 63, f = e >> 6;                // f = chunk * 3 + dx
@@ -105,7 +147,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void conv2d_t8_kernel(const C2Args A
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             wv[i] = (dy >= 0 && dy <= 2)
-                        ? A.w[((size_t)oc * C2_CIN + chunk * C2_KC + i) * 9 + dy * 3 + dx] * C2_WSCALE
+                        ? A.w[((size_t)oc * C2_CIN + chunk * C2_KC + i) * 9 + dy * 3 + dx] * SC.ws
                         : 0.f;
         f16x4 hi, lo;
         c2_split(wv, hi, lo);
@@ -211,17 +253,24 @@ __global__ __launch_bounds__(C2_THREADS, 2) void conv2d_t8_kernel(const C2Args A
     };
     auto stash = [&](unsigned char* buf, auto set_c) {   // registers -> LDS: normalisation, the sum, the padding, the split
         constexpr int SET = decltype(set_c)::value;
+        // The activation scale rides in the folded coefficients, multiplied HERE: the coefficients are scalar loads
+        // issued by fetch() a chunk earlier; touching them there would wait for them on the spot (measured: +27 us per
+        // launch of the full-width kernel).
+        float cs[C2_KC], cs2[C2_KC], chs[C2_KC];
+#pragma unroll
+        for (int ch = 0; ch < C2_KC; ++ch) {
+            cs[ch] = NA ? vs[SET][ch] * SC.as : SC.as;
+            cs2[ch] = (TWO && NB2) ? vs2[SET][ch] * SC.as : SC.as;
+            chs[ch] = ((NA ? vh[SET][ch] : 0.f) + ((TWO && NB2) ? vh2[SET][ch] : 0.f)) * SC.as;
+        }
 #pragma unroll
         for (int k = 0; k < C2_POS; ++k) {
             float v[4];
 #pragma unroll
             for (int ch = 0; ch < C2_KC; ++ch) {
-                float t = NA ? vs[SET][ch] * va[SET][k][ch] : va[SET][k][ch];
-                if (TWO) t = NB2 ? fmaf(vs2[SET][ch], vb[SET][k][ch], t) : t + vb[SET][k][ch];
-                if (NA || (TWO && NB2)) {   // both shifts vanish in the padding
-                    const float hsum = (NA ? vh[SET][ch] : 0.f) + ((TWO && NB2) ? vh2[SET][ch] : 0.f);
-                    t = fmaf(hsum, inside_regs[SET][k], t);
-                }
+                float t = cs[ch] * va[SET][k][ch];
+                if (TWO) t = fmaf(cs2[ch], vb[SET][k][ch], t);
+                if (NA || (TWO && NB2)) t = fmaf(chs[ch], inside_regs[SET][k], t);   // both shifts vanish in the padding
                 v[ch] = t;
             }
             f16x4 hi, lo;
@@ -231,7 +280,8 @@ __global__ __launch_bounds__(C2_THREADS, 2) void conv2d_t8_kernel(const C2Args A
         }
     };
 
-    const float bias0 = (A.bias ? A.bias[2 * q] : 0.f) * C2_WSCALE, bias1 = (A.bias ? A.bias[2 * q + 1] : 0.f) * C2_WSCALE;
+    const float bscale = SC.ws * SC.as;
+    const float bias0 = (A.bias ? A.bias[2 * q] : 0.f) * bscale, bias1 = (A.bias ? A.bias[2 * q + 1] : 0.f) * bscale;
     const int b_base = ((2 * C2_RP * wave + q) * C2_RS + n16) * 8;     // halo row of the wave's first pair + yi, column n
     const unsigned out_lane = (unsigned)((size_t)(2 * q) * cstride + n16) * 4u;
     const unsigned out_c1 = (unsigned)cstride * 4u;
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void conv2d_t8_kernel(const C2Args A
                         out_base + (int)(((size_t)Pcur.d * A.H + min(y, A.H - 1)) * A.W + Pcur.x0) * (int)sizeof(float));
 #pragma unroll
                     for (int j = 0; j < C2_NB; ++j) {
-                        float t = acc[p][j][r] * (1.f / C2_WSCALE);
+                        float t = acc[p][j][r] * SC.unscale;
                         if (A.lrelu) t = fmaxf(t, t * kLeakySlope);
                         const bool ok = y < A.H && Pcur.x0 + 16 * j + n16 < A.W;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), ro,
@@ -385,6 +435,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         A.out, 0, (int)((size_t)A.N * C2_COUT * cstride * sizeof(float)), 0x00020000);
 
+    const C2Scales SC = c2_scales(A, TWO, reinterpret_cast<float*>(ibuf));
     // ---- A fragments -> LDS (as above); zero padding columns of the input buffers -------------------------------------
     for (int e = tid; e < C2_CHUNKS * 3 * 64; e += C2W_THREADS) {
         const int l = e & 63, f = e >> 6;
@@ -394,7 +445,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             wv[i] = (dy >= 0 && dy <= 2)
-                        ? A.w[((size_t)oc * C2_CIN + chunk * C2_KC + i) * 9 + dy * 3 + dx] * C2_WSCALE
+                        ? A.w[((size_t)oc * C2_CIN + chunk * C2_KC + i) * 9 + dy * 3 + dx] * SC.ws
                         : 0.f;
         f16x4 hi, lo;
         c2_split(wv, hi, lo);
@@ -483,6 +534,14 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     auto stash = [&](unsigned char* buf, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
+        // the activation scale rides in the folded coefficients, multiplied here and not where they are loaded (a scalar
+        // load touched in fetch() is waited for on the spot: +27 us per launch)
+        float cs[C2_KC], chs[C2_KC];
+#pragma unroll
+        for (int ch = 0; ch < C2_KC; ++ch) {
+            cs[ch] = vs[SET][ch] * SC.as;
+            chs[ch] = vh[SET][ch] * SC.as;
+        }
 #pragma unroll
         for (int k = 0; k < C2W_ITEMS; ++k)
 #pragma unroll
@@ -494,9 +553,9 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                     float v[4];
 #pragma unroll
                     for (int ch = 0; ch < C2_KC; ++ch) {
-                        float t = vs[SET][ch] * va[SET][k][ch][px];
-                        if (TWO) t += vb[SET][k][ch][px];
-                        v[ch] = fmaf(vh[SET][ch], inside_regs[SET][k], t);   // (the shift vanishes in the padding rows)
+                        float t = cs[ch] * va[SET][k][ch][px];
+                        if (TWO) t = fmaf(SC.as, vb[SET][k][ch][px], t);
+                        v[ch] = fmaf(chs[ch], inside_regs[SET][k], t);   // (the shift vanishes in the padding rows)
                     }
                     f16x4 hi, lo;
                     c2_split(v, hi, lo);
@@ -511,7 +570,8 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
             }
     };
 
-    const float bias0 = (A.bias ? A.bias[2 * q] : 0.f) * C2_WSCALE, bias1 = (A.bias ? A.bias[2 * q + 1] : 0.f) * C2_WSCALE;
+    const float bscale = SC.ws * SC.as;
+    const float bias0 = (A.bias ? A.bias[2 * q] : 0.f) * bscale, bias1 = (A.bias ? A.bias[2 * q + 1] : 0.f) * bscale;
     // halo row of the wave's pair + yi, slot of column (16 * first block + n) - 1 (+ dx), i.e. + 2 - 1
     const int b_base = ((2 * pair + q) * RSW + 16 * half * NBH + n16 + 1) * 8;
     const unsigned out_lane = (unsigned)((size_t)(2 * q) * cstride + 16 * half * NBH + n16) * 4u;
@@ -598,7 +658,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                     out_base + (int)(((size_t)Pcur.d * A.H + min(y, A.H - 1)) * A.W) * (int)sizeof(float));
 #pragma unroll
                 for (int j = 0; j < NBH; ++j) {
-                    float t = acc[j][r] * (1.f / C2_WSCALE);
+                    float t = acc[j][r] * SC.unscale;
                     if (A.lrelu) t = fmaxf(t, t * kLeakySlope);
                     const bool ok = y < A.H && 16 * (half * NBH + j) + n16 < A.W;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), ro,
@@ -629,7 +689,7 @@ template <bool TWO, bool NA, bool NB2>
 int launch_c2t8(const C2Args& A, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)C2_ABYTES + 2 * C2_BUF;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8_kernel<TWO, NA, NB2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
@@ -663,7 +723,7 @@ int launch_c2t8w(C2Args& A, hipStream_t s) {
     static int cus[32] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8w_kernel<TWO, NBH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         int n = 0;
@@ -681,9 +741,9 @@ bool conv2d_t8_supported(const ConvLayer& L) {
     if (!c2t8_enabled()) return false;
     if (L.kd != 1 || L.stride != 1 || L.in.c != C2_CIN || L.out_g.c != C2_COUT) return false;
     if (L.l0A || L.side_out || L.plane_weight_sets > 0) return false;   // (the caller checks that no statistics are wanted)
-    // the fp16-split arithmetic wants O(1) inputs: behind an InstanceNorm, or marked so by the pipeline
-    if (!(L.a.normed || L.a.scale || L.unit_range)) return false;
-    if (L.b.p && !(L.b.normed || L.b.scale || L.unit_range)) return false;
+    // the fp16-split arithmetic scales its operands by the sources' range certificates (Src::bound)
+    if (!L.a.bounded) return false;
+    if (L.b.p && !L.b.bounded) return false;
     if (L.b.p && L.b.bcast_d) return false;
     if ((size_t)L.in.n * C2_CIN * L.in.d * L.in.h * L.in.w >= ((size_t)1 << 29)) return false;   // 31-bit byte offsets
     const long tiles = (long)L.in.n * L.in.d * ((L.in.h + C2_TY - 1) / C2_TY) * ((L.in.w + C2_TX - 1) / C2_TX);
@@ -705,6 +765,8 @@ int launch_conv2d_t8(const ConvLayer& L, hipStream_t s) {
     A.tiles_x = (A.W + C2_TX - 1) / C2_TX;
     A.tiles_y = (A.H + C2_TY - 1) / C2_TY;
     A.tiles = A.N * A.D * A.tiles_y * A.tiles_x;
+    if (!A.a.bound || A.a.bound_n <= 0 || (L.b.p && (!A.b.bound || A.b.bound_n <= 0)))
+        return set_error(-1, "conv2d_t8: a source without a range bound");
     if (c2t8_wide(L)) {
         const int blocks = (A.W + 15) / 16, nbh = (blocks + 1) / 2;
         if (nbh <= 8) return L.b.p ? launch_c2t8w<true, 8>(A, s) : launch_c2t8w<false, 8>(A, s);

@@ -408,7 +408,7 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     A.bias_set_stride = L.plane_weight_sets > 0 ? L.out_g.c : 0;
     const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         const int bytes = (int)(160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -298,7 +298,7 @@ int launch_conv2d_wino16(const ConvLayer& L, size_t w_set_stride, int bias_set_s
     A.bias_set_stride = bias_set_stride;
     const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino16_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino16_kernel<false>),

@@ -7,15 +7,18 @@
 // product is the sum of the leading partial products, each an exact 16-bit x 16-bit product accumulated in fp32 by
 // v_mfma_f32_32x32x16_{f16,bf16}.  Two forms (template parameter P = parts per operand):
 //   P = 2, fp16 (round 3b)  a = a1 + a2 (2 x 11 significand bits; |a - a1 - a2| <= 2^-22 |a|),
-//       a*b ~= a1*b2 + a2*b1 + a1*b1: THREE products.  fp16 has a 5-bit exponent, so the operands are pre-scaled by exact
-//       powers of two (weights x 2^10 when they are packed, normalised activations x 2^4 inside their InstanceNorm
-//       coefficients; the epilogue multiplies the sums back) -- low parts then stay in or near the normal range and
-//       MFMA inputs keep their subnormals.  Measured on an MI355X (tools/ubench/fp16x2_probe.hip, K = 576 as in this
-//       layer): mean |error| 2.0e-7 against 3.1e-7 of the fp32 fmaf chain, 1 800 TFLOP/s of fp16 = 600 fp32-equivalent
-//       TFLOP/s (power-limited clock): 0.20 ms of bare MFMA time for this layer's 122.3 GFLOP at config 2.
-//       Pre-condition: |activation| < 4 094 behind an InstanceNorm (always true: a normalised value is bounded by the
-//       square root of the plane size), < 65 504 for a plain input -- beyond that the result is inf / NaN, never
-//       silently wrong.  Used when the input is InstanceNorm'ed or the pipeline marks it as O(1) (ConvLayer::unit_range).
+//       a*b ~= a1*b2 + a2*b1 + a1*b1: THREE products.  fp16 has a 5-bit exponent, so both operands are pre-scaled by
+//       exact powers of two that are DERIVED FROM THE DATA (round 4; rounds 3's constants 2^10 / 2^4 overflowed for
+//       |w| >= 64 or large gamma): weights by ws = the largest power of two with ws max|w| <= 2^14, found when they are
+//       packed (pack.hip mode 7); activations by as = the largest power of two with as * bound <= 2^14, where `bound` is
+//       the range certificate that travels with the source (common.hpp Src::bound: |gamma| sqrt(count) + |beta| behind
+//       an InstanceNorm, the producer's own per-workgroup maxima for a plain tensor); the epilogue multiplies the sums
+//       by 1 / (ws as).  Any finite operands are therefore in range, low parts stay in or near the normal range (the
+//       format has 30 binades for 22 bits, a bound may be loose by 2^8 at no cost) and MFMA inputs keep their
+//       subnormals.  A source WITHOUT a certificate (a caller's tensor of unknown scale) takes the bf16 form below.
+//       Measured on an MI355X (tools/ubench/fp16x2_probe.hip, K = 576 as in this layer): mean |error| 2.0e-7 against
+//       3.1e-7 of the fp32 fmaf chain, 1 800 TFLOP/s of fp16 = 600 fp32-equivalent TFLOP/s (power-limited clock):
+//       0.20 ms of bare MFMA time for this layer's 122.3 GFLOP at config 2.
 //   P = 3, bf16 (round 3a)  a = a1 + a2 + a3 exactly (3 x 8 bits), SIX products of order <= 2^-16 (dropped:
 //       a2*b3 + a3*b2 + a3*b3 <= 2^-23 |a*b|); bf16 has the fp32 exponent, so this form is range-safe: it takes inputs of
 //       unknown scale (data gradients, plain tensors of the generic entry point).  Mean |error| 2.4e-7; 320
@@ -81,10 +84,6 @@ struct X3Cfg {
     static constexpr int LDS_BYTES = LDS_EPI + (P == 2 ? 4 * EPI_WAVE : 0);
     static constexpr int W_ITERS = (W_STAGE / 16 + STAGERS - 1) / STAGERS;   // 16-byte pieces of a weight stage per thread
     static constexpr int PRODUCTS = P == 3 ? 6 : 3;
-    // power-of-two operand scales of the fp16 form (exact): weights when packed, normalised activations in the folded
-    // InstanceNorm coefficients; plain activations are taken as they are
-    static constexpr float W_SCALE = P == 2 ? 1024.f : 1.f;
-    static constexpr float A_SCALE_NORM = P == 2 ? 16.f : 1.f;
 };
 static_assert(X3Cfg<3>::LDS_BYTES <= 160 * 1024 && X3Cfg<2>::LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
@@ -112,6 +111,11 @@ struct X3Args {
     int planes;                               // N * D
     int nks;                                  // Cin / 16
     int epi_lds;                              // fp16 form: stores of interior tiles go through the LDS transposition
+    // fp16 form: the power-of-two operand scales (header comment).  ascale is computed by every workgroup from the
+    // source's range certificate, 1 / ws was left behind the tile-queue counters by the weight packing.
+    const float* __restrict__ bound;
+    int bound_n;
+    float ascale, unscale;                    // device side only: filled in by the kernel before the roles split
 };
 
 struct Tile {
@@ -256,6 +260,12 @@ __device__ __forceinline__ float x3_fma(float a, float b, float c) {
     return r;
 }
 
+__device__ __forceinline__ float x3_mul(float a, float b) {   // (same reason)
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ Tile decode_tile(const X3Args& A, int v) {
     Tile t;
     const int p = v / A.tiles;
@@ -358,9 +368,8 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
     float* obase = A.out + (((size_t)cur.n * A.CoutStride) * A.D + cur.d) * L.plane;   // uniform
     const float slope = A.lrelu ? kLeakySlope : 1.f;
     const f32x2 slope2 = {slope, slope};
-    // the fp16 form accumulates (2^10 w) * (2^4 x or x): one exact power of two back, in the same fma as the bias
-    constexpr float unscale = 1.f / (C::W_SCALE * (NORM ? C::A_SCALE_NORM : 1.f));
-    const f32x2 unscale2 = {unscale, unscale};
+    // the fp16 form accumulates (ws w) * (as x): one exact power of two back, in the same fma as the bias
+    const f32x2 unscale2 = {A.unscale, A.unscale};
     constexpr int MBLOCKS = NARROW ? 2 : 4;
     const bool interior = (A.W & 3) == 0 && cur.y0 + TH <= A.H && cur.x0 + (NARROW ? 16 : TW) <= A.W;   // uniform
 #define PDS_X3_EPILOGUE(MASKED)                                                                                       \
@@ -600,7 +609,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         constexpr unsigned pack_sel = P == 3 ? 0x07060302u : 0x05040100u;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            float r = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : x[c];
+            float r = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : (P == 2 ? x3_mul(x[c], A.ascale) : x[c]);
             r = inimg ? r : 0.f;
             if constexpr (P == 3) {
                 // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
@@ -679,8 +688,8 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     };
     auto write_coef = [&](float cs, float ch, int table) {
         if (NORM) {
-            coef_tab[table * 2 * CMAX + coef_c] = cs * C::A_SCALE_NORM;   // (exact power of two of the fp16 form)
-            coef_tab[table * 2 * CMAX + CMAX + coef_c] = ch * C::A_SCALE_NORM;
+            coef_tab[table * 2 * CMAX + coef_c] = cs * A.ascale;   // (exact power of two of the fp16 form; 1 for bf16)
+            coef_tab[table * 2 * CMAX + CMAX + coef_c] = ch * A.ascale;
         }
     };
     // one fp64 (sum, sum of squares) record per tile and channel from the four MFMA waves' rows
@@ -807,11 +816,24 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
 }  // namespace
 
 template <int P, bool NORM>
-__global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A) {
+__global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int* next_slot = reinterpret_cast<int*>(lds + X3Cfg<P>::LDS_NEXT);
+    X3Args A = A0;
+    A.ascale = 1.f;
+    A.unscale = 1.f;
+    if constexpr (P == 2) {
+        // operand scales of the fp16 form: the source's range certificate -> as; 1 / ws from the packed weights' tail
+        const float bound = block_bound(A.bound, A.bound_n, reinterpret_cast<float*>(lds + X3Cfg<P>::LDS_RED));
+        // (wave-uniform: kept in scalar registers, the MFMA waves have no vector registers to spare)
+        A.ascale = __builtin_bit_cast(
+            float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_scale(bound, kHalfTarget))));
+        A.unscale = __builtin_bit_cast(
+            float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+                       int, reinterpret_cast<const float*>(A.queue)[13] * (1.f / A.ascale))));
+    }
     if (tid == STAGERS)
         next_slot[0] = draw_tile(A.queue, blockIdx.x & 7, A.planes, A.tiles, A.tiles_x, A.tiles_x_full,
                                  A.tiles_y * A.tiles_x_full);
@@ -857,20 +879,20 @@ int conv2d_x3_tiles(const ConvLayer& L) {
 static size_t x3_weight_dwords(int cin, int parts) { return (size_t)(cin / 16) * 3 * (3 * parts * 2 * W_FRAG / 4); }
 size_t conv2d_x3_packed_floats(int cin) { return x3_weight_dwords(cin, 3) + 64; }
 
-// fp16 form (three products) when the input is O(1): behind an InstanceNorm, or marked so by the pipeline
+// fp16 form (three products) when the source carries a range certificate (Src::bound), else the range-safe bf16 form
 static bool x3_use_fp16(const ConvLayer& L) {
     static const bool enabled = []() {  // PDS_X3_FP16=0: every launch on the range-safe bf16 form (A/B, debugging)
         const char* e = getenv("PDS_X3_FP16");
         return !(e && e[0] == '0');
     }();
-    return enabled && (L.a.normed || L.a.scale != nullptr || L.unit_range);
+    return enabled && L.a.bounded;
 }
 
 template <int P>
 static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t s) {
     using C = X3Cfg<P>;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false>),
@@ -929,11 +951,14 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
         return !(e && e[0] == '0');
     }();
     A.epi_lds = epi_lds ? 1 : 0;
+    A.bound = L.a.bound;
+    A.bound_n = L.a.bound_n;
+    if (fp16 && (!A.bound || A.bound_n <= 0)) return set_error(-1, "conv2d_x3: fp16 form without a range bound");
     static std::atomic<unsigned> cus_done{0};   // one bit per device
     static int cus[32] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (first_use_on_device(cus_done)) {
+    if (DeviceOnce once{cus_done}) {
         int n = 0;
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         cus[dev & 31] = n > 0 ? n : 256;

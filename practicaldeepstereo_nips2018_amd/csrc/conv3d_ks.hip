@@ -328,7 +328,7 @@ int launch_ks(KsArgs A, int batch, hipStream_t s) {
     if (lds_bytes < 4096) lds_bytes = 4096;
     if (lds_bytes > 160 * 1024) return set_error(-1, "conv3d_ks: tile does not fit in LDS (%zu bytes)", lds_bytes);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }

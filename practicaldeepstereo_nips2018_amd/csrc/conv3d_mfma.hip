@@ -356,7 +356,7 @@ int launch3(const Args3& A0, hipStream_t s) {
     using C = Cfg3<S, MB, TZ, TY, NB, KC>;
     Args3 A = A0;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<MODE, S, MB, TZ, TY, NB, KC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }

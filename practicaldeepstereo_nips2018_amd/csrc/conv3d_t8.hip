@@ -376,7 +376,7 @@ int launch_t8(const T8Args& A, int batch, hipStream_t s) {
     using C = T8Cfg<NB>;
     constexpr size_t lds_bytes = (size_t)2 * C::LDS_FLOATS * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_t8_kernel<NB, SRC, EXACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }

@@ -384,8 +384,21 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
                                                           const float* __restrict__ beta, int channels,
                                                           int inner, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ mean_out,
-                                                          float* __restrict__ rstd_out) {
+                                                          float* __restrict__ rstd_out, float* __restrict__ bound_out,
+                                                          unsigned* __restrict__ nonfinite) {
     const int g = blockIdx.x;
+    // Range certificate of the normalised tensor (common.hpp, Src::bound): a group of `count` values with unit
+    // (biased) variance has no z-score beyond sqrt(count - 1), so |gamma| sqrt(count) + |beta| bounds every value.
+    if (bound_out && g == 0 && threadIdx.x < 64) {
+        float m = 0.f;
+        const float root = sqrtf((float)count);
+        for (int c = threadIdx.x; c < channels; c += 64) {
+            const float v = fabsf(gamma ? gamma[c] : 1.f) * root + fabsf(beta ? beta[c] : 0.f);
+            m = fmaxf(m, v == v ? v : __builtin_inff());
+        }
+        m = wave_max(m);
+        if (threadIdx.x == 0) *bound_out = m;
+    }
     const double* p = partials + (size_t)g * per_group * 2;
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < per_group; i += 256) {
@@ -406,6 +419,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
         q = red[0][1] + red[1][1] + red[2][1] + red[3][1];
         const double mean = s / count;
         double var = q / count - mean * mean;
+        // a NaN / inf reached this layer (or it overflowed): counted in host-mapped memory, pds_nonfinite_statistics()
+        if (nonfinite && !(fabs(mean) < 1.7e308 && fabs(var) < 1.7e308)) atomicAdd_system(nonfinite, 1u);
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + kInEps);
         const int c = (g / inner) % channels;
@@ -419,11 +434,52 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
     }
 }
 
+// ---- the non-finite statistics counter (include/pds_hip.h, ABI v5): one word of host-mapped memory ----------------
+namespace {
+std::atomic<unsigned*> g_nonfinite{nullptr};
+std::atomic<int> g_nonfinite_state{0};   // 0 not tried, 1 ready, -1 unavailable
+unsigned* nonfinite_counter(hipStream_t s) {
+    const int st = g_nonfinite_state.load(std::memory_order_acquire);
+    if (st == 1) return g_nonfinite.load(std::memory_order_relaxed);
+    if (st < 0) return nullptr;
+    // (an allocation is not allowed while a stream is being captured into a graph: the counter then waits for the
+    // next eager call)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (g_nonfinite_state.load(std::memory_order_acquire) == 1) return g_nonfinite.load(std::memory_order_relaxed);
+    unsigned* p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        g_nonfinite_state.store(-1, std::memory_order_release);
+        return nullptr;
+    }
+    *p = 0u;
+    g_nonfinite.store(p, std::memory_order_relaxed);
+    g_nonfinite_state.store(1, std::memory_order_release);
+    return p;
+}
+}  // namespace
+
+long long nonfinite_statistics(int reset) {
+    if (g_nonfinite_state.load(std::memory_order_acquire) != 1)
+        return g_nonfinite_state.load(std::memory_order_acquire) < 0 ? -1 : 0;
+    unsigned* p = g_nonfinite.load(std::memory_order_relaxed);
+    volatile unsigned* vp = p;
+    const unsigned v = *vp;
+    if (reset) __atomic_fetch_sub(p, v, __ATOMIC_RELAXED);   // (kernels still in flight keep adding)
+    return (long long)v;
+}
+
 int launch_in_finalize(const double* partials, int groups, int per_group, double count, const float* gamma,
                        const float* beta, int channels, int inner, float* scale, float* shift, float* mean,
-                       float* rstd, hipStream_t s) {
+                       float* rstd, hipStream_t s, float* bound) {
     hipLaunchKernelGGL(in_finalize_kernel, dim3(groups), dim3(256), 0, s, partials, per_group, count, gamma,
-                       beta, channels, inner, scale, shift, mean, rstd);
+                       beta, channels, inner, scale, shift, mean, rstd, bound, nonfinite_counter(s));
     return check_launch("in_finalize");
 }
 
@@ -432,7 +488,9 @@ int launch_in_finalize(const double* partials, int groups, int per_group, double
 // ExpansionBlock3d / MatchingOperation outputs, residual sums)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void materialize_kernel(const Src a, const Src b, const Geom g,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float* __restrict__ amax) {
+    __shared__ float red[16];
+    float seen = 0.f;   // largest |out| of this thread (the range certificate of the plain result, Src::bound)
     const size_t vol = g.volume();
     const size_t plane = g.plane();
     const int nc = blockIdx.y;  // n*C + c
@@ -449,7 +507,9 @@ __global__ __launch_bounds__(256) void materialize_kernel(const Src a, const Src
             v += fmaf(sb, b.p[off], hb);
         }
         out[(size_t)nc * vol + i] = v;
+        seen = fmaxf(seen, fabsf(v) == fabsf(v) ? fabsf(v) : __builtin_inff());
     }
+    if (amax) block_amax_record(seen, amax + (size_t)blockIdx.y * gridDim.x + blockIdx.x, red);
 }
 
 // out[n,c,d,y,x] = norm(a) + x0,  x0 = A[n,c,y,x] + G[n,c,y,x-d] formed on the fly (misc.hip: l0_combine_kernel)
@@ -457,7 +517,10 @@ __global__ __launch_bounds__(256) void materialize_kernel(const Src a, const Src
 __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const Geom g, const float* __restrict__ A,
                                                              const float* __restrict__ G,
                                                              const float* __restrict__ G2, size_t l0_cstride,
-                                                             int l0_rs, int d_begin, float* __restrict__ out) {
+                                                             int l0_rs, int d_begin, float* __restrict__ out,
+                                                             float* __restrict__ amax) {
+    __shared__ float red[16];
+    float seen = 0.f;
     // grid: x = tile over (y, x/4), y = d, z = n*C + c
     const int nc = blockIdx.z, d = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
@@ -496,6 +559,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
                 x0v += (x == g.w - 1 && disp >= 1) ? pG2[off] : pG[off];
             }
             r[k] = fmaf(sa, av[k], ha) + x0v;
+            if (x < g.w) seen = fmaxf(seen, fabsf(r[k]));
         }
         if (vec) {
             *reinterpret_cast<float4*>(po + i) = make_float4(r[0], r[1], r[2], r[3]);
@@ -505,6 +569,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
                 if (x0 + k < g.w) po[i + k] = r[k];
         }
     }
+    if (amax) block_amax_record(seen, amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
 }
 
 // Plane-sweeping form of the above for rows that are a multiple of 4 wide: one thread owns four consecutive x of
@@ -516,7 +581,10 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
 __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, const Geom g, const float* __restrict__ A,
                                                                    const float* __restrict__ G,
                                                                    const float* __restrict__ G2, size_t l0_cstride,
-                                                                   int l0_rs, int d_begin, float* __restrict__ out) {
+                                                                   int l0_rs, int d_begin, float* __restrict__ out,
+                                                                   float* __restrict__ amax) {
+    __shared__ float red[16];
+    float seen = 0.f;
     const int nc = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
     const size_t px = g.plane();
@@ -567,6 +635,7 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
             const float4 r = make_float4(fmaf(sa, t[j].x, ha) + (lv[0] + gw[0]), fmaf(sa, t[j].y, ha) + (lv[1] + gw[1]),
                                          fmaf(sa, t[j].z, ha) + (lv[2] + gw[2]), fmaf(sa, t[j].w, ha) + (lv[3] + g3));
             if (active) *reinterpret_cast<float4*>(po + (size_t)d * px) = r;
+            seen = fmaxf(fmaxf(seen, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
             // slide the window to disparity disp + 1
             const float from_left = __builtin_bit_cast(
                 float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw[3]), 0x138, 0xf, 0xf, true));
@@ -580,29 +649,49 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
             }
         }
     }
+    // (fmaxf drops NaNs: a NaN anywhere in the sum also shows in the statistics of the layers behind it)
+    if (amax) block_amax_record(seen, amax + (size_t)blockIdx.y * gridDim.x + blockIdx.x, red);
 }
 
-int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
-                          size_t l0_cstride, int l0_rs, int d_begin, float* out, hipStream_t s) {
-    if ((g.w & 3) == 0) {
-        const int quads = g.h * (g.w / 4);
-        hipLaunchKernelGGL(materialize_l0_sweep_kernel, dim3((quads + 255) / 256, g.n * g.c), dim3(256), 0, s, a, g, A, G,
-                           G2, l0_cstride, l0_rs, d_begin, out);
-        return check_launch("materialize_l0");
-    }
+static dim3 materialize_l0_grid(const Geom& g) {
+    if ((g.w & 3) == 0) return dim3((unsigned)((g.h * (g.w / 4) + 255) / 256), (unsigned)(g.n * g.c));
     const int quads = g.h * ((g.w + 3) / 4);
     unsigned bx = (unsigned)((quads + 255) / 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(materialize_l0_kernel, dim3(bx, g.d, g.n * g.c), dim3(256), 0, s, a, g, A, G, G2, l0_cstride,
-                       l0_rs, d_begin, out);
+    return dim3(bx, (unsigned)g.d, (unsigned)(g.n * g.c));
+}
+int materialize_l0_records(const Geom& g) {
+    const dim3 grid = materialize_l0_grid(g);
+    return (int)(grid.x * grid.y * grid.z);
+}
+
+int launch_materialize_l0(const Src& a, const Geom& g, const float* A, const float* G, const float* G2,
+                          size_t l0_cstride, int l0_rs, int d_begin, float* out, hipStream_t s, float* amax) {
+    const dim3 grid = materialize_l0_grid(g);
+    if ((g.w & 3) == 0)
+        hipLaunchKernelGGL(materialize_l0_sweep_kernel, grid, dim3(256), 0, s, a, g, A, G, G2, l0_cstride, l0_rs, d_begin,
+                           out, amax);
+    else
+        hipLaunchKernelGGL(materialize_l0_kernel, grid, dim3(256), 0, s, a, g, A, G, G2, l0_cstride, l0_rs, d_begin, out,
+                           amax);
     return check_launch("materialize_l0");
 }
 
-int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s) {
+// workgroups along a channel volume: enough to fill the chip, few enough that the amax records (one per workgroup)
+// stay a few thousand floats for the consumer to reduce
+static int materialize_bx(const Geom& g) {
     const size_t vol = g.volume();
     int bx = (int)((vol + 255) / 256);
-    if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(materialize_kernel, dim3(bx, g.n * g.c), dim3(256), 0, s, a, b, g, out);
+    const int nc = g.n * g.c;
+    int cap = 8192 / (nc > 0 ? nc : 1);
+    if (cap < 1) cap = 1;
+    if (cap > 4096) cap = 4096;
+    return bx < cap ? bx : cap;
+}
+int materialize_records(const Geom& g) { return materialize_bx(g) * g.n * g.c; }
+
+int launch_materialize(const Src& a, const Src& b, const Geom& g, float* out, hipStream_t s, float* amax) {
+    hipLaunchKernelGGL(materialize_kernel, dim3(materialize_bx(g), g.n * g.c), dim3(256), 0, s, a, b, g, out, amax);
     return check_launch("materialize");
 }
 

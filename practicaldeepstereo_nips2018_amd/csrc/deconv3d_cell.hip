@@ -365,7 +365,7 @@ int launch_cell(const CellArgs& A, int batch, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)2 * C::LDS_FLOATS * sizeof(float);
     static_assert(lds_bytes >= (size_t)DC_THREADS * 8 * sizeof(double), "reduction scratch must fit");
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }

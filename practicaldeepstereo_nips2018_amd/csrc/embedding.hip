@@ -49,9 +49,16 @@ __global__ __launch_bounds__(256) void image_stats_kernel(const float* __restric
 // out: [N, 4C, h2, w2], channel (a*2 + b)*C + c holds pixel (2i + a, 2j + b) of the padded image; positions past
 // the padded image are literal zeros (the convolution's own padding).
 __global__ __launch_bounds__(256) void space_to_depth_kernel(const Src a, int C, int H, int W, int top, int left,
-                                                             int h2, int w2, float* __restrict__ out) {
+                                                             int h2, int w2, float* __restrict__ out,
+                                                             float* __restrict__ bound_out) {
     const int nc = blockIdx.y;
     const int n = nc / C, c = nc % C;
+    // the range certificate travels with the values (Src::bound): a re-layout changes none of them
+    if (bound_out && blockIdx.x == 0 && nc == 0 && threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < a.bound_n; ++i) m = fmaxf(m, a.bound[i] == a.bound[i] ? fabsf(a.bound[i]) : __builtin_inff());
+        *bound_out = m;
+    }
     float sc = 1.f, sh = 0.f;
     if (a.scale) {
         sc = a.scale[nc];
@@ -175,12 +182,14 @@ int launch_image_stats(const float* img, int nc, int h, int w, double* partials,
     return check_launch("image_stats");
 }
 
-int launch_space_to_depth(const Src& a, int n, int c, int h, int w, int top, int left, float* out, hipStream_t s) {
+int launch_space_to_depth(const Src& a, int n, int c, int h, int w, int top, int left, float* out, hipStream_t s,
+                          float* bound_out) {
+    if (bound_out && !a.bound) return set_error(-1, "space_to_depth: the source carries no range bound to pass on");
     const int h2 = (h + top + 1) / 2, w2 = (w + left + 1) / 2;
     size_t bx = ((size_t)h2 * w2 + 255) / 256;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(space_to_depth_kernel, dim3((unsigned)bx, n * c), dim3(256), 0, s, a, c, h, w, top, left, h2, w2,
-                       out);
+                       out, bound_out);
     return check_launch("space_to_depth");
 }
 

@@ -11,8 +11,11 @@
 //   x3     (mode 6): conv 3x3 weights split three ways into bf16 (round-to-nearest: w = w1 + w2 + w3 exactly) in the
 //           A-fragment order of v_mfma_f32_32x32x16_bf16, for conv2d_x3.hip:
 //           [k-step of 16 channels][dy][dx][part][32-channel block][lane][8 bf16]; `total` counts dwords (2 bf16).
-//   x3 fp16 (mode 7): the same order with TWO fp16 parts of 2^10 w (round-to-nearest; 2^10 keeps the low part of
-//           |w| > 1e-4 out of the subnormal range, |w| < 64 in range), for v_mfma_f32_32x32x16_f16.
+//   x3 fp16 (mode 7): the same order with TWO fp16 parts of ws * w (round-to-nearest), for v_mfma_f32_32x32x16_f16.
+//           ws is the largest power of two with ws * max|w| <= 2^14, derived from the layer's own weights by a
+//           one-workgroup-per-job launch ahead of the packing (pack_wscale_kernel: at packing time only), so any
+//           finite weights are in range and the low parts of all but vanishing weights stay normal; ws and 1 / ws sit
+//           behind the tile-queue counters (dwords 12 and 13 of the 16-dword tail) for the kernel's epilogue.
 #include "common.hpp"
 
 namespace pds {
@@ -63,13 +66,15 @@ __device__ __forceinline__ unsigned bf16_split_part(float v, int part) {
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const PackJob J = T.j[blockIdx.y];
     const int ks_n = J.kc / 4;
+    // mode 7: the weight scale of the job, left in the tail by pack_wscale_kernel (launched ahead of this kernel)
+    const float wscale = J.mode == 7 ? J.dst[J.total - 16 + 12] : 1.f;
     const int ncls = J.mode == 1 ? 8 : (J.mode == 2 ? 4 : 1);  // modes 0 and 3: plain convolutions
     const int kdn = J.mode == 1 ? 4 : 3;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
         if (J.mode == 6 || J.mode == 7) {
             if (e >= J.total - 16) {   // the tile-queue counters of conv2d_x3 sit behind its weights: zeroed with them
-                reinterpret_cast<unsigned*>(J.dst)[e] = 0u;
+                if (J.mode == 6 || e < J.total - 16 + 12) reinterpret_cast<unsigned*>(J.dst)[e] = 0u;   // (12, 13: ws, 1 / ws)
                 continue;
             }
             const int nparts = J.mode == 6 ? 3 : 2;
@@ -89,11 +94,11 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
             unsigned lo = 0, hi = 0;
             if (oc < J.cout && ic < J.cin) {
                 const float v = J.src[((size_t)oc * J.cin + ic) * 9 + dy * 3 + dx];
-                lo = J.mode == 6 ? bf16_split_part(v, part) : fp16_split_part(v * 1024.f, part);
+                lo = J.mode == 6 ? bf16_split_part(v, part) : fp16_split_part(v * wscale, part);
             }
             if (oc < J.cout && ic + 1 < J.cin) {
                 const float v = J.src[((size_t)oc * J.cin + ic + 1) * 9 + dy * 3 + dx];
-                hi = J.mode == 6 ? bf16_split_part(v, part) : fp16_split_part(v * 1024.f, part);
+                hi = J.mode == 6 ? bf16_split_part(v, part) : fp16_split_part(v * wscale, part);
             }
             reinterpret_cast<unsigned*>(J.dst)[e] = lo | (hi << 16);
             continue;
@@ -155,6 +160,31 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     }
 }
 
+// ws and 1 / ws of every mode-7 job of the table (one workgroup per job; the others leave at once)
+__global__ __launch_bounds__(1024) void pack_wscale_kernel(const PackTable T) {
+    const PackJob J = T.j[blockIdx.x];
+    if (J.mode != 7) return;
+    __shared__ float red[16];
+    float m = 0.f;
+    const int nw = J.cout * J.cin * 9;
+    // (a tensor from PyTorch's allocator is 16-byte aligned; the tail covers counts that are not a multiple of 4)
+    const float4* src4 = reinterpret_cast<const float4*>(J.src);
+    const bool vec = (reinterpret_cast<uintptr_t>(J.src) & 15) == 0;
+    const int n4 = vec ? nw / 4 : 0;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = src4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < nw; i += 1024) m = fmaxf(m, fabsf(J.src[i]));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) {
+        const float ws = pow2_scale(m, kHalfTarget);
+        J.dst[J.total - 16 + 12] = ws;
+        J.dst[J.total - 16 + 13] = 1.f / ws;
+    }
+}
+
 int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s) {
     for (int first = 0; first < count; first += kMaxJobs) {
         PackTable T;
@@ -168,6 +198,12 @@ int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s) {
         int bx = (biggest + 255) / 256;
         if (bx > 128) bx = 128;
         if (bx < 1) bx = 1;
+        bool any_fp16 = false;
+        for (int i = 0; i < n; ++i) any_fp16 |= T.j[i].mode == 7;
+        if (any_fp16) {
+            hipLaunchKernelGGL(pack_wscale_kernel, dim3(n), dim3(1024), 0, s, T);
+            if (int rc = check_launch("pack_wscale")) return rc;
+        }
         hipLaunchKernelGGL(multi_pack_kernel, dim3(bx, n), dim3(256), 0, s, T);
         if (int rc = check_launch("multi_pack")) return rc;
     }

@@ -427,7 +427,7 @@ int launch_wgrad3d_s2_mfma(int transposed, const Src& a, const Src& b, const flo
     const int wgs = wgrad3d_s2_workgroups(small, pairs);
     const int taps = transposed ? 64 : 27;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
-    if (first_use_on_device(attr_done)) {
+    if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<3, false>),

@@ -17,13 +17,14 @@ n, c, d, h, w = 1, 64, 48, 144, 240
 x = torch.randn(n, c, d, h, w, device=dev) * 1.7 + 0.3
 chained = os.environ.get('PDS_BENCH_PLAIN', '0') == '0'   # the hot path's form: input behind a deferred InstanceNorm
 xs = torch.full((n * c * d,), 1.0 / 1.7, device=dev); xh = torch.full((n * c * d,), -0.3 / 1.7, device=dev)
+xb = (x.abs().max() / 1.7 + 0.3 / 1.7).reshape(1).contiguous()   # ABI v5 range certificate of the normalised input
 raw = torch.empty_like(x)
 scale = torch.empty(n * c * d, device=dev); shift = torch.empty(n * c * d, device=dev)
 ws = torch.empty(lib.pds_conv_block_workspace_bytes(n, c, c, d, h, w, 1, 1, 1), dtype=torch.uint8, device=dev)
 st = _lib.stream_handle(dev)
 def launch():
     if chained:
-        _lib.check(lib.pds_conv_block_chained_fwd(ctypes.byref(params), _lib.ptr(x), _lib.ptr(xs), _lib.ptr(xh), 1, _lib.ptr(raw),
+        _lib.check(lib.pds_conv_block_chained_fwd(ctypes.byref(params), _lib.ptr(x), _lib.ptr(xs), _lib.ptr(xh), 1, _lib.ptr(xb), _lib.ptr(raw),
                                                   _lib.ptr(scale), _lib.ptr(shift), n, c, c, d, h, w, 1, 1, 1, _lib.ptr(ws),
                                                   ws.numel(), st), 'conv_block_chained')
         return
