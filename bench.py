@@ -48,7 +48,8 @@ if ROOT not in sys.path:
 
 import practicaldeepstereo_nips2018_amd as pds  # noqa: E402
 from practicaldeepstereo_nips2018_amd import _lib  # noqa: E402
-from practicaldeepstereo_nips2018_amd.distributed import PairStreams, ShardedHotPath, ShardedMatching  # noqa: E402
+from practicaldeepstereo_nips2018_amd.distributed import (PairStreams, ShardedHotPath, ShardedMatching,  # noqa: E402
+                                                          gather_description)
 
 HEIGHT, WIDTH, MAX_DISPARITY = 540, 960, 191
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
@@ -58,21 +59,44 @@ CONV64_GFLOP = 2.0 * 48 * 144 * 240 * 64 * 64 * 9 / 1e9
 # HBM bytes per launch of that kernel come from the PMC record committed with the round's profiles (rocprofv3 must
 # wrap the process to collect counters, so this script cannot re-collect them): tools/collect_profiles.sh writes the
 # counters, profiles/r03_conv64_pmc.json holds FETCH_SIZE / WRITE_SIZE of this kernel and the guide's gfx950 correction
-CONV64_PMC_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_conv64_pmc.json')
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CONV64_SOURCE = os.path.join(ROOT, 'practicaldeepstereo_nips2018_amd', 'csrc', 'conv2d_x3.hip')
+
+
+def conv64_pmc_record():
+    """The newest committed counter record of the dominant kernel (profiles/rNN_conv64_pmc.json)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_conv64_pmc.json')))
+    return found[-1] if found else os.path.join(ROOT, 'profiles', 'r04_conv64_pmc.json')
+
+
+def source_sha256(path):
+    import hashlib
+    try:
+        with open(path, 'rb') as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
 
 
 def conv64_hbm_traffic():
-    """(bytes per launch, description) from the committed PMC record, or (None, reason) when it is absent."""
+    """(bytes per launch, description, stale) from the committed PMC record, or (None, reason, None) when it is absent.
+    `stale`: the record carries the sha256 of the kernel source it was measured on (tools/install_profiles.py); when the
+    source has changed since, the figure describes an older kernel and the line says so."""
+    path = conv64_pmc_record()
     try:
-        with open(CONV64_PMC_RECORD) as f:
+        with open(path) as f:
             rec = json.load(f)
     except (OSError, ValueError) as e:
-        return None, 'no PMC record: %s' % e
+        return None, 'no PMC record: %s' % e, None
     nbytes = (rec['FETCH_SIZE_KB'] * rec['fetch_correction'] + rec['WRITE_SIZE_KB']) * 1e3
+    recorded = rec.get('kernel_source_sha256')
+    stale = (recorded != source_sha256(CONV64_SOURCE)) if recorded else True
+    name = os.path.basename(path)
     return nbytes, ('rocprofv3 FETCH_SIZE %.1f MB x %g (gfx950 wide-read correction) + WRITE_SIZE %.1f MB, separate '
-                    '--pmc passes, profiles/r03_conv64_pmc.json <- profiles/r03_conv64_pmc.txt (algorithmic %.1f MB)'
-                    % (rec['FETCH_SIZE_KB'] / 1e3, rec['fetch_correction'], rec['WRITE_SIZE_KB'] / 1e3,
-                       rec['algorithmic_bytes'] / 1e6))
+                    '--pmc passes, profiles/%s <- profiles/%s (algorithmic %.1f MB)'
+                    % (rec['FETCH_SIZE_KB'] / 1e3, rec['fetch_correction'], rec['WRITE_SIZE_KB'] / 1e3, name,
+                       name.replace('conv64_pmc.json', 'pmc_all_kernels.txt'), rec['algorithmic_bytes'] / 1e6)), stale
 
 
 # Round 3: the layer runs on the 16-bit matrix pipe (csrc/conv2d_x3.hip): every fp32 operand is split into two fp16
@@ -118,6 +142,14 @@ def parse():
                     help='functional test only: every rank uses cuda:0 (needs --backend gloo)')
     return ap.parse_args()
 
+
+ARITHMETIC = (
+    ('fp32 storage and fp32 accumulation everywhere; the 64-channel 3x3 convolutions (3 of 6 layers of MatchingOperation, '
+     'the 64->8 layer, the 64-channel layers of the embedding) multiply on the 16-bit matrix pipe: every fp32 operand is '
+     'split into %s scaled by a power of two derived from the data, %d exact partial products per multiply accumulated in '
+     'fp32 (22 of 24 significand bits per operand; measured mean error below the fp32 fmaf chain\'s); all other layers '
+     'are exact fp32 MFMA / VALU fma' % (('two fp16 parts', 3) if X3_PRODUCTS == 3.0 else ('three bf16 parts', 6)))
+    if X3 else 'IEEE fp32 multiplies and fp32 accumulation everywhere (exact-fp32 MFMA, Winograd F(2,3) in fp32)')
 
 PAIRS = 4   # distinct stereo pairs the timed steps rotate through
 
@@ -183,16 +215,48 @@ def time_dominant_kernel(net, device, reps):
     # in the hot path.  Timed back to back with nothing in between, consecutive launches of this power-limited kernel
     # run at lower clocks than inside the path (0.47-0.51 ms against the 0.36-0.38 ms rocprofv3 reports there).
     spacer = torch.empty_like(raw)
-    events = []
-    for _ in range(reps):
-        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        launch()
-        stop.record()
-        torch.add(raw, 1.0, out=spacer)
-        events.append((start, stop))
+
+    def timed(spaced):
+        events = []
+        for _ in range(reps):
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            launch()
+            stop.record()
+            if spaced:
+                torch.add(raw, 1.0, out=spacer)
+            events.append((start, stop))
+        torch.cuda.synchronize(device)
+        return sum(a.elapsed_time(b) for a, b in events) / reps
+    return {'spaced_ms': timed(True), 'back_to_back_ms': timed(False)}
+
+
+def time_dominant_kernel_in_situ(run_pair, device, pairs):
+    """Durations (ms) of the 48-plane conv2d_x3 launches INSIDE sequential pairs of the hot path: the library's launch
+    probe (ABI v5, pds_probe_begin / pds_probe_end) puts a HIP event pair on the launch stream around every launch of
+    the kernel while `run_pair(i)` enqueues whole pairs -- the kernel the path runs, with the cache state and clocks it
+    finds there, not a micro-benchmark.  Returns None when no such launch was seen (PDS_X3=0)."""
+    lib = _lib.load()
+    full = 48 * 9 * 8   # planes x 16 x 32-pixel tiles of a 144 x 240 plane
+    for i in range(2):
+        run_pair(i)
     torch.cuda.synchronize(device)
-    return sum(a.elapsed_time(b) for a, b in events) / reps
+    capacity = min(256, 4 * pairs)
+    _lib.check(lib.pds_probe_begin(b'conv2d_x3<fp16>' if X3_PRODUCTS == 3.0 else b'conv2d_x3<bf16>', capacity), 'pds_probe_begin')
+    for i in range(pairs):
+        run_pair(i)
+    ms = (ctypes.c_float * capacity)()
+    wgs = (ctypes.c_int * capacity)()
+    n = lib.pds_probe_end(ms, wgs, capacity)
+    torch.cuda.synchronize(device)
+    if n < 0:
+        _lib.check(n, 'pds_probe_end')
+    times = [ms[i] for i in range(n) if wgs[i] == full]
+    if not times:
+        return None
+    times.sort()
+    return {'launch_ms': sum(times) / len(times), 'min_ms': times[0], 'median_ms': times[len(times) // 2],
+            'max_ms': times[-1], 'launches': len(times), 'pairs': pairs}
 
 
 def cpu_baseline(net, ld, rd, shortcut, gpu_disparity, gpu_signatures=None, gpu_cost=None):
@@ -284,7 +348,7 @@ def gpu_baseline(net, ld, rd, shortcut, device, gpu_disparity):
             'disparity_mae_vs_hip_path': float(delta.mean())}
 
 
-def train_main(args, world, rank, device):
+def train_main(args, world, rank, device, collectives=None):
     """--train: the config-5 line (same timing contract: W warm-up steps, then exactly K steps between barriers and
     synchronisations, MAX over ranks; rank 0 prints one JSON line)."""
     from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
@@ -329,7 +393,8 @@ def train_main(args, world, rank, device):
                                    'random-init weights seed 0, ground truth with an unknown band',
                        'parallelism': ('DistributedDataParallel x%d, gradient all-reduce over %s' %
                                        (world, 'RCCL' if args.backend == 'nccl' else args.backend))
-                       if world > 1 else 'single GPU'},
+                       if world > 1 else 'single GPU',
+                       'collectives': collectives},
             'forward_ms': (t1 - t0) * 1e3, 'loss_backward_ms': (t2 - t1) * 1e3,
             'first_loss': values[0], 'last_loss': values[-1], 'replicas_in_sync': in_sync,
             'peak_memory_gb': torch.cuda.max_memory_allocated(device) / 2 ** 30}))
@@ -380,8 +445,21 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    collectives = None
+    if world > 1:
+        # the first multi-GPU run is also the first RCCL run of this code: check the collectives on tiny tensors against
+        # locally computed expectations BEFORE the timed region and say which form of the gather is in use
+        from practicaldeepstereo_nips2018_amd.distributed import preflight_collectives
+        try:
+            collectives = preflight_collectives(device=device)
+        except Exception as e:   # fail loudly, with a line the driver can parse, instead of hanging in the timed region
+            if rank == 0:
+                print(json.dumps({'metric': 'stereo pairs/sec, 960x540 D=192, Matching+Regularization+SubpixelMap hot path',
+                                  'value': None, 'n_gpus': world, 'error': 'collective pre-flight failed: %s: %s'
+                                                                           % (type(e).__name__, e)}))
+            raise SystemExit(3)
     if args.train:
-        return train_main(args, world, rank, device)
+        return train_main(args, world, rank, device, collectives)
     net, descriptors, images = make_inputs(device)
     ld_g, rd_g, sc_g = descriptors[0]
     regularization, estimator = net._regularization, net._estimator
@@ -557,14 +635,17 @@ def main():
             'scaling': 'strong' if world > 1 else 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
+            # dtype names the type of every tensor and accumulator; the MULTIPLIES of the 64-channel layers are not IEEE
+            # fp32 multiplies:
+            'arithmetic': ARITHMETIC,
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: 960x540 pair padded to 576x960, D=192 (48 matching planes, 96 cost '
                                    'planes), batch 1, eval mode, random-init weights seed 0',
                        'parallelism': ('disparity-axis shard x%d + one all-gather (%s) per pair; Regularization + '
                                        'estimator of pair i on rank i %% %d; pairs dealt to %d streams per rank' %
-                                       (world, 'RCCL' if args.backend == 'nccl' else args.backend, world,
-                                        args.sharded_streams))
+                                       (world, gather_description(), world, args.sharded_streams))
                        if world > 1 else 'single GPU',
+                       'collectives': collectives,
                        'launch': 'hip graph replay' if use_graph else
                                  ('eager, whole pairs round-robin over %d HIP streams (ms_per_frame is the un-overlapped '
                                   'latency of one pair)' % args.streams
@@ -608,9 +689,17 @@ def main():
             line['time_per_image'].pop('mean_absolute_error', None)   # random ground truth: only the protocol counts
             line['time_per_image'].pop('three_pixels_error', None)
         with torch.no_grad():
-            kernel_ms = time_dominant_kernel(net, device, args.kernel_reps)
+            isolated = time_dominant_kernel(net, device, args.kernel_reps)
+            in_situ = None
+            if world == 1 and X3:
+                def run_pair(i):
+                    ld, rd, sc = descriptors[i % PAIRS]
+                    return tail(net._matching(ld, rd), sc)
+                in_situ = time_dominant_kernel_in_situ(run_pair, device, max(4, args.kernel_reps))
+        # launch_ms: the kernel INSIDE the path (launch probe); the micro-benchmark figures ride along
+        kernel_ms = in_situ['launch_ms'] if in_situ else isolated['spaced_ms']
         executed = CONV64_EXECUTED_GFLOP / kernel_ms  # GFLOP / ms == TFLOP/s
-        traffic, traffic_source = conv64_hbm_traffic()
+        traffic, traffic_source, traffic_stale = conv64_hbm_traffic()
         # "achieved" / "frac" are the EXECUTED matrix flops against the peak of the pipe that executes them (SURVEY.md 8d:
         # F_executed / (t * peak)); the algorithmic figures of the direct fp32 convolution are carried beside them
         line['roofline'] = {
@@ -620,7 +709,15 @@ def main():
             'frac': executed / CONV64_EXECUTED_PEAK,
             'frac_of_sustained_mfma_stream': (executed / 1800.0) if X3 else None,   # bare MFMA stream at the power limit
             'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_source': traffic_source,
-            'launch_ms': kernel_ms, 'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
+            'traffic_stale': traffic_stale,
+            'launch_ms': kernel_ms,
+            'launch_ms_source': ('in situ: HIP event pairs on the launch stream around the 48-plane launches of %d sequential '
+                                 'pairs of the hot path (launch probe, include/pds_hip.h ABI v5)' % in_situ['pairs'])
+                                if in_situ else 'isolated launches (no in-situ record: multi-GPU run or PDS_X3=0)',
+            'in_situ': in_situ,
+            'isolated': dict(isolated, note='pds_conv_block_chained_fwd timed alone (weight packing and in_finalize inside '
+                                            'the bracket): with a memory-bound pass between launches / back to back'),
+            'executed_gflop_per_launch': CONV64_EXECUTED_GFLOP,
             'algorithm': ('fp32 operands split into %s, %d partial products per multiply on v_mfma_f32_32x32x16_%s with fp32 '
                           'accumulation (mean error below the fp32 fmaf chain\'s, tools/ubench/fp16x2_probe.hip): executed '
                           'flops = %d x algorithmic, priced against the dense 16-bit MFMA peak; the bare MFMA stream '
@@ -643,8 +740,9 @@ def main():
             'algorithmic_mb': PATH_ALGORITHMIC_MB,
             'hbm_gbps_algorithmic': PATH_ALGORITHMIC_MB / frame_ms,
             'hbm_frac_of_8tbps': PATH_ALGORITHMIC_MB / frame_ms / 8000.0,
-            'note': 'SURVEY.md 8d counts; the 64-channel layers run on the bf16 pipe (6 executed flops per algorithmic '
-                    'one), so the fp32-MFMA floor is a yardstick here, not a bound'.replace('6 executed', '3 executed')}
+            'note': ('SURVEY.md 8d counts; the 64-channel layers run on the 16-bit matrix pipe (%d executed flops per '
+                     'algorithmic one), so the fp32-MFMA floor is a yardstick here, not a bound' % int(X3_PRODUCTS))
+                    if X3 else 'SURVEY.md 8d counts'}
         ordered = sorted(args.steps / w for w in windows)
         line['windows'] = {'count': len(windows), 'median': ordered[len(ordered) // 2], 'min': ordered[0],
                            'max': ordered[-1], 'unit': 'pairs/s',

@@ -49,6 +49,17 @@ const char* pds_last_error(void);
  * and resets it when `reset` is non-zero; -1 when the counter could not be set up. */
 long long pds_nonfinite_statistics(int reset);
 
+/* ABI v5.  Launch probe (measurement only; bench.py's roofline): times named kernels IN SITU -- inside whatever
+ * sequence of launches the caller enqueues -- with a HIP event pair on the launch stream around each of them, instead
+ * of a micro-benchmark of the isolated kernel.  pds_probe_begin arms the probe for launches whose name contains
+ * `kernel` ("conv2d_x3", "conv2d_t8w"), at most `capacity` of them (<= 256; events are created on first use and
+ * re-used); pds_probe_end disarms it, waits for the recorded events and writes the durations in launch order
+ * (milliseconds) and the launch grids (workgroups) to ms[] / workgroups[] (either may be NULL); returns the number of
+ * launches recorded, or a negative error code.  Not thread-safe and not for production paths: events between
+ * launches serialise them. */
+int pds_probe_begin(const char* kernel, int capacity);
+int pds_probe_end(float* ms, int* workgroups, int capacity);
+
 /* ------------------------------------------------------------------------------------
  * Layer parameters in the reference's own (PyTorch) layouts.
  *   conv   weight [Cout, Cin, kD, kH, kW]  (Conv2d: kD == 1)   network_blocks.py:9-24

@@ -139,6 +139,8 @@ SIGNATURES = {
     'pds_abi_version': (_I, []),
     'pds_last_error': (ctypes.c_char_p, []),
     'pds_nonfinite_statistics': (ctypes.c_longlong, [_I]),
+    'pds_probe_begin': (_I, [ctypes.c_char_p, _I]),
+    'pds_probe_end': (_I, [_VP, _VP, _I]),
     'pds_subpixel_map_fwd': (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_shift_concat_fwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_matching_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
@@ -289,8 +291,9 @@ def parameter_signature(module):
 def resident_key(module, parameter_owner, geometry):
     """Key under which a workspace may keep this module's re-laid-out weights between calls, or None (re-layout on every
     call -- the default).  Residency is opt-in: ``module.freeze_weights()`` promises that the parameters are not
-    edited behind autograd's back until ``thaw_weights()`` / ``invalidate_weights()``; ``.to()`` / ``.cuda()`` /
-    ``load_state_dict`` / ``train()`` thaw on their own (FrozenWeightsMixin)."""
+    edited behind autograd's back until ``thaw_weights()`` / ``invalidate_weights()``.  ``train()`` thaws;
+    ``.to()`` / ``.cuda()`` / ``load_state_dict`` only INVALIDATE (the next call re-lays out once, the module stays
+    frozen and goes on trusting (data_ptr, _version) afterwards) -- FrozenWeightsMixin."""
     if not getattr(module, '_weights_frozen', False):
         return None
     signature = parameter_signature(parameter_owner)

@@ -35,6 +35,29 @@ int check_launch(const char* what) {
     return 0;
 }
 
+// ---- launch probe (include/pds_hip.h, ABI v5): in-situ kernel timing for bench.py --------------------------------
+namespace {
+constexpr int kProbeMax = 256;
+std::atomic<int> g_probe_armed{0};
+char g_probe_name[64] = "";
+int g_probe_capacity = 0, g_probe_count = 0, g_probe_events = 0;
+hipEvent_t g_probe_start[kProbeMax], g_probe_stop[kProbeMax];
+int g_probe_wgs[kProbeMax];
+}  // namespace
+
+int probe_before(const char* name, hipStream_t s) {
+    if (!g_probe_armed.load(std::memory_order_relaxed)) return -1;
+    if (!strstr(name, g_probe_name) || g_probe_count >= g_probe_capacity) return -1;
+    const int slot = g_probe_count++;
+    (void)hipEventRecord(g_probe_start[slot], s);
+    return slot;
+}
+void probe_after(int slot, int workgroups, hipStream_t s) {
+    if (slot < 0) return;
+    g_probe_wgs[slot] = workgroups;
+    (void)hipEventRecord(g_probe_stop[slot], s);
+}
+
 int launch_conv2d_mfma(const ConvLayer& L, hipStream_t s);        // conv2d_mfma.hip
 bool conv2d_mfma_supported(const ConvLayer& L);
 int conv2d_mfma_tiles(const Geom& out_g);
@@ -1069,6 +1092,35 @@ extern "C" {
 
 int pds_abi_version(void) { return PDS_ABI_VERSION; }
 long long pds_nonfinite_statistics(int reset) { return nonfinite_statistics(reset); }
+
+int pds_probe_begin(const char* kernel, int capacity) {
+    PDS_REQUIRE(kernel && kernel[0] && strlen(kernel) < sizeof(g_probe_name), "probe: bad kernel name");
+    PDS_REQUIRE(capacity > 0 && capacity <= kProbeMax, "probe: capacity %d outside 1..%d", capacity, kProbeMax);
+    for (; g_probe_events < capacity; ++g_probe_events) {
+        if (hipEventCreate(&g_probe_start[g_probe_events]) != hipSuccess ||
+            hipEventCreate(&g_probe_stop[g_probe_events]) != hipSuccess)
+            return set_error(-1, "probe: hipEventCreate failed");
+    }
+    strcpy(g_probe_name, kernel);
+    g_probe_capacity = capacity;
+    g_probe_count = 0;
+    g_probe_armed.store(1, std::memory_order_release);
+    return 0;
+}
+
+int pds_probe_end(float* ms, int* workgroups, int capacity) {
+    g_probe_armed.store(0, std::memory_order_release);
+    const int n = g_probe_count < capacity ? g_probe_count : capacity;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_probe_stop[i]) != hipSuccess) return set_error(-1, "probe: hipEventSynchronize failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_probe_start[i], g_probe_stop[i]) != hipSuccess)
+            return set_error(-1, "probe: hipEventElapsedTime failed");
+        if (ms) ms[i] = t;
+        if (workgroups) workgroups[i] = g_probe_wgs[i];
+    }
+    return n;
+}
 const char* pds_last_error(void) { return g_error; }
 
 int pds_subpixel_map_fwd(const float* similarities, float* disparities, int batch, int planes, int height,

@@ -18,6 +18,11 @@ constexpr double kInEps = 1e-5;      // torch InstanceNorm default eps
 // ---- error reporting across the C ABI ------------------------------------------------
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// Launch probe (pds_probe_begin / pds_probe_end, api.hip): a launcher brackets its launch with
+//     const int probe = probe_before("conv2d_x3", stream);  <launch>  probe_after(probe, workgroups, stream);
+// (one relaxed atomic load when the probe is not armed)
+int probe_before(const char* name, hipStream_t s);
+void probe_after(int slot, int workgroups, hipStream_t s);
 long long nonfinite_statistics(int reset);   // conv_direct.hip: the host-mapped counter behind pds_nonfinite_statistics
 
 // Per-function attributes (hipFuncSetAttribute) and per-device launch data are set up once per DEVICE of the process:

@@ -732,7 +732,9 @@ int launch_c2t8w(C2Args& A, hipStream_t s) {
     }
     int wgs = cus[dev & 31] / 8 * 8;
     if (wgs > A.tiles) wgs = (A.tiles + 7) / 8 * 8;
+    const int probe = probe_before("conv2d_t8w", s);
     hipLaunchKernelGGL((conv2d_t8w_kernel<TWO, NBH>), dim3(wgs), dim3(C2W_THREADS), lds_bytes, s, A);
+    probe_after(probe, A.tiles, s);
     return check_launch("conv2d_t8w");
 }
 

@@ -898,9 +898,12 @@ static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     }
+    // (planes * tiles rides along as the "workgroups" of the probe record: it tells a 48-plane layer from a small one)
+    const int probe = probe_before(P == 2 ? "conv2d_x3<fp16>" : "conv2d_x3<bf16>", s);
     if (L.a.scale)
         hipLaunchKernelGGL((conv2d_x3_kernel<P, true>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
     else hipLaunchKernelGGL((conv2d_x3_kernel<P, false>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
+    probe_after(probe, A.planes * A.tiles, s);
     return check_launch("conv2d_x3");
 }
 

@@ -27,50 +27,158 @@ def shard_range(number_of_planes, rank, world_size):
     return rank * per_rank, per_rank
 
 
+# How the signatures are all-gathered (chosen once per process, by `preflight_collectives` or at the first gather):
+#   'coalesced'  batch * C all_gather_into_tensor calls on contiguous per-channel views of the FINAL [B, C, D, h, w]
+#                tensor, issued as one group (ncclGroupStart / End): one launch, no staging buffer, no re-layout copy
+#   'separate'   the same collectives one by one (every backend: gloo in the CPU tests)
+#   'single'     ONE all_gather_into_tensor into a rank-major staging buffer + a permuting copy (round 2's form: the
+#                most conservative use of the library)
+_GATHER_MODE = None
+_GATHER_NOTE = 'not decided yet (no gather has run)'
+
+
+def _device_backend(group, device):
+    """Name of the backend that serves `device` in this group ("nccl" is RCCL).  `dist.get_backend` names the group's
+    configuration, which for a multi-backend group ("cpu:gloo,cuda:nccl") is not the backend a CUDA tensor uses."""
+    try:
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        return pg._get_backend(torch.device(device)).name().lower()
+    except Exception:   # older / different process-group objects: fall back to the configured name
+        name = str(dist.get_backend(group)).lower()
+        if ':' in name:   # "cpu:gloo,cuda:nccl"
+            kind = 'cuda' if torch.device(device).type == 'cuda' else 'cpu'
+            parts = dict(item.split(':') for item in name.split(','))
+            return parts.get(kind, name)
+        return name
+
+
+def _views(out, local_planes):
+    batch, channels = local_planes.shape[:2]
+    return [(out[b, c].view(-1), local_planes[b, c].view(-1)) for b in range(batch) for c in range(channels)]
+
+
+def _gather_coalesced(out, local_planes, group):
+    from torch.distributed.distributed_c10d import _coalescing_manager
+    with _coalescing_manager(group=group, device=local_planes.device, async_ops=False):
+        for whole, mine in _views(out, local_planes):
+            dist.all_gather_into_tensor(whole, mine, group=group)
+
+
+def _gather_separate(out, local_planes, group):
+    for whole, mine in _views(out, local_planes):
+        dist.all_gather_into_tensor(whole, mine, group=group)
+
+
+def _gather_single(out, local_planes, group):
+    world_size = dist.get_world_size(group)
+    batch, channels, d_local, h, w = local_planes.shape
+    staging = local_planes.new_empty((world_size, batch, channels, d_local, h, w))
+    dist.all_gather_into_tensor(staging.view(-1), local_planes.view(-1), group=group)
+    out.view(batch, channels, world_size, d_local, h, w).copy_(staging.permute(1, 2, 0, 3, 4, 5))
+
+
+_GATHER_FORMS = {'coalesced': _gather_coalesced, 'separate': _gather_separate, 'single': _gather_single}
+
+
+def _all_ranks_agree(ok, device, group):
+    """True when `ok` holds on every rank (one tiny MIN all-reduce -- the most basic collective there is)."""
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() == 1.0)
+
+
+def _choose_gather_mode(device, group):
+    """Tries the forms in order of preference on a tiny tensor and takes the first one that runs AND reproduces the
+    locally computed expectation on every rank.  An exception (of any type: RCCL reports API misuse as RuntimeError)
+    or a wrong result on ANY rank moves all ranks on together, so the ranks never disagree about the form."""
+    global _GATHER_MODE, _GATHER_NOTE
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = _device_backend(group, device)
+    order = ['coalesced', 'separate', 'single'] if backend == 'nccl' else ['separate', 'single']
+    batch, channels, d_local, h, w = 2, 3, 2, 3, 5
+    def shard(r):
+        base = torch.arange(batch * channels * d_local * h * w, dtype=torch.float32).view(batch, channels, d_local, h, w)
+        return base + 1000.0 * r
+    expect = torch.cat([shard(r) for r in range(world)], dim=2).to(device)
+    mine = shard(rank).to(device).contiguous()
+    tried = []
+    for mode in order:
+        ok, why = True, ''
+        try:
+            out = mine.new_full((batch, channels, world * d_local, h, w), float('nan'))
+            _GATHER_FORMS[mode](out, mine, group)
+            if out.is_cuda:
+                torch.cuda.synchronize(out.device)
+            ok = bool(torch.equal(out, expect))
+            why = '' if ok else 'wrong result'
+        except Exception as error:   # noqa: BLE001  (any failure of this form means: use the next one)
+            ok, why = False, '%s: %s' % (type(error).__name__, str(error).split('\n')[0][:120])
+        agreed = _all_ranks_agree(ok, device, group)
+        tried.append('%s %s' % (mode, 'ok' if agreed else ('failed (%s)' % (why or 'on another rank'))))
+        if agreed:
+            _GATHER_MODE = mode
+            _GATHER_NOTE = 'backend %s; %s' % (backend, ', '.join(tried))
+            return mode
+    raise RuntimeError('no form of the all-gather works on this process group: %s' % ', '.join(tried))
+
+
+def preflight_collectives(group=None, device=None):
+    """Self-check of the collectives this package uses, on tiny tensors against locally computed expectations, BEFORE
+    anything is timed: all_reduce (SUM, MAX), then the all-gather forms (the form chosen is the one every later
+    gather uses).  Returns a description for the bench line; raises on failure (same outcome on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError('torch.distributed is not initialised')
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    device = torch.device(device)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    t = torch.tensor([float(rank + 1), 2.0], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if t.tolist() != [world * (world + 1) / 2.0, 2.0 * world]:
+        raise RuntimeError('all_reduce(SUM) returned %s on rank %d of %d' % (t.tolist(), rank, world))
+    t = torch.tensor([float(rank)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if t.item() != world - 1:
+        raise RuntimeError('all_reduce(MAX) returned %s on rank %d of %d' % (t.item(), rank, world))
+    mode = _choose_gather_mode(device, group)
+    info = {'all_reduce': 'ok', 'gather_mode': mode, 'gather_forms_tried': _GATHER_NOTE,
+            'backend': _device_backend(group, device), 'world_size': world}
+    if device.type == 'cuda':
+        try:
+            info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as error:   # noqa: BLE001
+            info['rccl_version'] = 'unknown (%s)' % type(error).__name__
+    import os
+    info['knobs'] = {k: os.environ[k] for k in sorted(os.environ) if k.startswith(('NCCL_', 'RCCL_'))}
+    return info
+
+
 def _gather_planes_raw(local_planes, group):
     """[batch, C, D_local, h, w] shards -> [batch, C, world * D_local, h, w], written in its FINAL layout: for every
     (batch entry, channel) the D_local planes of a rank are one contiguous block, and the world blocks of that
     (batch entry, channel) are contiguous in rank order -- exactly what ``all_gather_into_tensor`` produces.  So the
     gather is batch * C collectives on contiguous views of the output (8 at batch 1), issued as ONE coalesced group
     on RCCL (ncclGroupStart / End: one launch, every rank sends its block straight to its 7 xGMI peers), and no
-    re-layout copy of the 53 MB result runs afterwards (round 2 gathered rank-major and permuted)."""
+    re-layout copy of the 53 MB result runs afterwards.  The form is decided ONCE per process by a self-check on a tiny
+    tensor (`_choose_gather_mode`; no multi-GPU node was available to the build, so nothing about RCCL is assumed)."""
     local_planes = local_planes.contiguous()
     world_size = dist.get_world_size(group)
     batch, channels, d_local, h, w = local_planes.shape
     out = local_planes.new_empty((batch, channels, world_size * d_local, h, w))
-    pairs = [(out[b, c].view(-1), local_planes[b, c].view(-1)) for b in range(batch) for c in range(channels)]
-    global _COALESCE_OK
-    if local_planes.is_cuda and dist.get_backend(group) == 'nccl' and len(pairs) > 1 and _COALESCE_OK:
-        # (RCCL has never run this code in the build container -- one GPU at most -- so the grouped form is guarded: an
-        # API error of the coalescing manager is the same on every rank, and every rank then takes the plain form below,
-        # which re-issues all of the collectives)
-        try:
-            from torch.distributed.distributed_c10d import _coalescing_manager
-            with _coalescing_manager(group=group, device=local_planes.device, async_ops=False):
-                for whole, mine in pairs:
-                    dist.all_gather_into_tensor(whole, mine, group=group)
-            return out
-        except (ImportError, TypeError, AttributeError, NotImplementedError) as error:
-            _COALESCE_OK = False
-            import warnings
-            warnings.warn('grouped all-gather unavailable (%s: %s); using %d separate collectives per pair'
-                          % (type(error).__name__, error, len(pairs)))
-    for whole, mine in pairs:
-        dist.all_gather_into_tensor(whole, mine, group=group)
+    mode = _GATHER_MODE or _choose_gather_mode(local_planes.device, group)
+    _GATHER_FORMS[mode](out, local_planes, group)
     return out
 
 
-_COALESCE_OK = True
-
-
 def gather_description(group=None):
-    """What the bench line records about the collective (config.parallelism): its form and the RCCL knobs in force."""
-    import os
-    knobs = ', '.join('%s=%s' % (k, os.environ[k]) for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS',
-                                                                'NCCL_MAX_NCHANNELS', 'RCCL_MSCCL_ENABLE')
-                      if k in os.environ)
-    return ('batch x 8 all_gather_into_tensor calls on contiguous per-channel views of the [B, 8, D\', h, w] result, '
-            'coalesced into one group (no staging buffer, no re-layout copy); RCCL knobs: %s' % (knobs or 'library defaults'))
+    """What the bench line records about the collective (config.parallelism): the form ACTUALLY in use."""
+    forms = {'coalesced': "batch x 8 all_gather_into_tensor calls on contiguous per-channel views of the [B, 8, D', h, w] "
+                          'result, coalesced into one group (no staging buffer, no re-layout copy)',
+             'separate': "batch x 8 separate all_gather_into_tensor calls on contiguous per-channel views of the "
+                         "[B, 8, D', h, w] result (no staging buffer, no re-layout copy)",
+             'single': 'one all_gather_into_tensor into a rank-major staging buffer + one permuting copy',
+             None: 'form not decided yet'}
+    return '%s [%s]' % (forms[_GATHER_MODE], _GATHER_NOTE)
 
 
 class _GatherPlanes(torch.autograd.Function):

@@ -38,8 +38,9 @@ class PdsNetwork(nn.Module):
 
     def freeze_weights(self):
         """Inference deployment: promise that the parameters stay untouched, so the modules keep their re-laid-out
-        weights between calls (``_lib.FrozenWeightsMixin``; not in the reference).  ``train()``, ``.to()`` and
-        ``load_state_dict`` undo it; after editing parameters through ``.data`` call ``invalidate_weights()``."""
+        weights between calls (``_lib.FrozenWeightsMixin``; not in the reference).  ``train()`` undoes it;
+        ``.to()`` and ``load_state_dict`` invalidate the kept weights once (the network stays frozen); after editing
+        parameters through ``.data`` call ``invalidate_weights()`` yourself."""
         for module in self.modules():
             if module is not self and hasattr(module, 'freeze_weights'):
                 module.freeze_weights()

@@ -238,3 +238,59 @@ def test_sharded_matching_is_differentiable():
         p.join(120)
         assert p.exitcode == 0
     assert all(results.get(r) for r in range(world)), dict(results)
+
+
+def preflight_worker(rank, world, port, results):
+    """preflight_collectives: the self-check picks a gather form that reproduces the expectation on every rank, a
+    form that fails is abandoned by ALL ranks together, and every form that runs here gives the layout."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        info = pdist.preflight_collectives(device='cpu')
+        ok = info['gather_mode'] in ('separate', 'single') and info['backend'] == 'gloo' and info['all_reduce'] == 'ok'
+        ok = ok and info['gather_mode'] in pdist.gather_description()
+        g = torch.Generator().manual_seed(21)
+        full = torch.randn(2, 8, 4 * world, 3, 5, generator=g)
+        mine = full[:, :, 4 * rank:4 * rank + 4].contiguous()
+        for mode in ('separate', 'single'):
+            out = torch.full_like(full, float('nan'))
+            pdist._GATHER_FORMS[mode](out, mine, None)
+            ok = ok and torch.equal(out, full)
+        # (i) a form that raises on EVERY rank (an API error -- RCCL reports misuse as RuntimeError -- is the same
+        # everywhere) and (ii) a form that completes but leaves a wrong result on ONE rank: all ranks must move on to
+        # the next form together
+        real = pdist._GATHER_FORMS['separate']
+        for kind in ('raises', 'wrong on rank 1'):
+            def broken(out, local, group, kind=kind):
+                if kind == 'raises':
+                    raise RuntimeError('injected failure')
+                real(out, local, group)
+                if rank == 1:
+                    out.view(-1)[3] += 1.0
+            pdist._GATHER_FORMS['separate'] = broken
+            try:
+                pdist._GATHER_MODE = None
+                mode = pdist._choose_gather_mode(torch.device('cpu'), None)
+            finally:
+                pdist._GATHER_FORMS['separate'] = real
+            ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
+        ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
+        ok = ok and torch.equal(pdist.gather_planes(mine), full)
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_preflight_and_gather_forms():
+    world = 2
+    ctx = mp.get_context('spawn')
+    results = ctx.Manager().dict()
+    port = free_port()
+    procs = [ctx.Process(target=preflight_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(results.get(r) for r in range(world)), dict(results)

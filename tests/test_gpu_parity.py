@@ -299,8 +299,12 @@ def test_config1_full_network_on_gpu(dev):
     assert out.shape == (1, 128, 256)
     rep = helpers.disparity_report(out, g['disparity'])
     print('config1 full network (GPU embedding)', rep)
-    assert rep['mae'] <= 5e-3, rep   # the GPU descriptors differ from the golden (CPU) ones by ~1e-5: a few flips
-    assert rep['mae_noflip'] <= 1e-4 and rep['flips'] <= 2e-4, rep
+    # the GPU descriptors differ from the golden (CPU) ones by ~1e-5: a few arg-max flips; the raw MAE is 1e-3
+    # (north_star) plus what every counted flip may add (at most 63 px / 32 768 px), as in the hot-path test above
+    flipped = round(rep['flips'] * out.numel())
+    assert flipped <= 6, rep
+    assert rep['mae'] <= TOL_DISPARITY_MAE + flipped * 63.0 / out.numel(), rep
+    assert rep['mae_noflip'] <= 1e-4, rep
     net.train()
     with torch.no_grad():
         cost = net(left.to(dev), right.to(dev))
@@ -335,8 +339,12 @@ def test_config2_full_size_vs_oracle_and_golden(dev):
     assert round(rep['flips'] * disparity.numel()) <= 8, rep
     assert rep['mae_noflip'] <= 1e-4, rep
     assert rep['mae'] <= TOL_DISPARITY_MAE, rep
+    # the committed sub-sample of the reference's own output (2 160 pixels: one ~100 px flip alone is 0.046 of MAE):
+    # at most one flipped sample, the others within the smooth tolerance
     sub = helpers.disparity_report(disparity[:, ::16, ::16], g['disparity_sub'])
-    assert sub['mae'] <= 1e-1, sub     # 2 160 samples: one ~100 px flip alone is 0.046
+    sub_flipped = round(sub['flips'] * g['disparity_sub'].numel())
+    assert sub_flipped <= 1 and sub['mae_noflip'] <= 1e-4, sub
+    assert sub['mae'] <= TOL_DISPARITY_MAE + sub_flipped * 191.0 / g['disparity_sub'].numel(), sub
     # fused eval path at full size
     _, _, fused = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     rep_f = helpers.disparity_report(fused, disp_o)
