@@ -252,6 +252,9 @@ def time_dominant_kernel_in_situ(run_pair, device, pairs):
     if n < 0:
         _lib.check(n, 'pds_probe_end')
     times = [ms[i] for i in range(n) if wgs[i] == full]
+    if times:   # a host stall between the start event and the launch shows up as GPU idle time inside the bracket: drop it
+        median = sorted(times)[len(times) // 2]
+        times = [t for t in times if t <= 3.0 * median]
     if not times:
         return None
     times.sort()

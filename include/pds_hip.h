@@ -229,6 +229,24 @@ int pds_matching_operation_bwd(const PdsMatchingParams* params, const PdsMatchin
                                int n, int h, int w, void* fwd_workspace, size_t fwd_workspace_bytes,
                                void* workspace, size_t workspace_bytes, pds_stream_t stream);
 
+/* ABI v5.  Matching(MatchingOperation) with gradients (reference matching.py:34-63 under autograd, driven by
+ * pds_trainer.py:40-46).  pds_matching_train_fwd is pds_matching_fwd on the differentiable route: layer 0 keeps its
+ * factorisation (conv_L(left) + shift_d(conv_R(right)): the [D', B, 128, h, w] concat of matching.py:50-62 never
+ * exists), x0 is materialised and every layer output is kept in `workspace`, which the caller preserves until
+ * pds_matching_bwd.  pds_matching_bwd walks back from grad_signatures [batch, 8, d_count, h, w] to the parameter
+ * gradients (`grads` mirrors `params`, written) and to grad_left / grad_right [batch, features, h, w] (written); layer 0
+ * is differentiated through its factorisation: one streaming reduction of d loss / d x0 over the disparity planes, then
+ * single-plane convolution gradients.  With d_begin / d_count the gradients are the partial sums of that plane range. */
+size_t pds_matching_train_workspace_bytes(const PdsMatchingParams* params, int batch, int h, int w, int d_count);
+int pds_matching_train_fwd(const PdsMatchingParams* params, const float* left, const float* right, float* signatures,
+                           int batch, int h, int w, int d_begin, int d_count, void* workspace, size_t workspace_bytes,
+                           pds_stream_t stream);
+size_t pds_matching_bwd_workspace_bytes(const PdsMatchingParams* params, int batch, int h, int w, int d_count);
+int pds_matching_bwd(const PdsMatchingParams* params, const PdsMatchingParams* grads, const float* left,
+                     const float* right, const float* grad_signatures, float* grad_left, float* grad_right, int batch,
+                     int h, int w, int d_begin, int d_count, void* fwd_workspace, size_t fwd_workspace_bytes,
+                     void* workspace, size_t workspace_bytes, pds_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Embedding                                 reference embedding.py:11-65 (producer of the path's inputs)
  *   image [batch, input_features, h, w] -> descriptor [batch, features, H4, W4], shortcut [batch, shortcut_features, H4, W4]

@@ -146,6 +146,11 @@ SIGNATURES = {
     'pds_matching_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
     'pds_matching_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I,
                               _VP, _SZ, _I, _VP]),
+    'pds_matching_train_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
+    'pds_matching_train_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP]),
+    'pds_matching_bwd_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
+    'pds_matching_bwd': (_I, [ctypes.POINTER(MatchingParams), ctypes.POINTER(MatchingParams), _VP, _VP, _VP, _VP, _VP,
+                              _I, _I, _I, _I, _I, _VP, _SZ, _VP, _SZ, _VP]),
     'pds_matching_operation_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I]),
     'pds_matching_operation_fwd': (_I, [ctypes.POINTER(MatchingParams), _VP, _VP, _I, _I, _I,
                                         _VP, _SZ, _VP]),

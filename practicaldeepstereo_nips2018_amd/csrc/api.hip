@@ -112,6 +112,16 @@ struct TapeTensor {
     int per_plane = 0;
     int bcast_d = 0;              // [N, C, H, W] tensor broadcast along D (g.d is the broadcast extent)
     bool needs_grad = true;       // false: nothing upstream wants a gradient (the image)
+    const float* bound = nullptr; // range certificate of the forward pass (Src::bound), still in the forward workspace
+    int bound_n = 0;
+    bool bounded = false;
+    Src src() const {
+        Src s{raw, scale, shift, per_plane, bcast_d};
+        s.bound = bound;
+        s.bound_n = bound_n;
+        s.bounded = bounded ? 1 : 0;
+        return s;
+    }
 };
 struct TapeLayer {
     int type = 0;                 // 0 conv, 1 transposed conv, 2 sum (out = a^ + b^, plain),
@@ -258,6 +268,9 @@ static void tape_layer(Ctx& c, int type, int kd, int stride, const Src& a, const
     t.rstd = o.rstd;
     t.g = o.g;
     t.per_plane = o.per_plane;
+    t.bound = o.bound;
+    t.bound_n = o.bound_n;
+    t.bounded = o.bounded;
     o.id = c.tape->add(t);
     TapeLayer L;
     L.type = type;
@@ -514,12 +527,22 @@ static bool fused_matching_supported(const PdsMatchingParams& P, int batch, int 
     return conv2d_mfma_supported(L) && conv2d_mfma_supported(T);
 }
 
+// what the layer-0 backward (pds_matching_bwd) needs from a training-route walk
+struct MatchingL0 {
+    const float* w3 = nullptr;   // [3 sets][F][F][3][3]: left half, right half, right half without dx = +1
+};
+
+// train: the differentiable route.  Layer 0 keeps its factorisation (the right descriptor is convolved once, no
+// [D', B, 128, h, w] concat exists), x0 = A + shift_d(G) is materialised as the first tape tensor and the rest of
+// MatchingOperation runs layer by layer, every output kept for the backward pass.
 static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* left, const float* right,
-                              float* signatures, int batch, int h, int w, int d_begin, int d_count) {
+                              float* signatures, int batch, int h, int w, int d_begin, int d_count, bool train = false,
+                              MatchingL0* l0_out = nullptr) {
     const int F = P.features;
     const size_t wn = (size_t)F * F * 9;
     float* w3 = c.get<float>(3 * wn);       // [3 sets][F][F][3][3]: left half, right half, right half without dx=+1
     float* bias3 = c.get<float>(3 * F);
+    if (l0_out) l0_out->w3 = w3;
     const Geom g{batch, F, d_count, h, w};
     const bool fused = [&]() {
         static const bool enabled = []() {  // PDS_MATCHING_FUSED=0 selects the unfused sequence (A/B, debugging)
@@ -536,7 +559,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
             const char* e = getenv("PDS_MATCHING_COLUMNS");
             return !(e && e[0] == '0');
         }();
-        return enabled && fused && P.residual_blocks >= 1 && F % 8 == 0;
+        return enabled && fused && !train && P.residual_blocks >= 1 && F % 8 == 0;
     }();
     const int l0_planes = columns ? 2 : 3;
     // plane 0: left, planes 1(-2): right, each behind one zero column -- two in the column form: the width is even
@@ -562,13 +585,19 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         PdsConvBlockParams p3{w3, bias3, nullptr, nullptr};
         ConvExtra e3;
         e3.plane_weight_sets = l0_planes;
+        // (not a tape layer: the training route differentiates layer 0 through its factorisation, matching_backward)
+        Tape* tape = c.tape;
+        c.tape = nullptr;
         y3 = conv_block(c, plain_src(x3), no_src(), g3, p3, F, 1, 1, 1, nullptr, true, nullptr, nullptr, &e3).raw;
+        c.tape = tape;
     } else {
         // generic kernels share one weight set per launch: three launches into the planes of y3
         y3 = c.get<float>(g3.numel());
         float* tmp_in = c.get<float>((size_t)batch * F * h * (w + 1));
         float* tmp_out = c.get<float>((size_t)batch * F * h * (w + 1));
         const Geom g1{batch, F, 1, h, w + 1};
+        Tape* tape = c.tape;
+        c.tape = nullptr;   // (as above)
         for (int p = 0; p < 3; ++p) {
             if (!c.plan) c.run(launch_pad_left1(p == 0 ? left : right, tmp_in, (size_t)batch * F * h, w, c.s));
             PdsConvBlockParams pp{w3 + p * wn, bias3 + p * F, nullptr, nullptr};
@@ -579,6 +608,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
                                         (size_t)h * (w + 1) * sizeof(float), (size_t)h * (w + 1) * sizeof(float),
                                         (size_t)batch * F, hipMemcpyDeviceToDevice, c.s));
         }
+        c.tape = tape;
     }
     const size_t l0_cstride = (size_t)l0_planes * h * l0_rs;
     const float* l0A = y3 + l0_pad;                                      // column of x = 0 in plane 0
@@ -594,10 +624,24 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
                                        l0_cstride, l0_rs, l0_pad, batch, F, F, h, w, d_begin, d_count, c.s));
         l0G2 = g2buf + (size_t)h * l0_rs + (l0_pad - 1);
     }
-    if (!fused) {
-        float* x0 = c.get<float>(g.numel());
-        if (!c.plan) c.run(launch_l0_combine(l0A, l0G, l0G2, l0_cstride, x0, batch, F, h, w, d_begin, d_count, c.s));
-        operation_tail(c, P, plain_src(x0), g, signatures);
+    if (!fused || train) {
+        DT x0;   // plain; the kernel that forms it records its largest magnitudes (the range certificate, Src::bound)
+        x0.g = g;
+        x0.raw = c.get<float>(g.numel());
+        carve_amax(c, x0, l0_combine_records(batch, F, d_count));
+        if (!c.plan)
+            c.run(launch_l0_combine(l0A, l0G, l0G2, l0_cstride, x0.raw, batch, F, h, w, d_begin, d_count, c.s, x0.bound));
+        Src x0s = x0.src();
+        if (c.tape) {   // tape tensor 0 of the training route: its gradient is what the layer-0 backward starts from
+            TapeTensor t;
+            t.raw = x0.raw;
+            t.g = g;
+            t.bound = x0.bound;
+            t.bound_n = x0.bound_n;
+            t.bounded = true;
+            x0s.id = c.tape->add(t);
+        }
+        operation_tail(c, P, x0s, g, signatures);
         return;
     }
     // Fused: x0 = A + shift_d(G) is never stored.  The first conv forms it inside its loader; the first
@@ -980,7 +1024,15 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         }
         // 1. through InstanceNorm + LeakyReLU
         const float* dz = g;
+        // range certificate of dz (max |dz|, collected by the InstanceNorm backward that writes it): with it the
+        // 64-channel weight and data gradients run their fp16-split kernels; a bare layer's dz (the caller's gradient)
+        // has none and keeps the range-safe forms
+        Src sdz = plain_src(nullptr);
         if (L.norm) {
+            float* dz_amax = c.get<float>(kDzAmaxSlots);
+            sdz.bound = dz_amax;
+            sdz.bound_n = kDzAmaxSlots;
+            sdz.bounded = 1;
             float* dzb = c.get<float>(out.g.numel());
             double* scratch = c.get<double>(in_bwd_scratch_doubles(out.g));
             const int groups = out.g.n * out.g.c * (out.per_plane ? out.g.d : 1);
@@ -989,17 +1041,16 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             if (!c.plan)
                 c.run(launch_in_bwd(g, out.raw, out.g, out.per_plane, out.mean, out.rstd, L.P->gamma, scratch, m1, m2,
                                     dzb, const_cast<float*>(gp->gamma), const_cast<float*>(gp->beta),
-                                    const_cast<float*>(gp->bias), 0, c.s));   // (the bias gradient comes with it)
+                                    const_cast<float*>(gp->bias), 0, c.s, dz_amax));   // (the bias gradient comes with it)
             dz = dzb;
         }
+        sdz.p = dz;
         // 2. parameters
         const TapeTensor& ta = T.tensors[L.a];
-        Src sa{ta.raw, ta.scale, ta.shift, ta.per_plane, 0};
+        Src sa = ta.src();
+        sa.bcast_d = 0;
         Src sb = no_src();
-        if (L.b >= 0) {
-            const TapeTensor& tb = T.tensors[L.b];
-            sb = Src{tb.raw, tb.scale, tb.shift, tb.per_plane, tb.bcast_d};
-        }
+        if (L.b >= 0) sb = T.tensors[L.b].src();
         if (!L.norm) {   // a bare layer: dz is the upstream gradient itself, its channel sums need a pass of their own
             double* bias_scratch = c.get<double>((size_t)channel_sum_splits(out.g) * out.g.c);
             if (!c.plan) c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
@@ -1011,7 +1062,7 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         if (wgrad2d_mfma_supported(L.type, L.kd, L.stride, sb, L.in_g, L.out_g)) {
             float* ws = c.get<float>(wgrad2d_mfma_scratch_floats(L.in_g, L.out_g));
             if (!c.plan)
-                c.run(launch_wgrad2d_mfma(sa, sb, dz, dweight, L.in_g, L.out_g, 0, ws, c.s));
+                c.run(launch_wgrad2d_mfma(sa, sb, sdz, dweight, L.in_g, L.out_g, 0, ws, c.s));
         } else if (wgrad3d_mfma_supported(L.type, L.kd, L.stride, L.in_g, L.out_g)) {
             float* ws = c.get<float>(wgrad3d_mfma_scratch_floats(L.in_g, L.out_g));
             if (!c.plan)
@@ -1055,7 +1106,7 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
                         PdsConvBlockParams pf{wf + (size_t)j * 64 * L.out_g.c * taps, nullptr, nullptr, nullptr};
                         ConvExtra slice;
                         slice.out_batch_channels = L.in_g.c;
-                        conv_block(c, plain_src(dz), no_src(), L.out_g, pf, 64, 1, 1, 0,
+                        conv_block(c, sdz, no_src(), L.out_g, pf, 64, 1, 1, 0,
                                    dx ? dx + (size_t)j * 64 * vol : nullptr, true, nullptr, nullptr, &slice);
                     }
                 } else {
@@ -1071,7 +1122,7 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
                 }
             } else {
                 PdsConvBlockParams pf{wf, nullptr, nullptr, nullptr};
-                conv_block(c, plain_src(dz), no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);
+                conv_block(c, sdz, no_src(), L.out_g, pf, L.in_g.c, L.kd, 1, 0, dx);
             }
         } else if (!c.plan) {
             c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, weight, dx, L.in_g, L.out_g, c.s));
@@ -1172,6 +1223,60 @@ int pds_matching_fwd(const PdsMatchingParams* params, const float* left, const f
     return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
         matching_pipeline(c, *params, left, right, signatures, batch, h, w, d_begin, d_count);
     }, weights_resident != 0);
+}
+
+static int matching_backward(bool plan, size_t* bytes, const PdsMatchingParams* params, const PdsMatchingParams* grads,
+                             const float* left, const float* right, const float* grad_signatures, float* grad_left,
+                             float* grad_right, int batch, int h, int w, int d_begin, int d_count, void* fwd_workspace,
+                             void* workspace, hipStream_t stream);
+
+/* ABI v5: the differentiable route of Matching + MatchingOperation (see include/pds_hip.h) */
+size_t pds_matching_train_workspace_bytes(const PdsMatchingParams* params, int batch, int h, int w, int d_count) {
+    if (check_matching_params(params)) return 0;
+    Ctx c{nullptr, 0, true, nullptr};
+    matching_pipeline(c, *params, nullptr, nullptr, nullptr, batch, h, w, 0, d_count, true);
+    return c.off;
+}
+
+int pds_matching_train_fwd(const PdsMatchingParams* params, const float* left, const float* right, float* signatures,
+                           int batch, int h, int w, int d_begin, int d_count, void* workspace, size_t workspace_bytes,
+                           pds_stream_t stream) {
+    if (int rc = check_matching_params(params)) return rc;
+    PDS_REQUIRE(left && right && signatures && workspace, "matching_train: null pointer");
+    PDS_REQUIRE(batch > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0, "matching_train: bad shape");
+    PDS_REQUIRE(params->residual_blocks >= 0, "matching_train: bad block count");
+    const size_t need = pds_matching_train_workspace_bytes(params, batch, h, w, d_count);
+    PDS_REQUIRE(workspace_bytes >= need, "matching_train: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return run_with_batched_packing(workspace, (hipStream_t)stream, [&](Ctx& c) {
+        matching_pipeline(c, *params, left, right, signatures, batch, h, w, d_begin, d_count, true);
+    });
+}
+
+size_t pds_matching_bwd_workspace_bytes(const PdsMatchingParams* params, int batch, int h, int w, int d_count) {
+    if (check_matching_params(params)) return 0;
+    size_t bytes = 0;
+    if (matching_backward(true, &bytes, params, params, nullptr, nullptr, nullptr, nullptr, nullptr, batch, h, w, 0,
+                          d_count, nullptr, nullptr, nullptr))
+        return 0;
+    return bytes + 256;
+}
+
+int pds_matching_bwd(const PdsMatchingParams* params, const PdsMatchingParams* grads, const float* left,
+                     const float* right, const float* grad_signatures, float* grad_left, float* grad_right, int batch,
+                     int h, int w, int d_begin, int d_count, void* fwd_workspace, size_t fwd_workspace_bytes,
+                     void* workspace, size_t workspace_bytes, pds_stream_t stream) {
+    if (int rc = check_matching_params(params)) return rc;
+    if (int rc = check_matching_params(grads)) return rc;
+    PDS_REQUIRE(left && right && grad_signatures && grad_left && grad_right && fwd_workspace && workspace,
+                "matching_bwd: null pointer");
+    PDS_REQUIRE(batch > 0 && h > 0 && w > 0 && d_begin >= 0 && d_count > 0, "matching_bwd: bad shape");
+    PDS_REQUIRE(fwd_workspace_bytes >= pds_matching_train_workspace_bytes(params, batch, h, w, d_count),
+                "matching_bwd: forward workspace too small");
+    const size_t need = pds_matching_bwd_workspace_bytes(params, batch, h, w, d_count);
+    PDS_REQUIRE(workspace_bytes >= need, "matching_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    ArenaLimit limit(workspace_bytes);
+    return matching_backward(false, nullptr, params, grads, left, right, grad_signatures, grad_left, grad_right, batch, h,
+                             w, d_begin, d_count, fwd_workspace, workspace, (hipStream_t)stream);
 }
 
 size_t pds_matching_operation_workspace_bytes(const PdsMatchingParams* params, int n, int h, int w) {
@@ -1483,6 +1588,86 @@ static int operation_backward(bool plan, size_t* bytes, const PdsMatchingParams*
     if (!plan) c.limit = g_backward_arena_bytes;
     if (plan) dhat[0] = dhat[tape.tensors.size() - 1] = reinterpret_cast<float*>(8);
     backward_walk(c, tape, M, dhat, written);
+    if (bytes) *bytes = c.off;
+    return c.err;
+}
+
+// Backward of the training route of Matching (matching_pipeline(train)): the tape walk from the signatures down to
+// x0, then layer 0 through its factorisation -- ONE streaming reduction of d loss / d x0 over the disparity planes
+// (l0_combine_bwd) and single-plane convolution gradients, instead of a 128 -> 64 weight / data gradient over all planes
+// and the adjoint of an 850 MB concat (reference: autograd through matching.py:50-62).
+static int matching_backward(bool plan, size_t* bytes, const PdsMatchingParams* params, const PdsMatchingParams* grads,
+                             const float* left, const float* right, const float* grad_signatures, float* grad_left,
+                             float* grad_right, int batch, int h, int w, int d_begin, int d_count, void* fwd_workspace,
+                             void* workspace, hipStream_t stream) {
+    Tape tape;
+    MatchingL0 l0;
+    Ctx re{plan ? nullptr : (char*)fwd_workspace, 0, true, stream};
+    re.tape = &tape;
+    matching_pipeline(re, *params, left, right, const_cast<float*>(grad_signatures) /*placeholder*/, batch, h, w, d_begin,
+                      d_count, true, &l0);
+    if (re.err) return re.err;
+    if (tape.tensors.empty()) return set_error(-1, "matching_bwd: empty tape");
+    std::vector<float*> dhat(tape.tensors.size(), nullptr);
+    std::vector<char> written(tape.tensors.size(), 0);
+    dhat[tape.tensors.size() - 1] = plan ? reinterpret_cast<float*>(8) : const_cast<float*>(grad_signatures);
+    written[tape.tensors.size() - 1] = 1;
+    GradMap M{reinterpret_cast<const char*>(params), reinterpret_cast<const char*>(grads), sizeof(PdsMatchingParams)};
+    M.blocks_params = params->blocks;
+    M.blocks_grads = grads->blocks;
+    M.blocks_count = 2 * params->residual_blocks;
+    Ctx c{plan ? nullptr : (char*)workspace, 0, plan, stream};
+    if (!plan) c.limit = g_backward_arena_bytes;
+    backward_walk(c, tape, M, dhat, written);
+    if (c.err) return c.err;
+    if (!written[0]) return set_error(-1, "matching_bwd: no gradient reached x0");
+    // ---- layer 0 ----------------------------------------------------------------------------------------------------
+    const int F = params->features;
+    const size_t wn = (size_t)F * F * 9;
+    const Geom g1{batch, F, 1, h, w + 1};
+    const size_t n1 = g1.numel();
+    float* gy_a = c.get<float>(n1);
+    float* gy_gs = c.get<float>(n1);
+    float* gy_g = c.get<float>(n1);
+    float* gy_g2 = c.get<float>(n1);
+    float* lp = c.get<float>(n1);   // the descriptors behind one zero column, as the forward convolved them
+    float* rp = c.get<float>(n1);
+    float* dwl = c.get<float>(wn);
+    float* dws = c.get<float>(wn);
+    float* dwg = c.get<float>(wn);
+    float* wscratch = c.get<float>(wgrad2d_mfma_scratch_floats(g1, g1));
+    double* bias_scratch = c.get<double>((size_t)channel_sum_splits(g1) * F);
+    float* wf = c.get<float>(3 * wn);
+    float* dxa = c.get<float>(n1);
+    float* dxg = c.get<float>(n1);
+    float* dxg2 = c.get<float>(n1);
+    if (!wgrad2d_mfma_supported(0, 1, 1, no_src(), g1, g1)) return set_error(-1, "matching_bwd: unsupported feature width %d", F);
+    if (!c.plan) {
+        const size_t rows = (size_t)batch * F * h;
+        c.run(launch_l0_combine_bwd(dhat[0], gy_a, gy_gs, gy_g, gy_g2, batch, F, h, w, d_begin, d_count, c.s));
+        c.run(launch_pad_left1(left, lp, rows, w, c.s));
+        c.run(launch_pad_left1(right, rp, rows, w, c.s));
+        // parameters: the bias belongs to the left term; the right half takes the G + G2 gradient for its dx <= 0 taps
+        // and the G gradient alone for dx = +1 (G2 = conv_R without those taps)
+        c.run(launch_channel_sum(gy_a, g1, const_cast<float*>(grads->first.bias), 0, bias_scratch, c.s));
+        c.run(launch_wgrad2d_mfma(plain_src(lp), no_src(), plain_src(gy_a), dwl, g1, g1, 0, wscratch, c.s));
+        c.run(launch_wgrad2d_mfma(plain_src(rp), no_src(), plain_src(gy_gs), dws, g1, g1, 0, wscratch, c.s));
+        c.run(launch_wgrad2d_mfma(plain_src(rp), no_src(), plain_src(gy_g), dwg, g1, g1, 0, wscratch, c.s));
+        c.run(launch_first_weight_grads(dwl, dws, dwg, const_cast<float*>(grads->first.weight), F, F, c.s));
+        for (int k = 0; k < 3; ++k) c.run(launch_flip_weights(l0.w3 + k * wn, wf + k * wn, F, F, 9, c.s));
+    }
+    // descriptors: dx = conv(dz, flipped weights) on the forward kernels, one single-plane launch per term
+    const float* dz3[3] = {gy_a, gy_g, gy_g2};
+    float* dx3[3] = {dxa, dxg, dxg2};
+    for (int k = 0; k < 3; ++k) {
+        PdsConvBlockParams pf{wf + k * wn, nullptr, nullptr, nullptr};
+        conv_block(c, plain_src(dz3[k]), no_src(), g1, pf, F, 1, 1, 0, dx3[k]);
+    }
+    if (!c.plan) {
+        const size_t rows = (size_t)batch * F * h;
+        c.run(launch_crop_left1_add(dxa, nullptr, grad_left, rows, w, c.s));
+        c.run(launch_crop_left1_add(dxg, dxg2, grad_right, rows, w, c.s));
+    }
     if (bytes) *bytes = c.off;
     return c.err;
 }

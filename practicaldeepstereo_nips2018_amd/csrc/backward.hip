@@ -78,8 +78,13 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const double* __re
 // index = (n*C + c)*inner + d.
 __global__ __launch_bounds__(64) void in_bwd_params_kernel(const double* __restrict__ qs, int n_batch, int channels,
                                                            int inner, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
+                                                           float* __restrict__ dbeta, int accumulate,
+                                                           float* __restrict__ dz_amax) {
     const int c = blockIdx.x;
+    // the slots the apply kernel (next launch) collects max |dz| in -- the range certificate of dz (Src::bound) for the
+    // fp16-split weight- and data-gradient kernels -- start from zero
+    if (dz_amax && c == 0)
+        for (int i = threadIdx.x; i < kDzAmaxSlots; i += 64) dz_amax[i] = 0.f;
     double q = 0.0, s = 0.0;
     const int per_c = n_batch * inner;
     for (int i = threadIdx.x; i < per_c; i += 64) {
@@ -104,8 +109,10 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ m1, const float* __restrict__ m2,
-                                                           float* __restrict__ dz, double* __restrict__ bias_partial) {
+                                                           float* __restrict__ dz, double* __restrict__ bias_partial,
+                                                           float* __restrict__ dz_amax) {
     const int nc = blockIdx.z, d = blockIdx.y;
+    float seen = 0.f;
     const int c = nc % geom.c;
     const int grp = per_plane ? nc * geom.d + d : nc;
     const float mu = mean[grp], r = rstd[grp], a = gamma[c] * r, b1 = m1[grp], b2 = m2[grp];
@@ -119,13 +126,30 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
         const float v = tv > 0.f ? dt : dt * kLeakySlope;
         dz[base + i] = v;
         sum += v;
+        seen = fmaxf(seen, fabsf(v));
     }
     __shared__ double red[4];
+    __shared__ float redmax[4];
     const double ws = wave_sum((double)sum);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+    if (dz_amax) seen = wave_max(seen == seen ? seen : __builtin_inff());
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = ws;
+        redmax[threadIdx.x >> 6] = seen;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         bias_partial[((size_t)nc * geom.d + d) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (dz_amax) {
+            // One atomic per WORKGROUP that raises the maximum of its slot (non-negative floats order like their bit
+            // patterns); a coherent read first keeps the workgroups that do not raise it off the atomic unit, and the
+            // workgroups are spread over kDzAmaxSlots slots (memory channels).  A coherent read per WAVE of a kernel
+            // with one element per thread tripled its duration (65 -> 180 us): hence the four elements per thread.
+            const float m = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
+            float* slot = dz_amax + ((blockIdx.z * 7u + blockIdx.y * 13u + blockIdx.x) & (kDzAmaxSlots - 1));
+            if (m > *reinterpret_cast<volatile float*>(slot))
+                atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+        }
+    }
 }
 
 // db[c] (+)= sum over n and the [D * blocks] partials of (n, c)
@@ -157,7 +181,7 @@ size_t in_bwd_scratch_doubles(const Geom& g) {
 
 int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
                   const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
-                  float* dgamma, float* dbeta, float* dbias, int accumulate_params, hipStream_t s) {
+                  float* dgamma, float* dbeta, float* dbias, int accumulate_params, hipStream_t s, float* dz_amax) {
     const unsigned tiles = plane_tiles(geom);
     double* partials = scratch;
     double* qs = scratch + (size_t)geom.n * geom.c * geom.d * tiles * 2;
@@ -171,11 +195,12 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
     hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(groups), dim3(256), 0, s, partials, per_group, count, mean, rstd,
                        m1, m2, qs);
     hipLaunchKernelGGL(in_bwd_params_kernel, dim3(geom.c), dim3(64), 0, s, qs, geom.n, geom.c, inner, dgamma, dbeta,
-                       accumulate_params);
-    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(tiles * 4, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
-                       per_plane, mean, rstd, gamma, m1, m2, dz, bias_partial);
+                       accumulate_params, dz_amax);
+    // (one workgroup per 1024 positions of a plane: four elements per thread)
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(tiles, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
+                       per_plane, mean, rstd, gamma, m1, m2, dz, bias_partial, dz_amax);
     hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(geom.c), dim3(256), 0, s, bias_partial, geom.n, geom.c,
-                       (int)(geom.d * tiles * 4), dbias, accumulate_params);
+                       (int)(geom.d * tiles), dbias, accumulate_params);
     return check_launch("in_bwd");
 }
 

@@ -193,7 +193,9 @@ int launch_in_finalize(const double* partials, int groups, int per_group, double
 size_t in_bwd_scratch_doubles(const Geom& g);
 int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plane, const float* mean,
                   const float* rstd, const float* gamma, double* scratch, float* m1, float* m2, float* dz,
-                  float* dgamma, float* dbeta, float* dbias, int accumulate_params, hipStream_t s);
+                  float* dgamma, float* dbeta, float* dbias, int accumulate_params, hipStream_t s,
+                  float* dz_amax = nullptr);   // (kDzAmaxSlots floats whose maximum is max |dz|: the range certificate of dz)
+constexpr int kDzAmaxSlots = 1024;
 int channel_sum_splits(const Geom& g);
 int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s);
 int launch_flip_weights(const float* w, float* wf, int cout, int cin, int taps, hipStream_t s);
@@ -219,8 +221,14 @@ int launch_wgrad3d_mfma(const Src& a, const Src& b, const float* dz, float* dw, 
                         int accumulate, float* scratch, hipStream_t s);
 bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, const Geom& in, const Geom& out);
 size_t wgrad2d_mfma_scratch_floats(const Geom& in, const Geom& out);
-int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,
+// dz: the gradient with its range certificate (Src::bound; none: plain_src).  With it and certificates on a (and b) the
+// 64 -> 64 layers run the fp16-split kernel of wgrad2d_x3.hip
+int launch_wgrad2d_mfma(const Src& a, const Src& b, const Src& dz, float* dw, const Geom& in, const Geom& out,
                         int accumulate, float* scratch, hipStream_t s);
+bool wgrad2d_x3_supported(const Src& a, const Src& b, const Src& dz, const Geom& in, const Geom& out);   // wgrad2d_x3.hip
+int launch_wgrad2d_x3(const Src& a, const Src& b, const Src& dz, float* partial, int workgroups, const Geom& in,
+                      const Geom& out, hipStream_t s);
+int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, float* dw, int accumulate, hipStream_t s);
 int launch_grad_add(float* dst, const float* src, size_t count, int accumulate, hipStream_t s);
 int launch_grad_reduce_d(float* dst, const float* src, const Geom& g, int accumulate, hipStream_t s);
 int launch_shift_concat_bwd(const float* g, float* dleft, float* dright, int batch, int channels, int h, int w,
@@ -243,8 +251,16 @@ int launch_shift_concat(const float* left, const float* right, float* out, int b
 // Matching layer 0, factorised: x0[b,c,d,y,x] = A[b,c,y,x] + G[b,c,y,x-d] with the
 // right-edge fix.  A = conv_L(L)+bias [B,C,h,w]; G, G2 [B,C,h,w+1] indexed by u+1, u = x-d.
 // A, G, G2: row stride w + 1, channel stride `cstride`; A already points at column 1.
+// amax (may be null): l0_combine_records floats, the largest |x0| of every workgroup (the range certificate of x0)
 int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cstride, float* x0, int batch,
-                      int channels, int h, int w, int d_begin, int d_count, hipStream_t s);
+                      int channels, int h, int w, int d_begin, int d_count, hipStream_t s, float* amax = nullptr);
+int l0_combine_records(int batch, int channels, int d_count);
+// adjoint of l0_combine and the glue of the layer-0 backward (misc.hip; pds_matching_bwd)
+int launch_l0_combine_bwd(const float* g, float* gy_a, float* gy_gs, float* gy_g, float* gy_g2, int batch,
+                          int channels, int h, int w, int d_begin, int d_count, hipStream_t s);
+int launch_first_weight_grads(const float* dwl, const float* dws, const float* dwg, float* dw0, int cout, int cin_half,
+                              hipStream_t s);
+int launch_crop_left1_add(const float* a, const float* b, float* out, size_t rows, int w, hipStream_t s);
 int launch_l0_stack_inputs(const float* left, const float* right, float* out, size_t bc_count, int h, int w,
                            int planes, int pad, hipStream_t s);
 

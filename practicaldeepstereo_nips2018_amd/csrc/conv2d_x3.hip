@@ -431,6 +431,11 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
                         f32x2 tb = __builtin_elementwise_fma(f32x2{acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]}, unscale2, bv2);
                         ta = __builtin_elementwise_max(ta, ta * slope2);
                         tb = __builtin_elementwise_max(tb, tb * slope2);
+#ifdef PDS_X3_EPI_DUMPONLY   // timing ablation (wrong results): the MFMA wave only parks its raw accumulators in LDS
+                        *reinterpret_cast<f32x4*>(wr + nb * 32 * C::EPI_ROW + g * 32) =
+                            f32x4{acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
+                        continue;
+#endif
                         *reinterpret_cast<f32x4*>(wr + nb * 32 * C::EPI_ROW + g * 32) = f32x4{ta[0], ta[1], tb[0], tb[1]};
                         s2[nb][0] += ta;
                         s2[nb][1] += tb;
@@ -441,6 +446,9 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
                 const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (q >> 2) : mb);
                 const int x = cur.x0 + (NARROW ? 4 * (q & 3) : 4 * q);
                 float* po = obase + (size_t)cg * L.cstride + (size_t)y * A.W + x;
+#if defined(PDS_X3_EPI_DUMPONLY) || defined(PDS_X3_EPI_NOSTORE)   // timing ablations (wrong results)
+                if (acc[0][0][0] != 12345.f) continue;
+#endif
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     *reinterpret_cast<f32x4*>(po + (size_t)(8 * j) * L.cstride) =
@@ -609,6 +617,12 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         constexpr unsigned pack_sel = P == 3 ? 0x07060302u : 0x05040100u;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
+#ifdef PDS_X3_NOCONVERT   // timing ablation (wrong results by design): staging as a pure copy -- no InstanceNorm, no split
+            h[0][c] = __builtin_bit_cast(unsigned, x[c]);
+            if (P > 1) h[1][c] = __builtin_bit_cast(unsigned, x[c]) >> 16;
+            if (P > 2) h[P - 1][c] = 0u;
+            continue;
+#endif
             float r = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : (P == 2 ? x3_mul(x[c], A.ascale) : x[c]);
             r = inimg ? r : 0.f;
             if constexpr (P == 3) {

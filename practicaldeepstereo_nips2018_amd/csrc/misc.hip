@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void l0_combine_kernel(const float* __restrict
                                                          const float* __restrict__ G,
                                                          const float* __restrict__ G2, size_t cstride,
                                                          float* __restrict__ x0, int C, int h, int w,
-                                                         int d_begin, int d_count) {
+                                                         int d_begin, int d_count, float* __restrict__ amax) {
+    __shared__ float red[16];
+    float seen = 0.f;   // largest |x0| of this thread: the range certificate of the plain result (Src::bound)
     // grid: x = row tile, y = local disparity, z = b*C + c
     const int bc = blockIdx.z, dl = blockIdx.y;
     const int d = d_begin + dl;
@@ -68,17 +70,110 @@ __global__ __launch_bounds__(256) void l0_combine_kernel(const float* __restrict
             v += (x == w - 1 && d >= 1) ? g2[off] : g[off];
         }
         dst[i] = v;
+        seen = fmaxf(seen, fabsf(v));
+    }
+    if (amax) block_amax_record(seen, amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
+}
+
+// one workgroup per (batch entry, channel, plane): the amax records (one per workgroup) stay a few thousand
+int l0_combine_records(int batch, int channels, int d_count) { return batch * channels * d_count; }
+
+int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cstride, float* x0, int batch,
+                      int channels, int h, int w, int d_begin, int d_count, hipStream_t s, float* amax) {
+    hipLaunchKernelGGL(l0_combine_kernel, dim3(1, d_count, batch * channels), dim3(256), 0, s, A, G, G2, cstride, x0,
+                       channels, h, w, d_begin, d_count, amax);
+    return check_launch("l0_combine");
+}
+
+// ---- adjoint of l0_combine (training: pds_matching_bwd) -----------------------------------------------------------
+// g [B, C, d_count, h, w] = d loss / d x0  ->  the gradients of the three planes x0 was formed from, each as a
+// contiguous single-plane tensor [B*C][h][w + 1] in the column convention of the forward (A at column x + 1, G / G2
+// at column u + 1, u = x - d >= -1):
+//   gA[x]  = sum_d g[d][x]
+//   gG[u]  = sum over the planes d with 0 <= u + d <= w - 1 that read G there (not the x = w - 1, d >= 1 case)
+//   gG2[u] = g[d*][w - 1] for the one plane d* = w - 1 - u >= 1 of this call that read G2[u], else 0
+// Written as  gy_a = gA,  gy_gs = gG + gG2,  gy_g = gG: the weight gradient of the right half is
+// wgrad(R~, gG + gG2) for the taps dx <= 0 and wgrad(R~, gG) for dx = +1 (G2 = conv_R without its dx = +1 taps).
+// One thread per column j = u + 1 = x + 1 of one (b, c, y) row; consecutive threads read consecutive addresses of
+// every plane, so the 425 MB gradient streams through once for gA and once more (mostly from L2) for gG.
+__global__ __launch_bounds__(256) void l0_combine_bwd_kernel(const float* __restrict__ g, float* __restrict__ gy_a,
+                                                             float* __restrict__ gy_gs, float* __restrict__ gy_g,
+                                                             float* __restrict__ gy_g2, int h, int w, int d_begin,
+                                                             int d_count) {
+    const int bc = blockIdx.z, y = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > w) return;
+    const size_t px = (size_t)h * w;
+    const float* row = g + (size_t)bc * d_count * px + (size_t)y * w;
+    const int x = j - 1, u = j - 1;
+    float sa = 0.f, sg = 0.f, sg2 = 0.f;
+    for (int dl = 0; dl < d_count; ++dl) {
+        const int d = d_begin + dl;
+        const float* p = row + (size_t)dl * px;
+        if (x >= 0) sa += p[x];
+        const int xs = u + d;   // the column of plane d that read G[u] (or G2[u])
+        if (xs >= 0 && xs <= w - 1) {
+            const float v = p[xs];
+            if (xs == w - 1 && d >= 1) sg2 += v;
+            else sg += v;
+        }
+    }
+    const size_t o = ((size_t)bc * h + y) * (w + 1) + j;
+    gy_a[o] = sa;
+    gy_gs[o] = sg + sg2;
+    gy_g[o] = sg;
+    gy_g2[o] = sg2;
+}
+
+int launch_l0_combine_bwd(const float* g, float* gy_a, float* gy_gs, float* gy_g, float* gy_g2, int batch,
+                          int channels, int h, int w, int d_begin, int d_count, hipStream_t s) {
+    hipLaunchKernelGGL(l0_combine_bwd_kernel, dim3((w + 1 + 255) / 256, h, batch * channels), dim3(256), 0, s, g, gy_a,
+                       gy_gs, gy_g, gy_g2, h, w, d_begin, d_count);
+    return check_launch("l0_combine_bwd");
+}
+
+// d conv0.weight [cout][2C][9] from the three single-plane weight gradients (see above): left half = dwl, right half =
+// dws for the taps dx <= 0 and dwg for dx = +1
+__global__ __launch_bounds__(256) void first_weight_grads_kernel(const float* __restrict__ dwl,
+                                                                 const float* __restrict__ dws,
+                                                                 const float* __restrict__ dwg, float* __restrict__ dw0,
+                                                                 int cout, int C) {
+    const int total = cout * C * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int t = i % 9;
+        const int c = (i / 9) % C;
+        const int o = i / (9 * C);
+        dw0[((size_t)o * 2 * C + c) * 9 + t] = dwl[i];
+        dw0[((size_t)o * 2 * C + C + c) * 9 + t] = (t % 3 == 2) ? dwg[i] : dws[i];
     }
 }
 
-int launch_l0_combine(const float* A, const float* G, const float* G2, size_t cstride, float* x0, int batch,
-                      int channels, int h, int w, int d_begin, int d_count, hipStream_t s) {
-    const size_t px = (size_t)h * w;
-    unsigned bx = (unsigned)((px + 255) / 256);
-    if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(l0_combine_kernel, dim3(bx, d_count, batch * channels), dim3(256), 0, s, A, G, G2, cstride, x0,
-                       channels, h, w, d_begin, d_count);
-    return check_launch("l0_combine");
+int launch_first_weight_grads(const float* dwl, const float* dws, const float* dwg, float* dw0, int cout, int cin_half,
+                              hipStream_t s) {
+    const int total = cout * cin_half * 9;
+    hipLaunchKernelGGL(first_weight_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dwl, dws, dwg, dw0, cout,
+                       cin_half);
+    return check_launch("first_weight_grads");
+}
+
+// out[r][x] = a[r][x + 1] (+ b[r][x + 1]): drops the zero column the layer-0 planes carry on their left
+__global__ __launch_bounds__(256) void crop_left1_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ out, size_t rows, int w) {
+    const size_t total = rows * (size_t)w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / w;
+        const int x = (int)(i % w);
+        const size_t o = r * (w + 1) + x + 1;
+        out[i] = a[o] + (b ? b[o] : 0.f);
+    }
+}
+
+int launch_crop_left1_add(const float* a, const float* b, float* out, size_t rows, int w, hipStream_t s) {
+    const size_t total = rows * (size_t)w;
+    unsigned bx = (unsigned)((total + 255) / 256);
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(crop_left1_add_kernel, dim3(bx), dim3(256), 0, s, a, b, out, rows, w);
+    return check_launch("crop_left1_add");
 }
 
 // Inputs of the layer-0 convolutions as ONE volume [B*C][planes][h][w+pad]: plane 0 = left descriptor,

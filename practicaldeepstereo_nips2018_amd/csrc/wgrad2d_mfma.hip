@@ -290,8 +290,14 @@ size_t wgrad2d_mfma_scratch_floats(const Geom& in, const Geom& out) {
     return (size_t)wgrad2d_workgroups(in) * out.c * in.c * 9;
 }
 
-int launch_wgrad2d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,
+int launch_wgrad2d_mfma(const Src& a, const Src& b, const Src& dzs, float* dw, const Geom& in, const Geom& out,
                         int accumulate, float* scratch, hipStream_t s) {
+    if (wgrad2d_x3_supported(a, b, dzs, in, out)) {   // fp16-split form on the 16-bit matrix pipe (wgrad2d_x3.hip)
+        const int wgs = wgrad2d_workgroups(in);
+        if (int rc = launch_wgrad2d_x3(a, b, dzs, scratch, wgs, in, out, s)) return rc;
+        return launch_wgrad_reduce_f32(scratch, (size_t)out.c * in.c * 9, wgs, dw, accumulate, s);
+    }
+    const float* dz = dzs.p;
     WArgs A;
     A.a = a;
     A.b = b;

@@ -1,0 +1,291 @@
+// Weight gradient of the 64 -> 64 (and 64k -> 64) 3x3 convolutions of MatchingOperation / the embedding on the 16-bit
+// matrix pipe (round 4; reference: autograd through network_blocks.py:47-58, driven by pds_trainer.py:40-46):
+//   dW[oc][c][tap] = sum over (n, d, y, x) of dz[oc][p] * xhat[c][p + tap]
+// wgrad2d_mfma.hip runs this contraction on v_mfma_f32_16x16x4_f32 (1/16 of the 16-bit MFMA rate): 11 launches x 1.2 ms =
+// a third of the config-5 training step.  Here both operands are split into two fp16 parts exactly as in conv2d_x3.hip
+// (hi = fp16(v), lo = fp16(v - hi): 22 significand bits) and a product is hi*lo + lo*hi + hi*hi on
+// v_mfma_f32_16x16x16_f16 with fp32 accumulation.  Both operands are pre-scaled by powers of two derived from the data:
+// xhat by its range certificate (common.hpp Src::bound), dz by max|dz|, which the InstanceNorm backward that writes dz
+// collects (backward.hip in_bwd_apply_kernel); the partial sums are multiplied back when they are written.  A layer
+// without both certificates keeps the exact-fp32 kernel.
+//
+// GEMM view: M = 64 output channels, N = (input channel, tap), K = positions, 16 per MFMA.
+//   work item   2 rows x 32 columns of one (n, d) plane = four K-steps; persistent workgroups stride over the items, keep
+//               their partial dW in registers and write ONE partial per workgroup (fp32; a second kernel sums the
+//               partials in fp64 in a fixed order: deterministic).
+//   workgroup   4 waves, two workgroups per CU (67.6 KB of LDS each): one stages while the other multiplies.  Wave w owns
+//               the 16 input channels of block w, all nine taps and all 64 output channels: 4 x 9 accumulator tiles =
+//               144 registers.  The B fragments of a wave are its own; the A fragments (dz) are shared by the four waves.
+//   LDS         xhat [part][64 ch][4 rows][40] fp16, S[j] holds column x0 - 4 + j, so that an aligned 16-byte global
+//               load lands as one aligned 8-byte LDS write per part; dz [part][64 oc][2 rows x 32].  Channel strides
+//               == 2 dwords (mod 32): the 16 lanes x 8 bytes of a fragment read cover all 32 banks once.
+//   taps        a lane's B fragment is four CONSECUTIVE positions of one channel; the three kernel columns are the
+//               windows S[b + 3 + dx .. b + 6 + dx]: three aligned 8-byte reads (b, b + 4, b + 8) per part and three
+//               v_alignbit give all of them -- no unaligned LDS access, no re-staging per tap.
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int TR = 2, TWG = 32;            // rows x columns of positions per work item
+constexpr int XR = TR + 2;                 // staged xhat rows
+constexpr int RSX = 40;                    // xhat row stride (fp16 elements): columns x0 - 4 .. x0 + 35
+constexpr int CSX = XR * RSX + 36;         // xhat channel stride: 196 == 4 (mod 64) elements = 2 dwords (mod 32)
+constexpr int CSD = TR * TWG + 4;          // dz channel stride: 68 == 4 (mod 64)
+constexpr int CG = 64;                     // input channels per workgroup (grid.y walks further groups)
+constexpr int XPART = CG * CSX, DPART = 64 * CSD;   // elements of one split part
+constexpr int LDS_BYTES = (2 * XPART + 2 * DPART) * 2;
+static_assert(CSX % 64 == 4 && CSD % 64 == 4, "conflict-free fragment reads");
+static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct WX3Args {
+    Src a, b;
+    const float* __restrict__ dz;
+    const float* __restrict__ dz_bound;
+    int dz_bound_n;
+    float* __restrict__ partial;  // [workgroup][64][Cin][9]
+    int N, Cin, D, H, W;
+    int items, segs, rowpairs;
+};
+
+__device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)v[i];
+        lo[i] = (_Float16)(v[i] - (float)hi[i]);
+    }
+}
+
+__device__ __forceinline__ f16x4 as_f16x4(unsigned lo, unsigned hi) { return __builtin_bit_cast(f16x4, u32x2{lo, hi}); }
+
+}  // namespace
+
+template <bool HAS_B>
+__global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    _Float16* xs = reinterpret_cast<_Float16*>(lds_raw);     // [2][CG][CSX]
+    _Float16* dl = xs + 2 * XPART;                           // [2][64][CSD]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the wave's input-channel block
+    const int cg0 = blockIdx.y * CG;
+    const size_t plane = (size_t)A.H * A.W;
+
+    // operand scales (powers of two): xhat by the sources' range certificates, dz by its recorded maximum
+    float bound = block_bound(A.a.bound, A.a.bound_n, reinterpret_cast<float*>(lds_raw));
+    if (HAS_B) bound += block_bound(A.b.bound, A.b.bound_n, reinterpret_cast<float*>(lds_raw));
+    const float as = pow2_scale(bound, kHalfTarget);
+    const float ds = pow2_scale(block_bound(A.dz_bound, A.dz_bound_n, reinterpret_cast<float*>(lds_raw)), kHalfTarget);
+    const float unscale = (1.f / as) * (1.f / ds);
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses (elements): A: row m = lane & 15 of output block mb, positions 4 kg ..; B: channel n = lane & 15
+    const int frag_k = 4 * (lane >> 4);
+    const _Float16* arow = dl + (lane & 15) * CSD + frag_k;
+    const _Float16* brow = xs + (wave * 16 + (lane & 15)) * CSX + frag_k;
+
+    for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
+        int r = item;
+        const int seg = r % A.segs;
+        r /= A.segs;
+        const int ry = r % A.rowpairs;
+        r /= A.rowpairs;
+        const int d = r % A.D;
+        const int n = r / A.D;
+        const int x0 = seg * TWG, y0 = ry * TR;
+
+        // ---- stage xhat: 64 channels x 4 rows x 10 aligned quads (columns x0 - 4 .. x0 + 35), 10 quads per thread ----
+        // A run of 10 consecutive threads covers one (channel, row): 160 contiguous bytes.  The deferred InstanceNorm,
+        // the skip sum, the literal zero padding and the fp16 split are applied on the way to LDS.
+        // (batches of two quads per source: the 144 accumulator registers leave room for no more in flight, and the
+        // other workgroup of the CU covers the load latency with its MFMAs)
+        constexpr int BATCH = 2;
+#pragma unroll 1
+        for (int half = 0; half < 10 / BATCH; ++half) {
+            f32x4 qa[BATCH], qb[HAS_B ? BATCH : 1];
+            float sa[BATCH], ha[BATCH], sb2[BATCH], hb2[BATCH];
+            bool ok[BATCH];
+            int dst[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int slot = tid + (half * BATCH + j) * THREADS;     // < 2560
+                const int q = slot % 10, cr = slot / 10, c = cr / XR, rr = cr - c * XR;
+                const int x = x0 - 4 + 4 * q, y = y0 - 1 + rr;
+                ok[j] = x >= 0 && x < A.W && y >= 0 && y < A.H;
+                const int xc = min(max(x, 0), A.W - 4), yc = min(max(y, 0), A.H - 1);
+                const int ch = cg0 + c;
+                const size_t off = ((size_t)(n * A.Cin + ch) * A.D + d) * plane + (size_t)yc * A.W + xc;
+                qa[j] = *reinterpret_cast<const f32x4*>(A.a.p + off);
+                if (HAS_B) qb[j] = *reinterpret_cast<const f32x4*>(A.b.p + off);
+                sa[j] = 1.f;
+                ha[j] = 0.f;
+                if (A.a.scale) {
+                    const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                    sa[j] = A.a.scale[g];
+                    ha[j] = A.a.shift[g];
+                }
+                sb2[j] = 1.f;
+                hb2[j] = 0.f;
+                if (HAS_B && A.b.scale) {
+                    const int g = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
+                    sb2[j] = A.b.scale[g];
+                    hb2[j] = A.b.shift[g];
+                }
+                dst[j] = c * CSX + rr * RSX + 4 * q;
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaf(sa[j], qa[j][e], ha[j]);
+                    if (HAS_B) t += fmaf(sb2[j], qb[j][e], hb2[j]);
+                    v[e] = ok[j] ? t * as : 0.f;
+                }
+                f16x4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<f16x4*>(xs + dst[j]) = hi;
+                *reinterpret_cast<f16x4*>(xs + XPART + dst[j]) = lo;
+            }
+        }
+        // ---- stage dz: 64 output channels x 2 rows x 8 quads, 4 quads per thread -----------------------------------
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x4 qz[2];
+            bool ok[2];
+            int dst[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int slot = tid + (half * 2 + j) * THREADS;     // < 1024
+                const int q = slot & 7, rr = (slot >> 3) & 1, oc = slot >> 4;
+                const int x = x0 + 4 * q, y = y0 + rr;
+                ok[j] = x < A.W && y < A.H;
+                const int xc = min(x, A.W - 4), yc = min(y, A.H - 1);
+                qz[j] = *reinterpret_cast<const f32x4*>(A.dz + ((size_t)(n * 64 + oc) * A.D + d) * plane + (size_t)yc * A.W + xc);
+                dst[j] = oc * CSD + rr * TWG + 4 * q;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok[j] ? qz[j][e] * ds : 0.f;
+                f16x4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<f16x4*>(dl + dst[j]) = hi;
+                *reinterpret_cast<f16x4*>(dl + DPART + dst[j]) = lo;
+            }
+        }
+        __syncthreads();
+
+        // ---- four K-steps of 16 positions: (row r2, half hs) ----------------------------------------------------------
+#pragma unroll 1
+        for (int ks = 0; ks < TR * 2; ++ks) {
+            const int r2 = ks >> 1, hs = ks & 1;
+            f16x4 ah[4], al[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ah[m] = *reinterpret_cast<const f16x4*>(arow + m * 16 * CSD + r2 * TWG + 16 * hs);
+                al[m] = *reinterpret_cast<const f16x4*>(arow + DPART + m * 16 * CSD + r2 * TWG + 16 * hs);
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const _Float16* bp = brow + (r2 + dy) * RSX + 16 * hs;
+                // three aligned groups per part: S[b .. b+3], S[b+4 .. b+7], S[b+8 .. b+11]
+                u32x2 g[2][3];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) g[p][k] = *reinterpret_cast<const u32x2*>(bp + p * XPART + 4 * k);
+                f16x4 bf[2][3];   // [part][dx]: window S[b + 3 + dx .. b + 6 + dx]
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const unsigned mid = __builtin_amdgcn_alignbit(g[p][1][1], g[p][1][0], 16);   // {G1.e1, G1.e2}
+                    bf[p][0] = as_f16x4(__builtin_amdgcn_alignbit(g[p][1][0], g[p][0][1], 16), mid);   // {G0.e3, G1.e0..e2}
+                    bf[p][1] = as_f16x4(g[p][1][0], g[p][1][1]);                                        // G1
+                    bf[p][2] = as_f16x4(mid, __builtin_amdgcn_alignbit(g[p][2][0], g[p][1][1], 16));    // {G1.e1..e3, G2.e0}
+                }
+                // small partial products first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const f16x4 av = prod == 1 ? al[m] : ah[m];
+                            const f16x4 bv = prod == 0 ? bf[1][dx] : bf[0][dx];
+                            acc[m][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc[m][dy * 3 + dx], 0, 0, 0);
+                        }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one partial per workgroup: [64][Cin][9] -------------------------------------------------------------------
+    float* dst = A.partial + (size_t)blockIdx.x * 64 * A.Cin * 9;
+    const int c = cg0 + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int oc = m * 16 + 4 * (lane >> 4) + rr;
+                dst[((size_t)oc * A.Cin + c) * 9 + t] = acc[m][t][rr] * unscale;
+            }
+}
+
+bool wgrad2d_x3_supported(const Src& a, const Src& b, const Src& dz, const Geom& in, const Geom& out) {
+    static const bool enabled = []() {  // PDS_WGRAD2D_X3=0 keeps the exact-fp32 kernel (A/B, debugging)
+        const char* e = getenv("PDS_WGRAD2D_X3");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled || out.c != 64 || in.c % CG != 0 || (in.w & 3) != 0) return false;
+    if (!dz.bound || dz.bound_n <= 0 || !a.bound || a.bound_n <= 0 || (b.p && (!b.bound || b.bound_n <= 0 || b.bcast_d)))
+        return false;
+    if ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(b.p) | reinterpret_cast<uintptr_t>(dz.p)) & 15)
+        return false;
+    return true;
+}
+
+int launch_wgrad2d_x3(const Src& a, const Src& b, const Src& dz, float* partial, int workgroups, const Geom& in,
+                      const Geom& out, hipStream_t s) {
+    (void)out;
+    WX3Args A;
+    A.a = a;
+    A.b = b;
+    A.dz = dz.p;
+    A.dz_bound = dz.bound;
+    A.dz_bound_n = dz.bound_n;
+    A.partial = partial;
+    A.N = in.n;
+    A.Cin = in.c;
+    A.D = in.d;
+    A.H = in.h;
+    A.W = in.w;
+    A.segs = (in.w + TWG - 1) / TWG;
+    A.rowpairs = (in.h + TR - 1) / TR;
+    A.items = in.n * in.d * A.rowpairs * A.segs;
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    if (DeviceOnce once{attr_done}) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    const dim3 grid(workgroups, in.c / CG);
+    if (b.p) hipLaunchKernelGGL((wgrad2d_x3_kernel<true>), grid, dim3(THREADS), LDS_BYTES, s, A);
+    else hipLaunchKernelGGL((wgrad2d_x3_kernel<false>), grid, dim3(THREADS), LDS_BYTES, s, A);
+    return check_launch("wgrad2d_x3");
+}
+
+}  // namespace pds

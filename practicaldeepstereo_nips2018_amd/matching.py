@@ -216,17 +216,67 @@ class Matching(_lib.FrozenWeightsMixin, nn.Module):
                 return _FusedMatchingFunction.apply(self, left, right, begin, count,
                                                     *operation.parameters())
             _lib.warn_eval_with_grad(self)
-            # Training: the differentiable route is shift/concat -> MatchingOperation over all planes at once
-            # (the statistics of InstanceNorm2d are per image, so planes may be folded into the batch).
-            batch = left.size(0)
-            concatenated = _ShiftConcatFunction.apply(left, right, begin, count)
-            folded = operation(concatenated.view(count * batch, *concatenated.shape[2:]))
-            return folded.view(count, batch, *folded.shape[1:]).permute(1, 2, 0, 3, 4).contiguous()
+            # Training: the differentiable route keeps the factorised first layer (no [D', B, 128, h, w] concat) and
+            # every layer output for the backward pass (pds_matching_train_fwd / pds_matching_bwd).
+            return _TrainMatchingFunction.apply(self, left, right, begin, count, *operation.parameters())
         return self._forward_generic(left, right, begin, count)
 
     def _forward_generic(self, left, right, begin, count):
         concatenated = _ShiftConcatFunction.apply(left, right, begin, count)
         return torch.stack([self._operation(plane) for plane in concatenated.unbind(0)], dim=2)
+
+
+class _TrainMatchingFunction(torch.autograd.Function):
+    """pds_matching_train_fwd / pds_matching_bwd: Matching + MatchingOperation under autograd (matching.py:34-63 as
+    pds_trainer.py:40-46 drives it).  The forward runs in a workspace of its own, kept until backward; the gradient
+    of the first (linear) layer is taken through its factorisation: one reduction of d loss / d x0 over the disparity
+    planes, then single-plane convolution gradients."""
+
+    @staticmethod
+    def forward(ctx, module, left, right, begin, count, *unused_parameters):
+        lib = _lib.load()
+        operation = module._operation
+        left, right = left.contiguous(), right.contiguous()
+        batch, _, h, w = left.shape
+        params, keep = operation.native_params()
+        out = torch.empty((batch, operation.number_of_signature_features, count, h, w),
+                          dtype=torch.float32, device=left.device)
+        nbytes = lib.pds_matching_train_workspace_bytes(ctypes.byref(params), batch, h, w, count)
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=left.device)
+        with torch.cuda.device(left.device):
+            _lib.check(lib.pds_matching_train_fwd(
+                ctypes.byref(params), _lib.ptr(left), _lib.ptr(right), _lib.ptr(out), batch, h, w, begin, count,
+                _lib.ptr(ws), ws.numel(), _lib.stream_handle(left.device)), 'pds_matching_train_fwd')
+        del keep
+        ctx.module = module
+        ctx.geometry = (begin, count)
+        ctx.forward_workspace = ws
+        ctx.save_for_backward(left, right)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        operation = ctx.module._operation
+        left, right = ctx.saved_tensors
+        begin, count = ctx.geometry
+        batch, _, h, w = left.shape
+        grad_out = grad_out.contiguous()
+        params, keep = operation.native_params()
+        grads, tensor_of = _lib.gradient_buffers(operation)
+        grad_params, keep_grads = operation.native_params(tensor_of)
+        grad_left, grad_right = torch.empty_like(left), torch.empty_like(right)
+        nbytes = lib.pds_matching_bwd_workspace_bytes(ctypes.byref(params), batch, h, w, count)
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=left.device)
+        fws = _lib.saved_workspace(ctx, 'matching')
+        with torch.cuda.device(left.device):
+            _lib.check(lib.pds_matching_bwd(
+                ctypes.byref(params), ctypes.byref(grad_params), _lib.ptr(left), _lib.ptr(right), _lib.ptr(grad_out),
+                _lib.ptr(grad_left), _lib.ptr(grad_right), batch, h, w, begin, count, _lib.ptr(fws), fws.numel(),
+                _lib.ptr(ws), ws.numel(), _lib.stream_handle(left.device)), 'pds_matching_bwd')
+        del keep, keep_grads
+        ctx.forward_workspace = None
+        return (None, grad_left, grad_right, None, None) + tuple(grads[id(p)] for p in operation.parameters())
 
 
 class _FusedMatchingFunction(torch.autograd.Function):

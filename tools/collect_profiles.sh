@@ -1,12 +1,12 @@
 #!/bin/bash
-# Collects the round's judged evidence on the GPU box into gpurun_out/profiles_${ROUND:-r03}/ (copy to profiles/ afterwards):
+# Collects the round's judged evidence on the GPU box into gpurun_out/profiles_${ROUND:-r04}/ (copy to profiles/ afterwards):
 #   kernels_seq.txt     rocprofv3 --kernel-trace --stats of sequential pairs (un-overlapped kernel durations)
 #   kernels_3streams.txt the default bench schedule (three streams)
 #   pmc.txt             PMC counters (separate passes, FETCH_SIZE / WRITE_SIZE apart) of every kernel of the hot path
 #   bench_line.json     the default bench.py line
 #   train_step_kernels.txt  kernel summary of the full-size training step (tools/train_step_bench.py)
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/profiles_${ROUND:-r03}
+OUT=$PWD/gpurun_out/profiles_${ROUND:-r04}
 rm -rf $OUT; mkdir -p $OUT
 SEQ="bench.py --steps 5 --warmup 1 --kernel-reps 2 --no-cpu-baseline --no-pipeline --windows 1"
 rocprofv3 --kernel-trace --stats -d $OUT/trace_seq -- python $SEQ > $OUT/seq.log 2>&1

@@ -7,7 +7,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 src = os.path.join(ROOT, 'gpurun_out', 'profiles_' + tag)
 dst = os.path.join(ROOT, 'profiles')
 for a, b in (('bench_line.json', 'bench_line.json'), ('kernels_seq.txt', 'kernels_sequential.txt'),
@@ -18,7 +18,16 @@ blocks = re.split(r'\n(?=\S)', open(os.path.join(dst, tag + '_pmc_all_kernels.tx
 block = [b for b in blocks if 'conv2d_x3_kernel<2, true>' in b.split('\n')[0] and '131072' in b.split('\n')[0]][0]
 values = {m.group(1): float(m.group(2)) for m in re.finditer(r'^\s+(\w+)\s+([\d.e+]+)\s*$', block, re.M)}
 path = os.path.join(dst, tag + '_conv64_pmc.json')
+if not os.path.exists(path):   # the fixed fields (correction rule, algorithmic bytes) carry over from the last round
+    import glob
+    shutil.copy(sorted(glob.glob(os.path.join(dst, 'r[0-9][0-9]_conv64_pmc.json')))[-1], path)
 record = json.load(open(path))
+# bench.py compares this with the source it runs on and reports `traffic_stale` when they differ
+import hashlib
+record['kernel_source_sha256'] = hashlib.sha256(open(os.path.join(
+    ROOT, 'practicaldeepstereo_nips2018_amd', 'csrc', 'conv2d_x3.hip'), 'rb').read()).hexdigest()
+record['source'] = ('profiles/%s_pmc_all_kernels.txt (tools/collect_profiles.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and '
+                    'WRITE_SIZE in separate passes; per launch, mean over the launches of that run)' % tag)
 record['kernel'] = block.split('\n')[0].strip()
 for key in ('TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES',
             'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'):
