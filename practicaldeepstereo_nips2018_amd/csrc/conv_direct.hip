@@ -379,17 +379,19 @@ int launch_deconv_direct(const DeconvLayer& L, hipStream_t s) {
 // InstanceNorm statistics: reduce partial records, emit folded (scale, shift) per group.
 // Biased variance, eps 1e-5 (torch.nn.InstanceNorm defaults, network_blocks.py:58,72,85).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restrict__ partials, int per_group,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int channels,
-                                                          int inner, float* __restrict__ scale,
-                                                          float* __restrict__ shift, float* __restrict__ mean_out,
-                                                          float* __restrict__ rstd_out, float* __restrict__ bound_out,
-                                                          unsigned* __restrict__ nonfinite) {
+// One WAVE per group (round 4; a 256-thread workgroup with two barriers took 5.4 us per launch, 22 launches per pair): the
+// lanes stride over the group's records, one shuffle reduction, lane 0 finishes.
+__global__ __launch_bounds__(64) void in_finalize_kernel(const double* __restrict__ partials, int per_group,
+                                                         double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int channels,
+                                                         int inner, float* __restrict__ scale,
+                                                         float* __restrict__ shift, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, float* __restrict__ bound_out,
+                                                         unsigned* __restrict__ nonfinite) {
     const int g = blockIdx.x;
     // Range certificate of the normalised tensor (common.hpp, Src::bound): a group of `count` values with unit
     // (biased) variance has no z-score beyond sqrt(count - 1), so |gamma| sqrt(count) + |beta| bounds every value.
-    if (bound_out && g == 0 && threadIdx.x < 64) {
+    if (bound_out && g == 0) {
         float m = 0.f;
         const float root = sqrtf((float)count);
         for (int c = threadIdx.x; c < channels; c += 64) {
@@ -399,24 +401,17 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
         m = wave_max(m);
         if (threadIdx.x == 0) *bound_out = m;
     }
-    const double* p = partials + (size_t)g * per_group * 2;
+    const double2* p = reinterpret_cast<const double2*>(partials) + (size_t)g * per_group;
     double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < per_group; i += 256) {
-        s += p[2 * i];
-        q += p[2 * i + 1];
+#pragma unroll 4
+    for (int i = threadIdx.x; i < per_group; i += 64) {
+        const double2 r = p[i];
+        s += r.x;
+        q += r.y;
     }
-    __shared__ double red[4][2];
     s = wave_sum(s);
     q = wave_sum(q);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        red[wave][0] = s;
-        red[wave][1] = q;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        s = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        q = red[0][1] + red[1][1] + red[2][1] + red[3][1];
         const double mean = s / count;
         double var = q / count - mean * mean;
         // a NaN / inf reached this layer (or it overflowed): counted in host-mapped memory, pds_nonfinite_statistics()
@@ -478,7 +473,7 @@ long long nonfinite_statistics(int reset) {
 int launch_in_finalize(const double* partials, int groups, int per_group, double count, const float* gamma,
                        const float* beta, int channels, int inner, float* scale, float* shift, float* mean,
                        float* rstd, hipStream_t s, float* bound) {
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(groups), dim3(256), 0, s, partials, per_group, count, gamma,
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(groups), dim3(64), 0, s, partials, per_group, count, gamma,
                        beta, channels, inner, scale, shift, mean, rstd, bound, nonfinite_counter(s));
     return check_launch("in_finalize");
 }
