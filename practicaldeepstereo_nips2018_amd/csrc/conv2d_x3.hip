@@ -613,6 +613,42 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         }
         const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
         const bool inimg = y >= 0 && y < A.H && xx >= 0 && xx < A.W;
+#if !defined(PDS_X3_NOCONVERT) && !defined(PDS_X3_NOPKCVT)
+        if constexpr (P == 2) {
+            // fp16 split of a PAIR of channels with the packed conversion of gfx950 (round to nearest even, like the
+            // scalar one): hi pair = cvt_pk(r0, r1) lands in slot order (the odd channel above the even one), the halves
+            // are widened again (the upper one through SDWA), the remainders (exact in fp32) converted as a pair --
+            // 6 instructions per pair instead of 4 conversions + 2 widenings + 2 subtractions + 2 byte permutes.
+            u32x4 whi[2], wlo[2];
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                const int c = 2 * pr;
+                float r0 = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : x3_mul(x[c], A.ascale);
+                float r1 = NORM ? x3_fma(cs[c >> 2][(c & 3) + 1], x[c + 1], ch[c >> 2][(c & 3) + 1]) : x3_mul(x[c + 1], A.ascale);
+                r0 = inimg ? r0 : 0.f;
+                r1 = inimg ? r1 : 0.f;
+                unsigned hi, lo;
+                float f0, f1;
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(r0), "v"(r1));
+                asm("v_cvt_f32_f16 %0, %1" : "=v"(f0) : "v"(hi));
+                asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(hi));
+                float d0, d1;
+                asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(r0), "v"(f0));
+                asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(r1), "v"(f1));
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+                whi[pr >> 2][pr & 3] = hi;
+                wlo[pr >> 2][pr & 3] = lo;
+            }
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    *reinterpret_cast<u32x4*>(buf + (0 * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = whi[g];
+                    *reinterpret_cast<u32x4*>(buf + (1 * 2 + g) * (PIX * 16) + third * (THIRD_PIX * 16) + lds_item) = wlo[g];
+                }
+            }
+            return;
+        }
+#endif
         unsigned h[P][16];   // part p of channel c: P = 3 in the high half, P = 2 in the low half of the dword
         constexpr unsigned pack_sel = P == 3 ? 0x07060302u : 0x05040100u;
 #pragma unroll
