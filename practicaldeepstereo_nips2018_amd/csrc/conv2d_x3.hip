@@ -50,7 +50,7 @@
 //   epilogue    bias, LeakyReLU, per-(plane, channel) sum / sum of squares -> one fp64 record per tile (the deferred
 //               InstanceNorm of common.hpp), folded by the staging waves during the next tile.  Stores: the fp16 form
 //               transposes every M block through a wave-private LDS area so that a store instruction writes 8 channels x
-//               128 contiguous bytes (PDS_X3_EPI_LDS=0 and the bf16 form: 16 bytes per lane straight from the D fragment,
+//               128 contiguous bytes (the bf16 form and border tiles: 16 bytes per lane straight from the D fragment,
 //               i.e. 32-byte pieces in 32 channel planes per instruction -- 10 400 against 7 100 cycles per tile).
 #include <type_traits>
 
@@ -999,11 +999,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     A.tiles_x_full = A.tiles_x - ((rem != 0 && rem <= 16) ? 1 : 0);
     A.planes = A.N * A.D;
     A.nks = A.Cin / 16;
-    static const bool epi_lds = []() {   // PDS_X3_EPI_LDS=0: direct 16-byte stores from the D fragment (A/B)
-        const char* e = getenv("PDS_X3_EPI_LDS");
-        return !(e && e[0] == '0');
-    }();
-    A.epi_lds = epi_lds ? 1 : 0;
+    A.epi_lds = 1;   // (round 3's PDS_X3_EPI_LDS=0 switch -- direct stores from the D fragment, 5 % slower -- is gone)
     A.bound = L.a.bound;
     A.bound_n = L.a.bound_n;
     if (fp16 && (!A.bound || A.bound_n <= 0)) return set_error(-1, "conv2d_x3: fp16 form without a range bound");

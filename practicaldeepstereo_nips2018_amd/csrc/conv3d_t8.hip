@@ -410,8 +410,23 @@ int conv3d_t8_records(const Geom& o) {
     return per_n < 8 ? 8 : per_n;
 }
 
+bool conv3d_t8x_enabled();   // conv3d_t8x.hip: the same layer on the 16-bit matrix pipe (split operands)
+int launch_conv3d_t8x(const ConvLayer& L, int nb, int tiles_x, int tiles_y, int tiles, int records, hipStream_t s);
+
 int launch_conv3d_t8(const ConvLayer& L, hipStream_t s) {
     const int nb = t8_choose_nb(L.out_g.w);
+    // Only layers whose sources all carry range certificates take the fp16-split kernel (measured at config 2: 79 us
+    // against 95-104 for the two-source layer of the last expansion block).  Its range-safe bf16 form (six products, 12
+    // conversion instructions per value) measured SLOWER than the exact-fp32 kernel below for the un-certified first
+    // layer (the caller's matching signatures): 112 against 85 us -- PDS_CONV3D_T8X=2 forces it for tests.
+    const bool certified = L.a.bound && L.a.bound_n > 0 && (!L.b.p || (L.b.bound && L.b.bound_n > 0));
+    static const bool force_x = []() {
+        const char* e = getenv("PDS_CONV3D_T8X");
+        return e && e[0] == '2';
+    }();
+    if (conv3d_t8x_enabled() && (certified || (force_x && !L.b.p)))
+        return launch_conv3d_t8x(L, nb, (L.in.w + 16 * nb - 1) / (16 * nb), (L.in.h + 3) / 4, t8_tiles(L.out_g, nb),
+                                 conv3d_t8_records(L.out_g), s);
     T8Args A;
     A.a = L.a;
     A.b = L.b;

@@ -12,7 +12,6 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
-    {'PDS_X3_EPI_LDS': '0'},                 # conv2d_x3 (fp16 form): direct stores from the D fragment
     {'PDS_X3_FP16': '0'},                    # conv2d_x3 on its range-safe form everywhere (three bf16 parts, six products)
     {'PDS_X3': '0'},                         # exact-fp32 MFMA kernels (Winograd domain) instead of the split-operand kernel
     {'PDS_X3': '0', 'PDS_WINOGRAD': '0'},    # ... and the direct exact-fp32 MFMA kernel
@@ -21,6 +20,8 @@ SWITCHES = [
     {'PDS_MATCHING_COLUMNS': '0'},  # whole-plane form of the layer-0 / layer-1 factorisation (3 + 5 planes)
     {'PDS_CONV3D_XCD_MAP': '0'},
     {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0', 'PDS_CONV3D_KS': '0'},   # generic MFMA kernels for all hourglass layers
+    {'PDS_CONV3D_T8X': '0'},        # exact-fp32 kernel for the 8 -> 8 full-resolution layers (round 3)
+    {'PDS_CONV3D_T8X': '2'},        # ... the split-operand kernel also for the un-certified first layer (bf16 x 3 form)
     {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
     {'PDS_CONV2D_T8W': '0'},        # ... its 16 x 32-tile form instead of the full-width one
 ]
