@@ -22,6 +22,14 @@
 //               barrier per tile.  Out-of-volume inputs read as zero through the buffer range check.
 //   epilogue    accumulators start at the bias; LeakyReLU; scatter to (2c + 1 + p); per-lane fp32 statistics of its
 //               four channels, reduced in fp64 to ONE record per (workgroup, channel).
+//
+// Round 4, template flag X: the same contraction on v_mfma_f32_16x16x16_f16 with split fp32 operands (as conv2d_x3.hip):
+// 56 of the 117 us of the (8, 4) layer were fp32 matrix time, and unlike the 8 -> 8 layers (conv3d_t8x.hip) the input of a
+// transposed convolution is an eighth of its output, so the conversion of the staged values is cheap.  K = 16 = the four
+// (yi, xi) corners (k group = lane >> 4) x FOUR input channels (a lane's four consecutive k): the LDS tile holds
+// [part][channel group][z][y][x][4 ch] fp16, a B fragment is one aligned 8-byte slot, one MFMA x three partial products
+// covers what four fp32 MFMAs did.  Operand scales are powers of two from max|w| (reduced per workgroup) and from the
+// range certificate of the source (common.hpp Src::bound); a source without one keeps the exact-fp32 form.
 #include <atomic>
 
 #include "common.hpp"
@@ -32,6 +40,15 @@ namespace {
 
 constexpr int DC_THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void cell_split(const float (&v)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)v[i];
+        lo[i] = (_Float16)(v[i] - (float)hi[i]);
+    }
+}
 
 struct CellArgs {
     Src a;
@@ -66,11 +83,13 @@ struct CellCfg {
 
 }  // namespace
 
-// NORM: the source carries a deferred InstanceNorm
-template <int CIN, int COUT, int MBW, int TZ, int TY, int NB, bool NORM>
+// NORM: the source carries a deferred InstanceNorm; X: fp16-split operands on the 16-bit matrix pipe (header comment)
+template <int CIN, int COUT, int MBW, int TZ, int TY, int NB, bool NORM, bool X>
 __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const CellArgs A) {
     using C = CellCfg<CIN, COUT, MBW, TZ, TY, NB>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // X: one buffer = [part 2][CIN / 4 groups][CS slots of 8 bytes] = the same CIN * CS * 4 bytes as the fp32 tile
+    constexpr int XPART = (CIN / 4) * C::CS * 8;   // bytes of one split part
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,11 +128,21 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
         az += step_z + carry;
     };
 
+    float ws = 1.f, as = 1.f;
+    if constexpr (X) {   // power-of-two operand scales (every thread; before anything else touches the LDS scratch)
+        float wm = 0.f;
+        for (int i = tid; i < CIN * COUT * 64; i += DC_THREADS) wm = fmaxf(wm, fabsf(A.w[i]));
+        wm = block_max(wm, lds);
+        const float bound = block_bound(A.a.bound, A.a.bound_n, lds);
+        ws = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_scale(wm, kHalfTarget))));
+        as = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_scale(bound, kHalfTarget))));
+    }
+    const float unscale = (1.f / ws) * (1.f / as);
     float sa[CIN], ha[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
-        sa[c] = (NORM && A.a.scale) ? A.a.scale[nb * CIN + c] : 1.f;
-        ha[c] = (NORM && A.a.scale) ? A.a.shift[nb * CIN + c] : 0.f;
+        sa[c] = ((NORM && A.a.scale) ? A.a.scale[nb * CIN + c] : 1.f) * as;   // (as = 1 in the exact form)
+        ha[c] = ((NORM && A.a.scale) ? A.a.shift[nb * CIN + c] : 0.f) * as;
     }
 
     // ---- staging positions (halo tile of (TZ+1) x (TY+1) x (16 NB + 1) inputs per channel) -----------------------
@@ -157,6 +186,24 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
             buf[c * C::CS + lo[k]] = v;
         }
     };
+    // X: the four channels of group cg at every position of the thread -> one 8-byte slot per part
+    auto stash_group = [&](int cg, float* buf) {
+        unsigned char* base = reinterpret_cast<unsigned char*>(buf) + cg * C::CS * 8;
+#pragma unroll
+        for (int k = 0; k < C::POS; ++k) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = NORM ? fmaf(sa[4 * cg + c], va[4 * cg + c][k], ha[4 * cg + c]) : va[4 * cg + c][k] * as;
+                if (NORM) t = ((inside_bits >> k) & 1u) ? t : 0.f;   // (a plain source: the range check delivered the zeros)
+                v[c] = t;
+            }
+            f16x4 hi, lo4;
+            cell_split(v, hi, lo4);
+            *reinterpret_cast<f16x4*>(base + lo[k] * 8) = hi;
+            *reinterpret_cast<f16x4*>(base + XPART + lo[k] * 8) = lo4;
+        }
+    };
 
     // ---- lane roles -----------------------------------------------------------------------------------------------
     const int n16 = lane & 15, q = lane >> 4;
@@ -177,6 +224,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
     float bias4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias4[r] = A.bias ? A.bias[ocb + r] : 0.f;
+    __syncthreads();   // (X: the scale reductions are done with the LDS scratch)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 
     int cur = 0;
@@ -186,14 +234,20 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
         for (int c0 = 0; c0 < CIN; c0 += 4) {
 #pragma unroll
             for (int c = c0; c < c0 + 4; ++c) fetch_channel(c);
+            if constexpr (X) {
+                stash_group(c0 / 4, lds);
+            } else {
 #pragma unroll
-            for (int c = c0; c < c0 + 4; ++c) stash_channel(c, lds);
+                for (int c = c0; c < c0 + 4; ++c) stash_channel(c, lds);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- A fragments: lane (m = lane & 15, k = q): A[m][k] = W[ic][oc][2 + pz - 2 zi][2 + py - 2 yi][2 + px - 2 xi] ----
-    float af[MBW][C::GROUPS];
+    constexpr int XG = (CIN / 4) * 2;            // X: k steps = (channel group, zi)
+    float af[X ? 1 : MBW][X ? 1 : C::GROUPS];
+    f16x4 afh[X ? MBW : 1][X ? XG : 1], afl[X ? MBW : 1][X ? XG : 1];
     {
         const int yi = q >> 1, xi = q & 1;
 #pragma unroll
@@ -202,11 +256,24 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
             const int c8 = v / COUT, oc = v % COUT;
             const int pz = c8 >> 2, py = (c8 >> 1) & 1, px = c8 & 1;
             const int ky = 2 + py - 2 * yi, kx = 2 + px - 2 * xi;
+            if constexpr (X) {
 #pragma unroll
-            for (int g = 0; g < C::GROUPS; ++g) {
-                const int ic = g >> 1, zi = g & 1;
-                const int kz = 2 + pz - 2 * zi;
-                af[bl][g] = A.w[(((size_t)ic * COUT + oc) * 4 + kz) * 16 + ky * 4 + kx];
+                for (int g = 0; g < XG; ++g) {
+                    const int cg = g >> 1, zi = g & 1;
+                    const int kz = 2 + pz - 2 * zi;
+                    float wv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        wv[c] = A.w[(((size_t)(4 * cg + c) * COUT + oc) * 4 + kz) * 16 + ky * 4 + kx] * ws;
+                    cell_split(wv, afh[bl][g], afl[bl][g]);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < C::GROUPS; ++g) {
+                    const int ic = g >> 1, zi = g & 1;
+                    const int kz = 2 + pz - 2 * zi;
+                    af[bl][g] = A.w[(((size_t)ic * COUT + oc) * 4 + kz) * 16 + ky * 4 + kx];
+                }
             }
         }
     }
@@ -229,8 +296,48 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
 #pragma unroll
             for (int r = 0; r < C::RW; ++r)
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[bl][r][j] = f32x4{bias4[0], bias4[1], bias4[2], bias4[3]};
+                for (int j = 0; j < NB; ++j)
+                    acc[bl][r][j] = X ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{bias4[0], bias4[1], bias4[2], bias4[3]};
 
+        if constexpr (X) {
+            // the next tile's values are requested before the (short) matrix loop and converted after it; the other
+            // workgroups of the CU cover what is not hidden
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) fetch_channel(c);
+            const unsigned char* bx = reinterpret_cast<const unsigned char*>(lds + cur * C::LDS_FLOATS) + b_base * 8;
+#pragma unroll
+            for (int g = 0; g < XG; ++g) {
+                const int cg = g >> 1, zi = g & 1;
+#pragma unroll
+                for (int r = 0; r < C::RW; ++r) {
+                    const unsigned char* p = bx + (cg * C::CS + (zi * C::YT + r) * C::RS) * 8;   // compile-time offsets
+                    f16x4 bh[NB], bl2[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        bh[j] = *reinterpret_cast<const f16x4*>(p + 16 * j * 8);
+                        bl2[j] = *reinterpret_cast<const f16x4*>(p + XPART + 16 * j * 8);
+                    }
+                    // small partial products first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int bl = 0; bl < MBW; ++bl)
+                            acc[bl][r][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(afh[bl][g], bl2[j], acc[bl][r][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int bl = 0; bl < MBW; ++bl)
+                            acc[bl][r][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(afl[bl][g], bh[j], acc[bl][r][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int bl = 0; bl < MBW; ++bl)
+                            acc[bl][r][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(afh[bl][g], bh[j], acc[bl][r][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int cg = 0; cg < CIN / 4; ++cg) stash_group(cg, nxt);
+        }
         const float* bp = lds + cur * C::LDS_FLOATS + b_base;
         float bb[2][C::RW * NB];
         auto read_group = [&](int g, float* dst) {
@@ -242,9 +349,9 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
                 for (int j = 0; j < NB; ++j) dst[r * NB + j] = p[16 * j];
             }
         };
-        read_group(0, bb[0]);
+        if constexpr (!X) read_group(0, bb[0]);
 #pragma unroll
-        for (int g = 0; g < C::GROUPS; ++g) {
+        for (int g = 0; g < (X ? 0 : C::GROUPS); ++g) {
             if (g + 1 < C::GROUPS) read_group(g + 1, bb[(g + 1) & 1]);
             if (g < CIN) fetch_channel(g);
             if (g >= CIN) stash_channel(g - CIN, nxt);
@@ -293,7 +400,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv3d_cell_kernel(const Cell
                     const unsigned off = ok ? out_lane[bl] + 128u * j : ~0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = acc[bl][r][j][e];
+                        float t = X ? fmaf(acc[bl][r][j][e], unscale, bias4[e]) : acc[bl][r][j][e];
                         if (A.lrelu) t = fmaxf(t, t * kLeakySlope);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), ro, off, row_bytes + e * cobytes, 0);
                         t = ok ? t : 0.f;
@@ -359,17 +466,17 @@ int cell_tiles(const Geom& in, const CellPlan& p) {
     return ((cx + 16 * p.nb - 1) / (16 * p.nb)) * ((cy + p.ty - 1) / p.ty) * ((cz + p.tz - 1) / p.tz);
 }
 
-template <int CIN, int COUT, int MBW, int TZ, int TY, int NB, bool NORM>
+template <int CIN, int COUT, int MBW, int TZ, int TY, int NB, bool NORM, bool X>
 int launch_cell(const CellArgs& A, int batch, hipStream_t s) {
     using C = CellCfg<CIN, COUT, MBW, TZ, TY, NB>;
     constexpr size_t lds_bytes = (size_t)2 * C::LDS_FLOATS * sizeof(float);
     static_assert(lds_bytes >= (size_t)DC_THREADS * 8 * sizeof(double), "reduction scratch must fit");
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM, X>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
-    hipLaunchKernelGGL((deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM>), dim3(A.records, batch), dim3(DC_THREADS),
+    hipLaunchKernelGGL((deconv3d_cell_kernel<CIN, COUT, MBW, TZ, TY, NB, NORM, X>), dim3(A.records, batch), dim3(DC_THREADS),
                        lds_bytes, s, A);
     return check_launch("deconv3d_cell");
 }
@@ -413,10 +520,22 @@ int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s) {
     A.tiles = cell_tiles(L.in, p);
     A.records = deconv3d_cell_records(L.in, L.out_g.c);
     const bool norm = L.a.scale != nullptr;
-    if (p.id == 0)
-        return norm ? launch_cell<8, 4, 2, 2, 4, 2, true>(A, L.in.n, s) : launch_cell<8, 4, 2, 2, 4, 2, false>(A, L.in.n, s);
-    if (p.id == 1)
-        return norm ? launch_cell<16, 8, 2, 2, 2, 4, true>(A, L.in.n, s) : launch_cell<16, 8, 2, 2, 2, 4, false>(A, L.in.n, s);
+    static const bool split_on = []() {  // PDS_DECONV_CELL_X=0: exact-fp32 MFMAs also for certified sources (A/B)
+        const char* e = getenv("PDS_DECONV_CELL_X");
+        return !(e && e[0] == '0');
+    }();
+    // fp16-split form when the source carries a range certificate (inside the hourglass: always)
+    const bool x = split_on && norm && L.a.bound && L.a.bound_n > 0;
+    if (p.id == 0) {
+        if (x) return launch_cell<8, 4, 2, 2, 4, 2, true, true>(A, L.in.n, s);
+        return norm ? launch_cell<8, 4, 2, 2, 4, 2, true, false>(A, L.in.n, s)
+                    : launch_cell<8, 4, 2, 2, 4, 2, false, false>(A, L.in.n, s);
+    }
+    if (p.id == 1) {
+        if (x) return launch_cell<16, 8, 2, 2, 2, 4, true, true>(A, L.in.n, s);
+        return norm ? launch_cell<16, 8, 2, 2, 2, 4, true, false>(A, L.in.n, s)
+                    : launch_cell<16, 8, 2, 2, 2, 4, false, false>(A, L.in.n, s);
+    }
     return set_error(-1, "deconv3d_cell: no configuration");
 }
 

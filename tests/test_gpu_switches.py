@@ -22,6 +22,7 @@ SWITCHES = [
     {'PDS_CONV3D_T8': '0', 'PDS_DECONV_CELL': '0', 'PDS_CONV3D_KS': '0'},   # generic MFMA kernels for all hourglass layers
     {'PDS_CONV3D_T8X': '0'},        # exact-fp32 kernel for the 8 -> 8 full-resolution layers (round 3)
     {'PDS_CONV3D_T8X': '2'},        # ... the split-operand kernel also for the un-certified first layer (bf16 x 3 form)
+    {'PDS_DECONV_CELL_X': '0'},     # exact-fp32 MFMAs in the dense-cell transposed convolutions
     {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
     {'PDS_CONV2D_T8W': '0'},        # ... its 16 x 32-tile form instead of the full-width one
 ]
