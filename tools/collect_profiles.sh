@@ -26,6 +26,6 @@ python bench.py > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/bench_line.json
 python tools/train_step_bench.py > $OUT/train_step.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/trace_train -- python tools/train_step_bench.py > $OUT/train_prof.log 2>&1
-python tools/prof_summary.py $OUT/trace_train $OUT/train_step_kernels.txt "tools/train_step_bench.py: 3 full-size training steps (960x540, D=192, one GPU, SubpixelCrossEntropy); un-profiled timing: $(tail -1 $OUT/train_step.log)" > /dev/null 2>&1
+python tools/prof_summary.py $OUT/trace_train $OUT/train_step_kernels.txt "tools/train_step_bench.py: 3 full-size training steps (960x540, D=192, one GPU, SubpixelCrossEntropy); un-profiled timing: $(tail -1 $OUT/train_step.log)" bygrid > /dev/null 2>&1
 rm -rf $OUT/trace_seq $OUT/trace_pipe $OUT/trace_train $OUT/pmc_[0-9]   # raw databases stay on the box
 ls -la $OUT
