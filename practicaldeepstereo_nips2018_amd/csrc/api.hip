@@ -972,6 +972,7 @@ struct ArenaLimit {
 static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<float*>& dhat,
                           std::vector<char>& written) {
     static const bool debug_arena = getenv("PDS_DEBUG_ARENA") != nullptr;
+    const std::vector<char> preset(written);  // gradients that live in the caller's tensors: never taken over
     for (int li = (int)T.layers.size() - 1; li >= 0; --li) {
         const TapeLayer& L = T.layers[li];
         const TapeTensor& out = T.tensors[L.out];
@@ -1006,8 +1007,14 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             written[id] = 1;
         };
         if (L.type == 2) {  // plain sum: the gradient flows unchanged to both terms
-            route(L.a, g, L.out_g);
-            route(L.b, g, L.out_g);
+            // Every consumer of the sum has delivered its share by now, so its gradient buffer is dead after this
+            // layer: ONE term may simply take it over instead of receiving a copy (a 425 MB copy per residual sum of
+            // Matching) -- but only a buffer of this arena, never the caller's gradient tensor.
+            const bool mine = !preset[L.out];
+            const bool a_takes = mine && L.a >= 0 && T.tensors[L.a].needs_grad && !T.tensors[L.a].bcast_d && !dhat[L.a] &&
+                                 !written[L.a];
+            route(L.a, g, L.out_g, a_takes);
+            route(L.b, g, L.out_g, mine && !a_takes);
             continue;
         }
         if (L.type == 3) {  // space-to-depth: the adjoint is the inverse permutation
@@ -1026,7 +1033,7 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         const float* dz = g;
         // range certificate of dz (max |dz|, collected by the InstanceNorm backward that writes it): with it the
         // 64-channel weight and data gradients run their fp16-split kernels; a bare layer's dz (the caller's gradient)
-        // has none and keeps the range-safe forms
+        // gets its certificate from the bias-gradient pass below
         Src sdz = plain_src(nullptr);
         if (L.norm) {
             float* dz_amax = c.get<float>(kDzAmaxSlots);
@@ -1052,8 +1059,15 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         Src sb = no_src();
         if (L.b >= 0) sb = T.tensors[L.b].src();
         if (!L.norm) {   // a bare layer: dz is the upstream gradient itself, its channel sums need a pass of their own
-            double* bias_scratch = c.get<double>((size_t)channel_sum_splits(out.g) * out.g.c);
-            if (!c.plan) c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s));
+            // (the same pass certifies the range of the caller's gradient)
+            const int records = channel_sum_splits(out.g) * out.g.c;
+            double* bias_scratch = c.get<double>((size_t)records);
+            float* dz_amax = c.get<float>((size_t)records);
+            sdz.bound = dz_amax;
+            sdz.bound_n = records;
+            sdz.bounded = 1;
+            if (!c.plan)
+                c.run(launch_channel_sum(dz, out.g, const_cast<float*>(gp->bias), 0, bias_scratch, c.s, dz_amax));
         }
         const float* weight = L.s2d_cin ? L.weight_used : L.P->weight;
         const int taps = L.kd * 9;

@@ -207,16 +207,26 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
 // ---------------------------------------------------------------------------------------------------
 // bias gradient: db[c] (+)= sum over n, d, y, x of dz
 // ---------------------------------------------------------------------------------------------------
-// two-stage: grid (C, splits) partial sums over a strided share of the positions, then one reduce
+// two-stage: grid (C, splits) partial sums over a strided share of the positions, then one reduce.  The pass reads the
+// whole of dz anyway: it also records max |dz| per workgroup (amax[split * C + c], may be null), the range certificate
+// (common.hpp Src::bound) that lets the gradients of a bare layer run their fp16-split kernels.
 __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ dz, const Geom geom,
-                                                                  double* __restrict__ partial) {
+                                                                  double* __restrict__ partial,
+                                                                  float* __restrict__ amax) {
     const int c = blockIdx.x, split = blockIdx.y, splits = gridDim.y;
     const size_t vol = geom.volume();
     double s = 0.0;
+    float m = 0.f;
     for (int n = 0; n < geom.n; ++n) {
         const float* p = dz + ((size_t)n * geom.c + c) * vol;
-        for (size_t i = (size_t)split * 256 + threadIdx.x; i < vol; i += (size_t)splits * 256) s += p[i];
+        for (size_t i = (size_t)split * 256 + threadIdx.x; i < vol; i += (size_t)splits * 256) {
+            const float v = p[i];
+            s += v;
+            m = (fabsf(v) > m || v != v) ? fabsf(v) : m;   // a NaN sticks
+        }
     }
+    __shared__ float redm[4];
+    if (amax) block_amax_record(m, amax + (size_t)split * geom.c + c, redm);
     __shared__ double red[4];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -242,9 +252,11 @@ int channel_sum_splits(const Geom& g) {
 }
 
 // scratch: channel_sum_splits(g) * C doubles
-int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s) {
+// amax (optional): channel_sum_splits(g) * C floats
+int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s,
+                       float* amax) {
     const int splits = channel_sum_splits(g);
-    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(g.c, splits), dim3(256), 0, s, dz, g, scratch);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(g.c, splits), dim3(256), 0, s, dz, g, scratch, amax);
     hipLaunchKernelGGL(channel_sum_reduce_kernel, dim3(g.c), dim3(64), 0, s, scratch, g.c, splits, db, accumulate);
     return check_launch("channel_sum");
 }

@@ -197,7 +197,8 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
                   float* dz_amax = nullptr);   // (kDzAmaxSlots floats whose maximum is max |dz|: the range certificate of dz)
 constexpr int kDzAmaxSlots = 1024;
 int channel_sum_splits(const Geom& g);
-int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s);
+int launch_channel_sum(const float* dz, const Geom& g, float* db, int accumulate, double* scratch, hipStream_t s,
+                       float* amax = nullptr);
 int launch_flip_weights(const float* w, float* wf, int cout, int cin, int taps, hipStream_t s);
 int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
                     const Geom& out, hipStream_t s);

@@ -1,4 +1,4 @@
-// Weight gradient of the 64 -> 64 (and 64k -> 64) 3x3 convolutions of MatchingOperation / the embedding on the 16-bit
+// Weight gradient of the 64k -> 64 and 64k -> (at most 16) 3x3 convolutions of MatchingOperation / the embedding on the 16-bit
 // matrix pipe (round 4; reference: autograd through network_blocks.py:47-58, driven by pds_trainer.py:40-46):
 //   dW[oc][c][tap] = sum over (n, d, y, x) of dz[oc][p] * xhat[c][p + tap]
 // wgrad2d_mfma.hip runs this contraction on v_mfma_f32_16x16x4_f32 (1/16 of the 16-bit MFMA rate): 11 launches x 1.2 ms =
@@ -35,10 +35,11 @@ constexpr int RSX = 40;                    // xhat row stride (fp16 elements): c
 constexpr int CSX = XR * RSX + 36;         // xhat channel stride: 196 == 4 (mod 64) elements = 2 dwords (mod 32)
 constexpr int CSD = TR * TWG + 4;          // dz channel stride: 68 == 4 (mod 64)
 constexpr int CG = 64;                     // input channels per workgroup (grid.y walks further groups)
-constexpr int XPART = CG * CSX, DPART = 64 * CSD;   // elements of one split part
-constexpr int LDS_BYTES = (2 * XPART + 2 * DPART) * 2;
+constexpr int XPART = CG * CSX;            // elements of one split part of xhat
+constexpr int dpart(int mb) { return 16 * mb * CSD; }   // ... of dz, for mb blocks of 16 output channels
+constexpr int lds_bytes(int mb) { return (2 * XPART + 2 * dpart(mb)) * 2; }
 static_assert(CSX % 64 == 4 && CSD % 64 == 4, "conflict-free fragment reads");
-static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+static_assert(lds_bytes(4) <= 80 * 1024, "two workgroups per CU");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -49,7 +50,7 @@ struct WX3Args {
     const float* __restrict__ dz_bound;
     int dz_bound_n;
     float* __restrict__ partial;  // [workgroup][64][Cin][9]
-    int N, Cin, D, H, W;
+    int N, Cin, D, H, W, Cout;
     int items, segs, rowpairs;
 };
 
@@ -65,11 +66,14 @@ __device__ __forceinline__ f16x4 as_f16x4(unsigned lo, unsigned hi) { return __b
 
 }  // namespace
 
-template <bool HAS_B>
+// MB = blocks of 16 output channels: 4 for the 64 -> 64 layers, 1 for the 64 -> 8 layer that closes MatchingOperation
+// (rows 8..15 of its block are zeros: the layer is bound by staging xhat, not by the matrix pipe).
+template <bool HAS_B, int MB>
 __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int DPART = dpart(MB);
     _Float16* xs = reinterpret_cast<_Float16*>(lds_raw);     // [2][CG][CSX]
-    _Float16* dl = xs + 2 * XPART;                           // [2][64][CSD]
+    _Float16* dl = xs + 2 * XPART;                           // [2][16 MB][CSD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the wave's input-channel block
@@ -83,9 +87,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
     const float ds = pow2_scale(block_bound(A.dz_bound, A.dz_bound_n, reinterpret_cast<float*>(lds_raw)), kHalfTarget);
     const float unscale = (1.f / as) * (1.f / ds);
 
-    f32x4 acc[4][9];
+    f32x4 acc[MB][9];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
         // the skip sum, the literal zero padding and the fp16 split are applied on the way to LDS.
         // (batches of two quads per source: the 144 accumulator registers leave room for no more in flight, and the
         // other workgroup of the CU covers the load latency with its MFMAs)
-        constexpr int BATCH = 2;
+        constexpr int BATCH = (MB == 1 || !HAS_B) ? 5 : 2;
 #pragma unroll 1
         for (int half = 0; half < 10 / BATCH; ++half) {
             f32x4 qa[BATCH], qb[HAS_B ? BATCH : 1];
@@ -158,24 +162,26 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
                 *reinterpret_cast<f16x4*>(xs + XPART + dst[j]) = lo;
             }
         }
-        // ---- stage dz: 64 output channels x 2 rows x 8 quads, 4 quads per thread -----------------------------------
+        // ---- stage dz: 16 MB output channels x 2 rows x 8 quads, MB quads per thread -------------------------------
+        constexpr int ZB = MB >= 2 ? 2 : 1;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            f32x4 qz[2];
-            bool ok[2];
-            int dst[2];
+        for (int half = 0; half < MB / ZB; ++half) {
+            f32x4 qz[ZB];
+            bool ok[ZB];
+            int dst[ZB];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int slot = tid + (half * 2 + j) * THREADS;     // < 1024
+            for (int j = 0; j < ZB; ++j) {
+                const int slot = tid + (half * ZB + j) * THREADS;     // < 256 MB
                 const int q = slot & 7, rr = (slot >> 3) & 1, oc = slot >> 4;
                 const int x = x0 + 4 * q, y = y0 + rr;
-                ok[j] = x < A.W && y < A.H;
-                const int xc = min(x, A.W - 4), yc = min(y, A.H - 1);
-                qz[j] = *reinterpret_cast<const f32x4*>(A.dz + ((size_t)(n * 64 + oc) * A.D + d) * plane + (size_t)yc * A.W + xc);
+                ok[j] = x < A.W && y < A.H && oc < A.Cout;
+                const int xc = min(x, A.W - 4), yc = min(y, A.H - 1), occ = min(oc, A.Cout - 1);
+                qz[j] = *reinterpret_cast<const f32x4*>(A.dz + ((size_t)(n * A.Cout + occ) * A.D + d) * plane +
+                                                        (size_t)yc * A.W + xc);
                 dst[j] = oc * CSD + rr * TWG + 4 * q;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < ZB; ++j) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ok[j] ? qz[j][e] * ds : 0.f;
@@ -191,9 +197,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
 #pragma unroll 1
         for (int ks = 0; ks < TR * 2; ++ks) {
             const int r2 = ks >> 1, hs = ks & 1;
-            f16x4 ah[4], al[4];
+            f16x4 ah[MB], al[MB];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MB; ++m) {
                 ah[m] = *reinterpret_cast<const f16x4*>(arow + m * 16 * CSD + r2 * TWG + 16 * hs);
                 al[m] = *reinterpret_cast<const f16x4*>(arow + DPART + m * 16 * CSD + r2 * TWG + 16 * hs);
             }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) {
+                        for (int m = 0; m < MB; ++m) {
                             const f16x4 av = prod == 1 ? al[m] : ah[m];
                             const f16x4 bv = prod == 0 ? bf[1][dx] : bf[0][dx];
                             acc[m][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc[m][dy * 3 + dx], 0, 0, 0);
@@ -230,17 +236,17 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
         __syncthreads();
     }
 
-    // ---- one partial per workgroup: [64][Cin][9] -------------------------------------------------------------------
-    float* dst = A.partial + (size_t)blockIdx.x * 64 * A.Cin * 9;
+    // ---- one partial per workgroup: [Cout][Cin][9] -----------------------------------------------------------------
+    float* dst = A.partial + (size_t)blockIdx.x * A.Cout * A.Cin * 9;
     const int c = cg0 + wave * 16 + (lane & 15);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int oc = m * 16 + 4 * (lane >> 4) + rr;
-                dst[((size_t)oc * A.Cin + c) * 9 + t] = acc[m][t][rr] * unscale;
+                if (MB == 4 || oc < A.Cout) dst[((size_t)oc * A.Cin + c) * 9 + t] = acc[m][t][rr] * unscale;
             }
 }
 
@@ -249,7 +255,7 @@ bool wgrad2d_x3_supported(const Src& a, const Src& b, const Src& dz, const Geom&
         const char* e = getenv("PDS_WGRAD2D_X3");
         return !(e && e[0] == '0');
     }();
-    if (!enabled || out.c != 64 || in.c % CG != 0 || (in.w & 3) != 0) return false;
+    if (!enabled || !(out.c == 64 || out.c <= 16) || in.c % CG != 0 || (in.w & 3) != 0) return false;
     if (!dz.bound || dz.bound_n <= 0 || !a.bound || a.bound_n <= 0 || (b.p && (!b.bound || b.bound_n <= 0 || b.bcast_d)))
         return false;
     if ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(b.p) | reinterpret_cast<uintptr_t>(dz.p)) & 15)
@@ -259,8 +265,8 @@ bool wgrad2d_x3_supported(const Src& a, const Src& b, const Src& dz, const Geom&
 
 int launch_wgrad2d_x3(const Src& a, const Src& b, const Src& dz, float* partial, int workgroups, const Geom& in,
                       const Geom& out, hipStream_t s) {
-    (void)out;
     WX3Args A;
+    A.Cout = out.c;
     A.a = a;
     A.b = b;
     A.dz = dz.p;
@@ -277,14 +283,23 @@ int launch_wgrad2d_x3(const Src& a, const Src& b, const Src& dz, float* partial,
     A.items = in.n * in.d * A.rowpairs * A.segs;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<true, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<false, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<true, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<false, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
     }
     const dim3 grid(workgroups, in.c / CG);
-    if (b.p) hipLaunchKernelGGL((wgrad2d_x3_kernel<true>), grid, dim3(THREADS), LDS_BYTES, s, A);
-    else hipLaunchKernelGGL((wgrad2d_x3_kernel<false>), grid, dim3(THREADS), LDS_BYTES, s, A);
+    if (out.c == 64) {
+        if (b.p) hipLaunchKernelGGL((wgrad2d_x3_kernel<true, 4>), grid, dim3(THREADS), lds_bytes(4), s, A);
+        else hipLaunchKernelGGL((wgrad2d_x3_kernel<false, 4>), grid, dim3(THREADS), lds_bytes(4), s, A);
+    } else {
+        if (b.p) hipLaunchKernelGGL((wgrad2d_x3_kernel<true, 1>), grid, dim3(THREADS), lds_bytes(1), s, A);
+        else hipLaunchKernelGGL((wgrad2d_x3_kernel<false, 1>), grid, dim3(THREADS), lds_bytes(1), s, A);
+    }
     return check_launch("wgrad2d_x3");
 }
 

@@ -2,14 +2,19 @@
 // loss.backward(), pds_trainer.py:40-46) on the fp32 MFMA units:
 //   dW[oc][c][tap] = sum over (n, z, y, x) of dz[oc][p] * xhat[c][p + tap]
 // GEMM view: M = output channels (one block of 16), N = 16 input channels per tap (27 column blocks), K = positions,
-// walked 4 at a time with v_mfma_f32_16x16x4_f32.
+// walked 4 at a time with v_mfma_f32_16x16x4_f32 (exact fp32: needs no range certificate).
+//   work unit   a column of the volume: 4 rows x 32 columns of positions, walked along z over a chunk of planes.  The
+//               three xhat planes a step needs live in an LDS ring: every step stages ONE new plane (6 rows x 34
+//               columns x 16 channels), i.e. 1.6 staged elements per position and channel -- the round-3 form staged
+//               nine rows for every single row of positions (9.6) and spent 7/8 of its time doing so.
+//   staging     the (channel, row, column) a thread stages is the same in every step: global offsets, LDS addresses,
+//               bounds and the deferred-InstanceNorm coefficients are computed once per unit; the loads of step z + 1
+//               are issued before the MFMAs of step z and land in LDS after them.
 //   workgroup   one (output-channel block, input-channel block) pair (grid.y); 4 waves split the 27 taps; persistent
-//               over work items (grid.x strides) with the partial dW kept in registers, ONE partial per workgroup;
-//               a second kernel sums the partials in fp64 (wgrad2d_mfma.hip: wgrad_reduce_f32_kernel).
-//   work item   a 32-position x-segment of one (n, z, y) row.
-//   LDS         xhat tile [16 ch][9 rows (3 z x 3 y)][34 columns] with the deferred InstanceNorm, the skip sum (also
-//               one broadcast along D, regularization.py:115) and zero padding applied while staging, and dz [16][32];
-//               row strides chosen so that both fragment reads are bank-conflict free (channel stride == 2 mod 32).
+//               over units (grid.x strides) with the partial dW in registers, ONE partial per workgroup; a second
+//               kernel sums the partials in fp64 in a fixed order (wgrad2d_mfma.hip: wgrad_reduce_f32_kernel).
+//   LDS         xhat [16 ch][3 planes][6 rows][36] and dz [16][4 x 32]; channel strides == 2 (mod 32), so the 32 lanes
+//               of a half-wave (16 channels x 2 positions) read 32 different banks.
 #include "common.hpp"
 
 namespace pds {
@@ -17,105 +22,185 @@ namespace pds {
 namespace {
 
 constexpr int THREADS = 256;
-constexpr int TWG = 32;          // positions per work item
-constexpr int RSX = 50;          // xhat row stride: >= TWG + 2, and 9 * RSX == 2 (mod 32)
-constexpr int XS = 9 * RSX;      // xhat channel stride
-constexpr int DS = 34;           // dz row stride, == 2 (mod 32)
-constexpr int TPW = 7;           // taps per wave (4 x 7 >= 27)
+constexpr int TY = 4, TWG = 32;                 // rows x columns of positions per step
+constexpr int ROWS = TY + 2, COLS = TWG + 2;    // staged rows y0 - 1 .. y0 + TY, columns x0 - 1 .. x0 + TWG
+constexpr int RSX = 36;                         // xhat row stride
+constexpr int PSX = ROWS * RSX;                 // plane (ring slot) stride
+constexpr int XS = 3 * PSX + 26;                // xhat channel stride: 674 == 2 (mod 32)
+constexpr int DS = TY * TWG + 2;                // dz channel stride: 130 == 2 (mod 32)
+constexpr int XSLOTS = 16 * ROWS * COLS;        // staged xhat elements per plane
+constexpr int NSTG = (XSLOTS + THREADS - 1) / THREADS;   // 13 per thread
+constexpr int NDZ = 16 * TY * TWG / THREADS;    // 8 per thread
+constexpr int TPW = 7;                          // taps per wave (4 x 7 >= 27)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(XS % 32 == 2 && DS % 32 == 2, "bank layout");
+static_assert((16 * XS + 16 * DS) * 4 <= 53 * 1024, "three workgroups per CU");
 
 struct W3Args {
     Src a, b;
     const float* __restrict__ dz;
     float* __restrict__ partial;  // [workgroup][Cout][Cin][27]
     int N, Cin, D, H, W, Cout;
-    int items, segs, ocbs;
+    int units, segs, yblocks, zchunks, zc, ocbs;
 };
 
 }  // namespace
 
-__global__ __launch_bounds__(THREADS) void wgrad3d_mfma_kernel(const W3Args A) {
+template <bool HAS_B>
+__global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A) {
     __shared__ __attribute__((aligned(16))) float xl[16 * XS];
     __shared__ __attribute__((aligned(16))) float dzl[16 * DS];
+    __shared__ f32x4 coef[16];   // per input channel: scale and shift of the two sources (deferred InstanceNorm)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ocb = blockIdx.y % A.ocbs, cb = blockIdx.y / A.ocbs;
     const int oc0 = ocb * 16, c0 = cb * 16;
-    const size_t plane = (size_t)A.H * A.W;
+    const int plane = A.H * A.W;
     const size_t vol = (size_t)A.D * plane;
-    const size_t bstride = A.b.bcast_d ? plane : vol;  // channel stride of the second source
+    const size_t bstride = HAS_B && A.b.bcast_d ? (size_t)plane : vol;  // channel stride of the second source
+    const int bz = HAS_B && A.b.bcast_d ? 0 : plane;                    // its plane stride
 
     f32x4 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
-        int r = item;
+    const float* arow = dzl + (lane & 15) * DS + (lane >> 4);
+    const float* brow = xl + (lane & 15) * XS + (lane >> 4);
+
+    for (int unit = blockIdx.x; unit < A.units; unit += gridDim.x) {
+        int r = unit;
         const int seg = r % A.segs;
         r /= A.segs;
-        const int y = r % A.H;
-        r /= A.H;
-        const int z = r % A.D;
-        const int n = r / A.D;
-        const int x0 = seg * TWG;
+        const int yb = r % A.yblocks;
+        r /= A.yblocks;
+        const int zci = r % A.zchunks;
+        const int n = r / A.zchunks;
+        const int x0 = seg * TWG, y0 = yb * TY;
+        const int z0 = zci * A.zc, z1 = min(z0 + A.zc, A.D);
+        const int rows = min(TY, A.H - y0);   // rows of positions that exist
 
-        // ---- stage xhat: 16 channels x 9 rows x 34 columns (x0 - 1 .. x0 + 32) ----------------------------
-        for (int e = tid; e < 16 * 9 * (TWG + 2); e += THREADS) {
-            const int c = e / (9 * (TWG + 2));
-            const int rem = e - c * 9 * (TWG + 2);
-            const int rr = rem / (TWG + 2), xx = rem - rr * (TWG + 2);
-            const int zz = z - 1 + rr / 3, yy = y - 1 + rr % 3, x = x0 - 1 + xx;
-            const int ch = c0 + c;
-            float v = 0.f;
-            if (ch < A.Cin && zz >= 0 && zz < A.D && yy >= 0 && yy < A.H && x >= 0 && x < A.W) {
-                const size_t inplane = (size_t)yy * A.W + x;
-                const int g = n * A.Cin + ch;
-                float sa = 1.f, ha = 0.f;
-                if (A.a.scale) {
-                    sa = A.a.scale[g];
-                    ha = A.a.shift[g];
-                }
-                v = fmaf(sa, A.a.p[(size_t)g * vol + (size_t)zz * plane + inplane], ha);
-                if (A.b.p) {
-                    float sb = 1.f, hb = 0.f;
-                    if (A.b.scale) {
-                        sb = A.b.scale[g];
-                        hb = A.b.shift[g];
-                    }
-                    v += fmaf(sb, A.b.p[(size_t)g * bstride + (A.b.bcast_d ? 0 : (size_t)zz * plane) + inplane], hb);
+        // ---- what this thread stages in every step -----------------------------------------------------------------
+        int xoff[NSTG], xdst[NSTG];      // offset inside the (n, c0) block of one plane index 0, or -1; LDS address or -1
+        if (tid < 16) {
+            const int g = n * A.Cin + min(c0 + tid, A.Cin - 1);
+            f32x4 cf{1.f, 0.f, 1.f, 0.f};
+            if (A.a.scale) {
+                cf[0] = A.a.scale[g];
+                cf[1] = A.a.shift[g];
+            }
+            if (HAS_B && A.b.scale) {
+                cf[2] = A.b.scale[g];
+                cf[3] = A.b.shift[g];
+            }
+            coef[tid] = cf;
+        }
+#pragma unroll
+        for (int j = 0; j < NSTG; ++j) {
+            const int e = tid + j * THREADS;
+            const int c = e / (ROWS * COLS), rem = e - c * (ROWS * COLS);
+            const int row = rem / COLS, col = rem - row * COLS;
+            const int y = y0 - 1 + row, x = x0 - 1 + col, ch = c0 + c;
+            const bool slot = e < XSLOTS;
+            const bool ok = slot && ch < A.Cin && y >= 0 && y < A.H && x >= 0 && x < A.W;
+            xdst[j] = slot ? c * XS + row * RSX + col : -1;
+            xoff[j] = ok ? c * (int)vol + y * A.W + x : -1;   // 16 channel volumes stay below 2^31 elements (launcher)
+        }
+        const float* abase = A.a.p + (size_t)(n * A.Cin + c0) * vol;
+        const float* bbase = HAS_B ? A.b.p + (size_t)(n * A.Cin + c0) * bstride : nullptr;
+        const unsigned bshrink = (unsigned)(vol - bstride);   // a source broadcast along D has one plane per channel
+        int doff[NDZ];
+#pragma unroll
+        for (int j = 0; j < NDZ; ++j) {
+            const int e = tid + j * THREADS;
+            const int o = e / (TY * TWG), rem = e % (TY * TWG);
+            const int y = y0 + rem / TWG, x = x0 + rem % TWG;
+            doff[j] = (oc0 + o < A.Cout && y < A.H && x < A.W) ? o * (int)vol + y * A.W + x : -1;
+        }
+        const float* dbase = A.dz + (size_t)(n * A.Cout + oc0) * vol;
+
+        float xa[NSTG], xb[HAS_B ? NSTG : 1], dv[NDZ];
+        // loads of xhat plane zz (zero outside the volume) / of dz plane z, into registers
+        auto load_x = [&](int zz) {
+            const bool zin = zz >= 0 && zz < A.D;
+            const unsigned zo = (unsigned)(min(max(zz, 0), A.D - 1) * plane);
+            const unsigned zob = (unsigned)(min(max(zz, 0), A.D - 1) * bz);
+#pragma unroll
+            for (int j = 0; j < NSTG; ++j) {
+                const bool ok = zin && xoff[j] >= 0;
+                const unsigned off = (unsigned)max(xoff[j], 0);
+                xa[j] = ok ? abase[off + zo] : 0.f;
+                if (HAS_B) {
+                    const unsigned c = (unsigned)(tid + j * THREADS) / (ROWS * COLS);
+                    xb[j] = ok ? bbase[off - c * bshrink + zob] : 0.f;
                 }
             }
-            xl[c * XS + rr * RSX + xx] = v;
-        }
-        // ---- stage dz: 16 output channels x 32 positions ----------------------------------------------------
-        for (int e = tid; e < 16 * TWG; e += THREADS) {
-            const int o = e / TWG, px = e - o * TWG;
-            const int x = x0 + px, oc = oc0 + o;
-            float v = 0.f;
-            if (oc < A.Cout && x < A.W)
-                v = A.dz[((size_t)(n * A.Cout + oc)) * vol + (size_t)z * plane + (size_t)y * A.W + x];
-            dzl[o * DS + px] = v;
-        }
-        __syncthreads();
+        };
+        auto store_x = [&](int zz) {
+            const bool zin = zz >= 0 && zz < A.D;
+            const int so = ((zz + 3) % 3) * PSX;   // zz >= -1
+#pragma unroll
+            for (int j = 0; j < NSTG; ++j) {
+                const f32x4 cf = coef[min((tid + j * THREADS) / (ROWS * COLS), 15)];
+                float v = fmaf(cf[0], xa[j], cf[1]);
+                if (HAS_B) v += fmaf(cf[2], xb[j], cf[3]);
+                if (!(zin && xoff[j] >= 0)) v = 0.f;   // the literal zero padding, not the normalised zero
+                if (xdst[j] >= 0) xl[xdst[j] + so] = v;
+            }
+        };
+        auto load_dz = [&](int z) {
+#pragma unroll
+            for (int j = 0; j < NDZ; ++j) {
+                dv[j] = doff[j] >= 0 ? dbase[(unsigned)doff[j] + (unsigned)(z * plane)] : 0.f;
+            }
+        };
+        auto store_dz = [&]() {
+#pragma unroll
+            for (int j = 0; j < NDZ; ++j) {
+                const int e = tid + j * THREADS;
+                dzl[(e / (TY * TWG)) * DS + e % (TY * TWG)] = dv[j];
+            }
+        };
 
-        const float* arow = dzl + (lane & 15) * DS + (lane >> 4);
-        const float* brow = xl + (lane & 15) * XS + (lane >> 4);
-#pragma unroll 2
-        for (int ks = 0; ks < TWG / 4; ++ks) {
-            const float af = arow[ks * 4];
+        // ---- prologue: planes z0 - 1 and z0 in the ring, plane z0 + 1 and dz(z0) in flight ---------------------------
+        load_x(z0 - 1);
+        __syncthreads();   // coef
+        store_x(z0 - 1);
+        load_x(z0);
+        store_x(z0);
+        load_x(z0 + 1);
+        load_dz(z0);
+        for (int z = z0; z < z1; ++z) {
+            store_x(z + 1);      // the slot held plane z - 2: the barrier closing step z - 1 released it
+            store_dz();
+            __syncthreads();
+            if (z + 1 < z1) {    // next step's operands: in flight during the MFMAs
+                load_x(z + 2);
+                load_dz(z + 1);
+            }
+            // plane z - 1 + dzt sits in ring slot (z + dzt + 2) % 3
+            int boff[TPW];
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int tap = wave + 4 * i;            // taps w, w + 4, ...: wave-uniform
-                if (tap < 27) {
-                    const int rr = tap / 3, dx = tap % 3;  // rr = dz * 3 + dy
-                    const float bf = brow[rr * RSX + ks * 4 + dx];
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
+                const int tap = min(wave + 4 * i, 26);   // taps w, w + 4, ...: wave-uniform
+                const int dzt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                boff[i] = ((z + dzt + 2) % 3) * PSX + dy * RSX + dx;
+            }
+            for (int rr = 0; rr < rows; ++rr) {
+#pragma unroll 2
+                for (int ks = 0; ks < TWG / 4; ++ks) {
+                    const float af = arow[rr * TWG + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        if (i < TPW - 1 || wave < 3) {   // tap 27 does not exist
+                            const float bf = brow[boff[i] + rr * RSX + ks * 4];
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
+                        }
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- one partial per workgroup: [Cout][Cin][27] ----------------------------------------------------------
@@ -142,20 +227,51 @@ bool wgrad3d_mfma_supported(int transposed, int kd, int stride, const Geom& in, 
     }();
     if (!enabled || transposed || kd != 3 || stride != 1) return false;
     if (in.d != out.d || in.h != out.h || in.w != out.w) return false;
+    if ((size_t)in.d * in.h * in.w * 16 >= ((size_t)1 << 31)) return false;   // 32-bit offsets inside a channel block
     return true;
 }
 
-static int wgrad3d_workgroups(const Geom& in, int pairs) {
-    const size_t items = (size_t)in.n * in.d * in.h * ((in.w + TWG - 1) / TWG);
-    size_t wgs = items / 8;                       // >= ~8 items per workgroup so the partial write amortises
-    const size_t cap = (size_t)(2048 / pairs) > 0 ? (size_t)(2048 / pairs) : 1;
-    if (wgs > cap) wgs = cap;
-    return wgs < 1 ? 1 : (int)wgs;
+namespace {
+
+// How the volume is cut into units and how many workgroups walk them.  A unit is one column (4 rows x 32 columns) over a
+// chunk of `zc` planes and stages zc + 2 planes for zc steps: long chunks stage less, short ones give more units.
+// The chip holds 3 workgroups per CU: with plenty of work the workgroups are persistent over >= 3 units each (chunks of
+// 8, 6 or 4 planes); a small level gets the shortest chunks that still fit all units on the chip at once.
+struct W3Plan {
+    int segs, yblocks, zc, zchunks, units, wgs;
+};
+
+W3Plan wgrad3d_plan(const Geom& in, int pairs) {
+    W3Plan P;
+    P.segs = (in.w + TWG - 1) / TWG;
+    P.yblocks = (in.h + TY - 1) / TY;
+    const int columns = in.n * P.yblocks * P.segs;
+    const int slots = 768 / pairs > 0 ? 768 / pairs : 1;
+    P.zc = 0;
+    for (int zc : {8, 6, 4})
+        if (columns * ((in.d + zc - 1) / zc) >= 3 * slots) {
+            P.zc = zc;
+            break;
+        }
+    if (!P.zc) {
+        P.zc = in.d;
+        for (int zc = 1; zc <= in.d; ++zc)
+            if (columns * ((in.d + zc - 1) / zc) <= slots) {
+                P.zc = zc;
+                break;
+            }
+    }
+    P.zchunks = (in.d + P.zc - 1) / P.zc;
+    P.units = columns * P.zchunks;
+    P.wgs = P.units < slots ? P.units : slots;
+    return P;
 }
+
+}  // namespace
 
 size_t wgrad3d_mfma_scratch_floats(const Geom& in, const Geom& out) {
     const int pairs = ((out.c + 15) / 16) * ((in.c + 15) / 16);
-    return (size_t)wgrad3d_workgroups(in, pairs) * out.c * in.c * 27;
+    return (size_t)wgrad3d_plan(in, pairs).wgs * out.c * in.c * 27;
 }
 
 int launch_wgrad3d_mfma(const Src& a, const Src& b, const float* dz, float* dw, const Geom& in, const Geom& out,
@@ -171,14 +287,18 @@ int launch_wgrad3d_mfma(const Src& a, const Src& b, const float* dz, float* dw, 
     A.H = in.h;
     A.W = in.w;
     A.Cout = out.c;
-    A.segs = (in.w + TWG - 1) / TWG;
-    A.items = in.n * in.d * in.h * A.segs;
     A.ocbs = (out.c + 15) / 16;
     const int pairs = A.ocbs * ((in.c + 15) / 16);
-    const int wgs = wgrad3d_workgroups(in, pairs);
-    hipLaunchKernelGGL(wgrad3d_mfma_kernel, dim3(wgs, pairs), dim3(THREADS), 0, s, A);
+    const W3Plan P = wgrad3d_plan(in, pairs);
+    A.segs = P.segs;
+    A.yblocks = P.yblocks;
+    A.zc = P.zc;
+    A.zchunks = P.zchunks;
+    A.units = P.units;
+    if (b.p) hipLaunchKernelGGL((wgrad3d_mfma_kernel<true>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
+    else hipLaunchKernelGGL((wgrad3d_mfma_kernel<false>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
     if (int rc = check_launch("wgrad3d_mfma")) return rc;
-    return launch_wgrad_reduce_f32(scratch, (size_t)out.c * in.c * 27, wgs, dw, accumulate, s);
+    return launch_wgrad_reduce_f32(scratch, (size_t)out.c * in.c * 27, P.wgs, dw, accumulate, s);
 }
 
 }  // namespace pds
