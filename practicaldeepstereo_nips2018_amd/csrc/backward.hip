@@ -390,9 +390,268 @@ int launch_flip_weights(const float* w, float* wf, int cout, int cin, int taps, 
     return check_launch("flip_weights");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Data gradients of the stride-2 layers, second form (round 4).  The kernels above give a thread ONE input position and
+// walk every output channel and every tap in sequence: the transposed layers issue one strided 4-byte load per 4 FMAs,
+// the strided convolutions test all 27 taps for divisibility per lane (1 to 8 of them contribute), and the small
+// levels of the hourglass (a few thousand positions, 64-128 output channels) run a chain of thousands of dependent
+// iterations on a handful of workgroups.  Here:
+//   unit    one WAVE: one plane iz, RY rows, PW = 64 / RY pairs of adjacent columns (2 j, 2 j + 1) and CB input
+//           channels; a lane owns a column pair, so the loads of a row are shared by both positions (transposed: 6
+//           loads for 8 taps x CB FMAs; strided convolution: 2 loads for 3 taps x CB FMAs) and the stores are dense.
+//   parity  strided convolution: the wave's plane and rows all have ONE parity each (rows 2 r + py), so the taps
+//           that contribute are known per wave -- no divisibility tests, no masked-off work.
+//   OCG     the output channels are dealt to OCG (1, 2 or 4) waves of a workgroup, summed through LDS in wave order
+//           (deterministic): the small levels get 4 x the waves and a quarter of the chain.
+//   weights wave-uniform addresses: scalar loads.
+// ---------------------------------------------------------------------------------------------------
+struct Bwd2Launch {
+    int ry_shift;   // log2(RY)
+    int segs;       // column-pair segments per row
+    int yblocks;    // row blocks (per parity for the strided convolution)
+    int cbs;
+    int units;
+};
+
+template <int CB, int OCG>
+__device__ __forceinline__ void bwd2_reduce_store(float (&acc0)[CB], float (&acc1)[CB], float* red, int wave, int og,
+                                                  int lane, bool live, bool p0, bool p1, float* __restrict__ dst,
+                                                  size_t cstride, int nch) {
+    if (OCG > 1) {
+        // [wave][2 CB][64 lanes]
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            red[(wave * 2 * CB + 2 * c) * 64 + lane] = acc0[c];
+            red[(wave * 2 * CB + 2 * c + 1) * 64 + lane] = acc1[c];
+        }
+        __syncthreads();
+        if (og != 0) return;
+#pragma unroll
+        for (int k = 1; k < OCG; ++k)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                acc0[c] += red[((wave + k) * 2 * CB + 2 * c) * 64 + lane];
+                acc1[c] += red[((wave + k) * 2 * CB + 2 * c + 1) * 64 + lane];
+            }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        if (c < nch) {
+            if (p0) dst[(size_t)c * cstride] = acc0[c];
+            if (p1) dst[(size_t)c * cstride + 1] = acc1[c];
+        }
+}
+
+// transposed conv (kernel (KD,4,4), stride (KD == 4 ? 2 : 1, 2, 2), pad 1; weight [Cin, Cout, KD, 4, 4]):
+//   dx[c][i] = sum_oc sum_k dz[oc][s*i - 1 + k] * W[c][oc][k]
+template <int KD, int CB, int OCG>
+__global__ __launch_bounds__(256) void deconv_bwd_data2_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                               float* __restrict__ dx, const BwdGeom G,
+                                                               const Bwd2Launch Q) {
+    constexpr int SD = KD == 4 ? 2 : 1;
+    __shared__ float red[OCG > 1 ? 4 * 2 * CB * 64 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + wave;
+    const int og = gw % OCG;
+    int u = gw / OCG;
+    const bool live_unit = u < Q.units;
+    u = min(u, Q.units - 1);
+    const int seg = u % Q.segs;
+    u /= Q.segs;
+    const int yb = u % Q.yblocks;
+    u /= Q.yblocks;
+    const int iz = u % G.Di;
+    u /= G.Di;
+    const int c0 = (u % Q.cbs) * CB, n = u / Q.cbs;
+    const int pw = 64 >> Q.ry_shift;
+    const int iy = (yb << Q.ry_shift) + (lane / pw);
+    const int j = seg * pw + (lane & (pw - 1));
+    const int ix0 = 2 * j;
+    const bool rowok = iy < G.Hi;
+    const bool p0 = rowok && ix0 < G.Wi, p1 = rowok && ix0 + 1 < G.Wi;
+
+    int col[6];
+    bool cv[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int ox = 2 * ix0 - 1 + t;
+        cv[t] = ox >= 0 && ox < G.Wo;
+        col[t] = min(max(ox, 0), G.Wo - 1);
+    }
+    float acc0[CB], acc1[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc0[c] = acc1[c] = 0.f;
+    const size_t plane_o = (size_t)G.Ho * G.Wo;
+    if (live_unit)
+        for (int oc = og; oc < G.Cout; oc += OCG) {
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                const int oz = SD * iz - 1 + kd;
+                if (oz < 0 || oz >= G.Do) continue;   // wave-uniform
+                const float* pz = dz + (((size_t)n * G.Cout + oc) * G.Do + oz) * plane_o;
+#pragma unroll
+                for (int kh = 0; kh < 4; ++kh) {
+                    const int oy = 2 * iy - 1 + kh;
+                    const bool yv = oy >= 0 && oy < G.Ho;
+                    const float* pr = pz + (size_t)min(max(oy, 0), G.Ho - 1) * G.Wo;
+                    float v[6];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) v[t] = pr[col[t]];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) v[t] = (yv && cv[t]) ? v[t] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        const int ci = min(c0 + c, G.Cin - 1);
+                        const float* wp = w + (((size_t)ci * G.Cout + oc) * KD + kd) * 16 + kh * 4;
+                        const float w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                        acc0[c] = fmaf(v[0], w0, fmaf(v[1], w1, fmaf(v[2], w2, fmaf(v[3], w3, acc0[c]))));
+                        acc1[c] = fmaf(v[2], w0, fmaf(v[3], w1, fmaf(v[4], w2, fmaf(v[5], w3, acc1[c]))));
+                    }
+                }
+            }
+        }
+    const size_t cstride = (size_t)G.Di * G.Hi * G.Wi;
+    float* dst = dx + ((size_t)n * G.Cin + c0) * cstride + ((size_t)iz * G.Hi + min(iy, G.Hi - 1)) * G.Wi + min(ix0, G.Wi - 1);
+    bwd2_reduce_store<CB, OCG>(acc0, acc1, red, wave, og, lane, live_unit, p0, p1, dst, cstride, G.Cin - c0);
+}
+
+// conv (3 x 3 x 3, stride 2, pad 1; weight [Cout, Cin, 3, 3, 3]):  dx[c][i] = sum over (o, k) with 2 o - 1 + k = i.
+// Per axis: i even -> k = 1, o = i / 2;  i odd -> k = 0, o = (i + 1) / 2 (if it exists) and k = 2, o = (i - 1) / 2.
+template <int CB, int OCG>
+__global__ __launch_bounds__(256) void conv_s2_bwd_data2_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                float* __restrict__ dx, const BwdGeom G,
+                                                                const Bwd2Launch Q) {
+    __shared__ float red[OCG > 1 ? 4 * 2 * CB * 64 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + wave;
+    const int og = gw % OCG;
+    int u = gw / OCG;
+    const bool live_unit = u < Q.units;
+    u = min(u, Q.units - 1);
+    const int seg = u % Q.segs;
+    u /= Q.segs;
+    const int yb = u % Q.yblocks;
+    u /= Q.yblocks;
+    const int py = u & 1;
+    u >>= 1;
+    const int iz = u % G.Di;
+    u /= G.Di;
+    const int c0 = (u % Q.cbs) * CB, n = u / Q.cbs;
+    const int pw = 64 >> Q.ry_shift;
+    const int iy = 2 * ((yb << Q.ry_shift) + (lane / pw)) + py;
+    const int j = seg * pw + (lane & (pw - 1));
+    const int ix0 = 2 * j;
+    const bool rowok = iy < G.Hi;
+    const bool p0 = rowok && ix0 < G.Wi, p1 = rowok && ix0 + 1 < G.Wi;
+
+    // the contributing taps of the plane (wave-uniform) and of the row (same count for every lane, positions differ)
+    int nz, kdl[2], ozl[2];
+    if (iz & 1) {
+        nz = 0;
+        if ((iz + 1) / 2 < G.Do) {
+            kdl[nz] = 0;
+            ozl[nz++] = (iz + 1) / 2;
+        }
+        kdl[nz] = 2;
+        ozl[nz++] = (iz - 1) / 2;
+    } else {
+        nz = 1;
+        kdl[0] = 1;
+        ozl[0] = iz / 2;
+    }
+    const int ny = py ? 2 : 1;
+    const bool xv0 = j < G.Wo, xv1 = j + 1 < G.Wo;
+    const int xc0 = min(j, G.Wo - 1), xc1 = min(j + 1, G.Wo - 1);
+
+    float acc0[CB], acc1[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc0[c] = acc1[c] = 0.f;
+    const size_t plane_o = (size_t)G.Ho * G.Wo;
+    if (live_unit)
+        for (int oc = og; oc < G.Cout; oc += OCG) {
+            for (int a = 0; a < nz; ++a) {
+                const float* pz = dz + (((size_t)n * G.Cout + oc) * G.Do + ozl[a]) * plane_o;
+                for (int b = 0; b < ny; ++b) {
+                    // row taps: even row -> kh = 1, oy = iy / 2; odd row -> (kh = 0, oy = (iy + 1) / 2), (kh = 2, oy = (iy - 1) / 2)
+                    const int kh = py ? 2 * b : 1;
+                    const int oy = py ? (b == 0 ? (iy + 1) / 2 : (iy - 1) / 2) : iy / 2;
+                    const bool yv = oy < G.Ho;
+                    const float* pr = pz + (size_t)min(oy, G.Ho - 1) * G.Wo;
+                    float v0 = pr[xc0], v1 = pr[xc1];
+                    v0 = (yv && xv0) ? v0 : 0.f;
+                    v1 = (yv && xv1) ? v1 : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        const int ci = min(c0 + c, G.Cin - 1);
+                        const float* wp = w + ((((size_t)oc * G.Cin + ci) * 3 + kdl[a]) * 3 + kh) * 3;
+                        acc0[c] = fmaf(v0, wp[1], acc0[c]);                      // even column: kw = 1, ox = j
+                        acc1[c] = fmaf(v1, wp[0], fmaf(v0, wp[2], acc1[c]));     // odd column: kw = 0 at j + 1, kw = 2 at j
+                    }
+                }
+            }
+        }
+    const size_t cstride = (size_t)G.Di * G.Hi * G.Wi;
+    float* dst = dx + ((size_t)n * G.Cin + c0) * cstride + ((size_t)iz * G.Hi + min(iy, G.Hi - 1)) * G.Wi + min(ix0, G.Wi - 1);
+    bwd2_reduce_store<CB, OCG>(acc0, acc1, red, wave, og, lane, live_unit, p0, p1, dst, cstride, G.Cin - c0);
+}
+
+namespace {
+
+template <int CB, int OCG>
+void launch_bwd2_variant(int transposed, int kd, const float* dz, const float* w, float* dx, const BwdGeom& G,
+                         const Bwd2Launch& Q, hipStream_t s) {
+    const unsigned wgs = (unsigned)(((size_t)Q.units * OCG + 3) / 4);
+    if (!transposed)
+        hipLaunchKernelGGL((conv_s2_bwd_data2_kernel<CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+    else if (kd == 4)
+        hipLaunchKernelGGL((deconv_bwd_data2_kernel<4, CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+    else
+        hipLaunchKernelGGL((deconv_bwd_data2_kernel<3, CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+}
+
+// transposed (kd 3 or 4) or strided convolution (kd 3, stride 2)
+int launch_bwd_data2(int transposed, int kd, const float* dz, const float* w, float* dx, const BwdGeom& G, hipStream_t s) {
+    Bwd2Launch Q;
+    const int pairs = (G.Wi + 1) / 2;
+    int pw = 64;
+    while (pw > 8 && pw / 2 >= pairs) pw /= 2;        // narrow levels: several rows per wave
+    Q.ry_shift = pw == 64 ? 0 : pw == 32 ? 1 : pw == 16 ? 2 : 3;
+    const int ry = 64 / pw;
+    Q.segs = (pairs + pw - 1) / pw;
+    const int rows = transposed ? G.Hi : (G.Hi + 1) / 2;   // rows per parity for the strided convolution
+    Q.yblocks = (rows + ry - 1) / ry;
+    const int cb = (G.Cin % 8 == 0) ? 8 : 4;
+    Q.cbs = (G.Cin + cb - 1) / cb;
+    Q.units = G.N * Q.cbs * G.Di * (transposed ? 1 : 2) * Q.yblocks * Q.segs;
+    // enough waves to fill the chip (256 CUs x 16 wave slots) before the output channels stay with one wave
+    int ocg = 1;
+    while (ocg < 4 && (size_t)Q.units * ocg < 4096 && G.Cout >= 8 * ocg) ocg *= 2;
+    if (cb == 8) {
+        if (ocg == 1) launch_bwd2_variant<8, 1>(transposed, kd, dz, w, dx, G, Q, s);
+        else if (ocg == 2) launch_bwd2_variant<8, 2>(transposed, kd, dz, w, dx, G, Q, s);
+        else launch_bwd2_variant<8, 4>(transposed, kd, dz, w, dx, G, Q, s);
+    } else {
+        if (ocg == 1) launch_bwd2_variant<4, 1>(transposed, kd, dz, w, dx, G, Q, s);
+        else if (ocg == 2) launch_bwd2_variant<4, 2>(transposed, kd, dz, w, dx, G, Q, s);
+        else launch_bwd2_variant<4, 4>(transposed, kd, dz, w, dx, G, Q, s);
+    }
+    return check_launch("bwd_data2");
+}
+
+}  // namespace
+
 int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const float* w, float* dx, const Geom& in,
                     const Geom& out, hipStream_t s) {
     BwdGeom G{in.n, in.c, in.d, in.h, in.w, out.c, out.d, out.h, out.w};
+    static const bool v2 = []() {   // PDS_BWD_DATA_V2=0 keeps the one-position-per-thread kernels (A/B, debugging)
+        const char* e = getenv("PDS_BWD_DATA_V2");
+        return !(e && e[0] == '0');
+    }();
+    if (v2 && ((transposed && (kd == 3 || kd == 4)) || (!transposed && kd == 3 && stride == 2)))
+        return launch_bwd_data2(transposed, kd, dz, w, dx, G, s);
     constexpr int CB = 4;
     dim3 grid((unsigned)((in.h * in.w + 255) / 256), in.d, in.n * ((in.c + CB - 1) / CB));
     if (!transposed) {

@@ -10,9 +10,13 @@
 // without both certificates keeps the exact-fp32 kernel.
 //
 // GEMM view: M = 64 output channels, N = (input channel, tap), K = positions, 16 per MFMA.
-//   work item   2 rows x 32 columns of one (n, d) plane = four K-steps; persistent workgroups stride over the items, keep
-//               their partial dW in registers and write ONE partial per workgroup (fp32; a second kernel sums the
-//               partials in fp64 in a fixed order: deterministic).
+//   work unit   a strip 32 columns wide of one (n, d) plane, walked downwards two rows (four K-steps) at a time over a
+//               chunk of rows.  The four xhat rows of a step live in an LDS ring: a step stages only its two NEW rows
+//               (the one-step-per-item form of the first version staged all four every time: 1.6 GB through the
+//               memory path for a 64 -> 64 layer of MatchingOperation, which is what bounded it), and their global
+//               loads are issued before the MFMAs of the step before.  Persistent workgroups stride over the units,
+//               keep their partial dW in registers and write ONE partial per workgroup (fp32; a second kernel sums
+//               the partials in fp64 in a fixed order: deterministic).
 //   workgroup   4 waves, two workgroups per CU (67.6 KB of LDS each): one stages while the other multiplies.  Wave w owns
 //               the 16 input channels of block w, all nine taps and all 64 output channels: 4 x 9 accumulator tiles =
 //               144 registers.  The B fragments of a wave are its own; the A fragments (dz) are shared by the four waves.
@@ -51,7 +55,7 @@ struct WX3Args {
     int dz_bound_n;
     float* __restrict__ partial;  // [workgroup][64][Cin][9]
     int N, Cin, D, H, W, Cout;
-    int items, segs, rowpairs;
+    int units, segs, rowpairs, chunks, ch;   // a unit = one 32-column strip of one plane over `ch` row pairs
 };
 
 __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
@@ -61,6 +65,9 @@ __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo
         lo[i] = (_Float16)(v[i] - (float)hi[i]);
     }
 }
+
+template <int V>
+using IC = std::integral_constant<int, V>;
 
 __device__ __forceinline__ f16x4 as_f16x4(unsigned lo, unsigned hi) { return __builtin_bit_cast(f16x4, u32x2{lo, hi}); }
 
@@ -98,142 +105,189 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
     const _Float16* arow = dl + (lane & 15) * CSD + frag_k;
     const _Float16* brow = xs + (wave * 16 + (lane & 15)) * CSX + frag_k;
 
-    for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
-        int r = item;
+    // what a thread stages per step: 5 quads of two xhat rows (64 channels x 2 rows x 10 quads = 1280 slots), MB quads of dz
+    // registers for the next step's operands in flight during the MFMAs: the single-source 64 -> 64 form (144
+    // accumulator registers) has room for its xhat quads, the 16-output-channel form for everything; the two-source
+    // 64 -> 64 form loads after the MFMAs, two quads at a time
+    constexpr bool PREFETCH = !HAS_B || MB == 1, PREFETCH_DZ = MB == 1;
+    constexpr int PF = MB == 1 ? 5 : 3;   // quads in flight
+    f32x4 qa[5], qb[HAS_B ? 5 : 1], qz[MB];
+
+    for (int unit = blockIdx.x; unit < A.units; unit += gridDim.x) {
+        int r = unit;
+        const int chunk = r % A.chunks;
+        r /= A.chunks;
         const int seg = r % A.segs;
         r /= A.segs;
-        const int ry = r % A.rowpairs;
-        r /= A.rowpairs;
         const int d = r % A.D;
         const int n = r / A.D;
-        const int x0 = seg * TWG, y0 = ry * TR;
+        const int x0 = seg * TWG;
+        const int ry0 = chunk * A.ch, ry1 = min(ry0 + A.ch, A.rowpairs);
+        const unsigned cstride = (unsigned)(A.D * (int)plane);
+        const float* abase = A.a.p + ((size_t)(n * A.Cin + cg0) * A.D + d) * plane;
+        const float* bbase = HAS_B ? A.b.p + ((size_t)(n * A.Cin + cg0) * A.D + d) * plane : nullptr;
+        const float* zbase = A.dz + ((size_t)n * A.Cout * A.D + d) * plane;
 
-        // ---- stage xhat: 64 channels x 4 rows x 10 aligned quads (columns x0 - 4 .. x0 + 35), 10 quads per thread ----
-        // A run of 10 consecutive threads covers one (channel, row): 160 contiguous bytes.  The deferred InstanceNorm,
-        // the skip sum, the literal zero padding and the fp16 split are applied on the way to LDS.
-        // (batches of two quads per source: the 144 accumulator registers leave room for no more in flight, and the
-        // other workgroup of the CU covers the load latency with its MFMAs)
-        constexpr int BATCH = (MB == 1 || !HAS_B) ? 5 : 2;
-#pragma unroll 1
-        for (int half = 0; half < 10 / BATCH; ++half) {
-            f32x4 qa[BATCH], qb[HAS_B ? BATCH : 1];
-            float sa[BATCH], ha[BATCH], sb2[BATCH], hb2[BATCH];
-            bool ok[BATCH];
-            int dst[BATCH];
+        // ---- xhat rows ybase, ybase + 1: columns x0 - 4 .. x0 + 35 as 10 aligned quads; a run of 10 consecutive threads
+        // covers one (channel, row): 160 contiguous bytes.  Row y lives in ring slot (y + 1) & 3 of the 4-row tile: a step
+        // (rows y0 - 1 .. y0 + 2) keeps the two lower rows of the step before it and stages only two new ones.
+        auto load_rows = [&](int ybase, auto J0, auto J1) __attribute__((always_inline)) {   // quads J0 .. J1 - 1 of the thread's five
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                const int slot = tid + (half * BATCH + j) * THREADS;     // < 2560
-                const int q = slot % 10, cr = slot / 10, c = cr / XR, rr = cr - c * XR;
-                const int x = x0 - 4 + 4 * q, y = y0 - 1 + rr;
-                ok[j] = x >= 0 && x < A.W && y >= 0 && y < A.H;
+            for (int j = decltype(J0)::value; j < decltype(J1)::value; ++j) {
+                const int slot = tid + j * THREADS;     // < 1280
+                const int q = slot % 10, cr = slot / 10, c = cr >> 1, rr = cr & 1;
+                const int x = x0 - 4 + 4 * q, y = ybase + rr;
                 const int xc = min(max(x, 0), A.W - 4), yc = min(max(y, 0), A.H - 1);
+                // a wave-uniform base and a 32-bit lane offset (64 channel volumes stay below 2^31 elements: launcher)
+                const unsigned off = (unsigned)c * cstride + (unsigned)(yc * A.W + xc);
+                qa[j] = *reinterpret_cast<const f32x4*>(abase + off);
+                if (HAS_B) qb[j] = *reinterpret_cast<const f32x4*>(bbase + off);
+            }
+        };
+        // the deferred InstanceNorm, the skip sum, the literal zero padding and the fp16 split, on the way to LDS
+        auto store_rows = [&](int ybase, auto J0, auto J1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = decltype(J0)::value; j < decltype(J1)::value; ++j) {
+                const int slot = tid + j * THREADS;
+                const int q = slot % 10, cr = slot / 10, c = cr >> 1, rr = cr & 1;
+                const int x = x0 - 4 + 4 * q, y = ybase + rr;
+                const bool ok = x >= 0 && x < A.W && y >= 0 && y < A.H;
                 const int ch = cg0 + c;
-                const size_t off = ((size_t)(n * A.Cin + ch) * A.D + d) * plane + (size_t)yc * A.W + xc;
-                qa[j] = *reinterpret_cast<const f32x4*>(A.a.p + off);
-                if (HAS_B) qb[j] = *reinterpret_cast<const f32x4*>(A.b.p + off);
-                sa[j] = 1.f;
-                ha[j] = 0.f;
+                float sa = 1.f, ha = 0.f, sb2 = 1.f, hb2 = 0.f;
                 if (A.a.scale) {
                     const int g = A.a.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
-                    sa[j] = A.a.scale[g];
-                    ha[j] = A.a.shift[g];
+                    sa = A.a.scale[g];
+                    ha = A.a.shift[g];
                 }
-                sb2[j] = 1.f;
-                hb2[j] = 0.f;
                 if (HAS_B && A.b.scale) {
                     const int g = A.b.per_plane ? ((n * A.Cin + ch) * A.D + d) : (n * A.Cin + ch);
-                    sb2[j] = A.b.scale[g];
-                    hb2[j] = A.b.shift[g];
+                    sb2 = A.b.scale[g];
+                    hb2 = A.b.shift[g];
                 }
-                dst[j] = c * CSX + rr * RSX + 4 * q;
-            }
-#pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(sa[j], qa[j][e], ha[j]);
-                    if (HAS_B) t += fmaf(sb2[j], qb[j][e], hb2[j]);
-                    v[e] = ok[j] ? t * as : 0.f;
+                    float t = fmaf(sa, qa[j][e], ha);
+                    if (HAS_B) t += fmaf(sb2, qb[j][e], hb2);
+                    v[e] = ok ? t * as : 0.f;
                 }
                 f16x4 hi, lo;
                 split4(v, hi, lo);
-                *reinterpret_cast<f16x4*>(xs + dst[j]) = hi;
-                *reinterpret_cast<f16x4*>(xs + XPART + dst[j]) = lo;
+                const int dst = c * CSX + ((y + 1) & 3) * RSX + 4 * q;
+                *reinterpret_cast<f16x4*>(xs + dst) = hi;
+                *reinterpret_cast<f16x4*>(xs + XPART + dst) = lo;
             }
-        }
-        // ---- stage dz: 16 MB output channels x 2 rows x 8 quads, MB quads per thread -------------------------------
-        constexpr int ZB = MB >= 2 ? 2 : 1;
-#pragma unroll 1
-        for (int half = 0; half < MB / ZB; ++half) {
-            f32x4 qz[ZB];
-            bool ok[ZB];
-            int dst[ZB];
+        };
+        // ---- dz rows y0, y0 + 1: 16 MB output channels x 2 rows x 8 quads, MB quads per thread --------------------------
+        auto load_dz = [&](int y0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < ZB; ++j) {
-                const int slot = tid + (half * ZB + j) * THREADS;     // < 256 MB
+            for (int j = 0; j < MB; ++j) {
+                const int slot = tid + j * THREADS;     // < 256 MB
                 const int q = slot & 7, rr = (slot >> 3) & 1, oc = slot >> 4;
-                const int x = x0 + 4 * q, y = y0 + rr;
-                ok[j] = x < A.W && y < A.H && oc < A.Cout;
-                const int xc = min(x, A.W - 4), yc = min(y, A.H - 1), occ = min(oc, A.Cout - 1);
-                qz[j] = *reinterpret_cast<const f32x4*>(A.dz + ((size_t)(n * A.Cout + occ) * A.D + d) * plane +
-                                                        (size_t)yc * A.W + xc);
-                dst[j] = oc * CSD + rr * TWG + 4 * q;
+                const int xc = min(x0 + 4 * q, A.W - 4), yc = min(y0 + rr, A.H - 1), occ = min(oc, A.Cout - 1);
+                qz[j] = *reinterpret_cast<const f32x4*>(zbase + ((unsigned)occ * cstride + (unsigned)(yc * A.W + xc)));
             }
+        };
+        auto store_dz = [&](int y0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < ZB; ++j) {
+            for (int j = 0; j < MB; ++j) {
+                const int slot = tid + j * THREADS;
+                const int q = slot & 7, rr = (slot >> 3) & 1, oc = slot >> 4;
+                const bool ok = x0 + 4 * q < A.W && y0 + rr < A.H && oc < A.Cout;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ok[j] ? qz[j][e] * ds : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = ok ? qz[j][e] * ds : 0.f;
                 f16x4 hi, lo;
                 split4(v, hi, lo);
-                *reinterpret_cast<f16x4*>(dl + dst[j]) = hi;
-                *reinterpret_cast<f16x4*>(dl + DPART + dst[j]) = lo;
+                const int dst = oc * CSD + rr * TWG + 4 * q;
+                *reinterpret_cast<f16x4*>(dl + dst) = hi;
+                *reinterpret_cast<f16x4*>(dl + DPART + dst) = lo;
             }
-        }
+        };
+
+        // ---- prologue: all four rows of the first step (the barrier closing the previous unit released the tiles) ------
+        auto stage_rows = [&](int ybase) __attribute__((always_inline)) {   // load and store back to back, in batches the registers have room for
+            if (PREFETCH) {
+                load_rows(ybase, IC<0>{}, IC<5>{});
+                store_rows(ybase, IC<0>{}, IC<5>{});
+            } else {
+                load_rows(ybase, IC<0>{}, IC<1>{});
+                store_rows(ybase, IC<0>{}, IC<1>{});
+                load_rows(ybase, IC<1>{}, IC<2>{});
+                store_rows(ybase, IC<1>{}, IC<2>{});
+                load_rows(ybase, IC<2>{}, IC<3>{});
+                store_rows(ybase, IC<2>{}, IC<3>{});
+                load_rows(ybase, IC<3>{}, IC<4>{});
+                store_rows(ybase, IC<3>{}, IC<4>{});
+                load_rows(ybase, IC<4>{}, IC<5>{});
+                store_rows(ybase, IC<4>{}, IC<5>{});
+            }
+        };
+        stage_rows(2 * ry0 - 1);
+        stage_rows(2 * ry0 + 1);
+        load_dz(2 * ry0);
+        store_dz(2 * ry0);
         __syncthreads();
 
-        // ---- four K-steps of 16 positions: (row r2, half hs) ----------------------------------------------------------
+        for (int ry = ry0; ry < ry1; ++ry) {
+            const int y0 = ry * TR;
+            const bool more = ry + 1 < ry1;
+            if (PREFETCH && more) load_rows(y0 + 3, IC<0>{}, IC<PF>{});     // the next step's two new rows (and its dz): in flight
+            if (PREFETCH_DZ && more) load_dz(y0 + 2);    // during the MFMAs
+            const int ring = y0 & 3;   // slot of row y0 - 1
+            // ---- four K-steps of 16 positions: (row r2, half hs) ------------------------------------------------------
 #pragma unroll 1
-        for (int ks = 0; ks < TR * 2; ++ks) {
-            const int r2 = ks >> 1, hs = ks & 1;
-            f16x4 ah[MB], al[MB];
+            for (int ks = 0; ks < TR * 2; ++ks) {
+                const int r2 = ks >> 1, hs = ks & 1;
+                f16x4 ah[MB], al[MB];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                ah[m] = *reinterpret_cast<const f16x4*>(arow + m * 16 * CSD + r2 * TWG + 16 * hs);
-                al[m] = *reinterpret_cast<const f16x4*>(arow + DPART + m * 16 * CSD + r2 * TWG + 16 * hs);
-            }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const _Float16* bp = brow + (r2 + dy) * RSX + 16 * hs;
-                // three aligned groups per part: S[b .. b+3], S[b+4 .. b+7], S[b+8 .. b+11]
-                u32x2 g[2][3];
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) g[p][k] = *reinterpret_cast<const u32x2*>(bp + p * XPART + 4 * k);
-                f16x4 bf[2][3];   // [part][dx]: window S[b + 3 + dx .. b + 6 + dx]
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const unsigned mid = __builtin_amdgcn_alignbit(g[p][1][1], g[p][1][0], 16);   // {G1.e1, G1.e2}
-                    bf[p][0] = as_f16x4(__builtin_amdgcn_alignbit(g[p][1][0], g[p][0][1], 16), mid);   // {G0.e3, G1.e0..e2}
-                    bf[p][1] = as_f16x4(g[p][1][0], g[p][1][1]);                                        // G1
-                    bf[p][2] = as_f16x4(mid, __builtin_amdgcn_alignbit(g[p][2][0], g[p][1][1], 16));    // {G1.e1..e3, G2.e0}
+                for (int m = 0; m < MB; ++m) {
+                    ah[m] = *reinterpret_cast<const f16x4*>(arow + m * 16 * CSD + r2 * TWG + 16 * hs);
+                    al[m] = *reinterpret_cast<const f16x4*>(arow + DPART + m * 16 * CSD + r2 * TWG + 16 * hs);
                 }
-                // small partial products first; consecutive MFMAs hit different accumulators
 #pragma unroll
-                for (int prod = 0; prod < 3; ++prod)
+                for (int dy = 0; dy < 3; ++dy) {
+                    const _Float16* bp = brow + ((ring + r2 + dy) & 3) * RSX + 16 * hs;
+                    // three aligned groups per part: S[b .. b+3], S[b+4 .. b+7], S[b+8 .. b+11]
+                    u32x2 g[2][3];
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
+                    for (int p = 0; p < 2; ++p)
 #pragma unroll
-                        for (int m = 0; m < MB; ++m) {
-                            const f16x4 av = prod == 1 ? al[m] : ah[m];
-                            const f16x4 bv = prod == 0 ? bf[1][dx] : bf[0][dx];
-                            acc[m][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc[m][dy * 3 + dx], 0, 0, 0);
-                        }
+                        for (int k = 0; k < 3; ++k) g[p][k] = *reinterpret_cast<const u32x2*>(bp + p * XPART + 4 * k);
+                    f16x4 bf[2][3];   // [part][dx]: window S[b + 3 + dx .. b + 6 + dx]
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const unsigned mid = __builtin_amdgcn_alignbit(g[p][1][1], g[p][1][0], 16);   // {G1.e1, G1.e2}
+                        bf[p][0] = as_f16x4(__builtin_amdgcn_alignbit(g[p][1][0], g[p][0][1], 16), mid);   // {G0.e3, G1.e0..e2}
+                        bf[p][1] = as_f16x4(g[p][1][0], g[p][1][1]);                                        // G1
+                        bf[p][2] = as_f16x4(mid, __builtin_amdgcn_alignbit(g[p][2][0], g[p][1][1], 16));    // {G1.e1..e3, G2.e0}
+                    }
+                    // small partial products first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                            for (int m = 0; m < MB; ++m) {
+                                const f16x4 av = prod == 1 ? al[m] : ah[m];
+                                const f16x4 bv = prod == 0 ? bf[1][dx] : bf[0][dx];
+                                acc[m][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc[m][dy * 3 + dx], 0, 0, 0);
+                            }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                if (PREFETCH) {   // into the slots of rows y0 - 1 and y0
+                    if (PF < 5) load_rows(y0 + 3, IC<PF>{}, IC<5>{});
+                    store_rows(y0 + 3, IC<0>{}, IC<5>{});
+                } else {
+                    stage_rows(y0 + 3);
+                }
+                if (!PREFETCH_DZ) load_dz(y0 + 2);
+                store_dz(y0 + 2);
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
 
     // ---- one partial per workgroup: [Cout][Cin][9] -----------------------------------------------------------------
@@ -256,6 +310,7 @@ bool wgrad2d_x3_supported(const Src& a, const Src& b, const Src& dz, const Geom&
         return !(e && e[0] == '0');
     }();
     if (!enabled || !(out.c == 64 || out.c <= 16) || in.c % CG != 0 || (in.w & 3) != 0) return false;
+    if ((size_t)64 * in.d * in.h * in.w >= ((size_t)1 << 31)) return false;   // 32-bit offsets inside a 64-channel group
     if (!dz.bound || dz.bound_n <= 0 || !a.bound || a.bound_n <= 0 || (b.p && (!b.bound || b.bound_n <= 0 || b.bcast_d)))
         return false;
     if ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(b.p) | reinterpret_cast<uintptr_t>(dz.p)) & 15)
@@ -280,7 +335,14 @@ int launch_wgrad2d_x3(const Src& a, const Src& b, const Src& dz, float* partial,
     A.W = in.w;
     A.segs = (in.w + TWG - 1) / TWG;
     A.rowpairs = (in.h + TR - 1) / TR;
-    A.items = in.n * in.d * A.rowpairs * A.segs;
+    // strips are cut into chunks of row pairs: a chunk stages two halo rows once, so long chunks stage less; at least
+    // ~4 units per workgroup keep the persistent workgroups balanced
+    const int strips = in.n * in.d * A.segs;
+    int chunks = (4 * workgroups + strips - 1) / strips;
+    chunks = chunks < 1 ? 1 : chunks > A.rowpairs ? A.rowpairs : chunks;
+    A.ch = (A.rowpairs + chunks - 1) / chunks;
+    A.chunks = (A.rowpairs + A.ch - 1) / A.ch;
+    A.units = strips * A.chunks;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2d_x3_kernel<true, 4>),

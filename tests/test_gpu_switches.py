@@ -41,3 +41,25 @@ def test_alternative_paths(hip_library, switch):
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = out.stdout.decode(errors='replace')[-2000:]
     assert out.returncode == 0, tail
+
+
+# the kernel choices of the backward pass: every alternative must reproduce the oracle's gradients
+BACKWARD_SWITCHES = [
+    {'PDS_WGRAD2D_X3': '0'},          # 2-D weight gradients on the exact-fp32 MFMA kernel
+    {'PDS_BWD_DATA_V2': '0'},         # stride-2 data gradients on the one-position-per-thread kernels of round 2
+    {'PDS_WGRAD3D_MFMA': '0', 'PDS_WGRAD3D_S2_MFMA': '0'},   # 3-D weight gradients on the VALU kernels
+]
+
+
+@pytest.mark.parametrize('switch', BACKWARD_SWITCHES, ids=lambda s: '_'.join('%s=%s' % kv for kv in s.items()))
+def test_alternative_backward_paths(hip_library, switch):
+    env = dict(os.environ)
+    env.update(switch)
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+           'tests/test_gpu_backward.py::test_matching_operation_backward',
+           'tests/test_gpu_backward.py::test_matching_training_route_backward',
+           'tests/test_gpu_backward.py::test_regularization_backward',
+           'tests/test_gpu_backward.py::test_standalone_blocks_backward']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = out.stdout.decode(errors='replace')[-2000:]
+    assert out.returncode == 0, tail
