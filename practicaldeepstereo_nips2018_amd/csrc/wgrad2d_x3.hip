@@ -4,12 +4,12 @@
 // wgrad2d_mfma.hip runs this contraction on v_mfma_f32_16x16x4_f32 (1/16 of the 16-bit MFMA rate): 11 launches x 1.2 ms =
 // a third of the config-5 training step.  Here both operands are split into two fp16 parts exactly as in conv2d_x3.hip
 // (hi = fp16(v), lo = fp16(v - hi): 22 significand bits) and a product is hi*lo + lo*hi + hi*hi on
-// v_mfma_f32_16x16x16_f16 with fp32 accumulation.  Both operands are pre-scaled by powers of two derived from the data:
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation.  Both operands are pre-scaled by powers of two derived from the data:
 // xhat by its range certificate (common.hpp Src::bound), dz by max|dz|, which the InstanceNorm backward that writes dz
 // collects (backward.hip in_bwd_apply_kernel); the partial sums are multiplied back when they are written.  A layer
 // without both certificates keeps the exact-fp32 kernel.
 //
-// GEMM view: M = 64 output channels, N = (input channel, tap), K = positions, 16 per MFMA.
+// GEMM view: M = 64 output channels, N = (input channel, tap), K = positions, 32 per MFMA.
 //   work unit   a strip 32 columns wide of one (n, d) plane, walked downwards two rows (four K-steps) at a time over a
 //               chunk of rows.  The four xhat rows of a step live in an LDS ring: a step stages only its two NEW rows
 //               (the one-step-per-item form of the first version staged all four every time: 1.6 GB through the
@@ -23,9 +23,12 @@
 //   LDS         xhat [part][64 ch][4 rows][40] fp16, S[j] holds column x0 - 4 + j, so that an aligned 16-byte global
 //               load lands as one aligned 8-byte LDS write per part; dz [part][64 oc][2 rows x 32].  Channel strides
 //               == 2 dwords (mod 32): the 16 lanes x 8 bytes of a fragment read cover all 32 banks once.
-//   taps        a lane's B fragment is four CONSECUTIVE positions of one channel; the three kernel columns are the
-//               windows S[b + 3 + dx .. b + 6 + dx]: three aligned 8-byte reads (b, b + 4, b + 8) per part and three
-//               v_alignbit give all of them -- no unaligned LDS access, no re-staging per tap.
+//   taps        a lane's B fragment is eight CONSECUTIVE positions of one channel (v_mfma_f32_16x16x32_f16: K = 32 = one
+//               row of the strip; the 16-position v_mfma_f32_16x16x16_f16 of the first version issues at HALF the rate
+//               on gfx950 -- tools/ubench/mfma_rate.hip: 1.10 against 2.12 PFLOP/s chip-wide -- and bounded the kernel:
+//               606 -> 428 us per 64 -> 64 layer); the three kernel columns are the windows S[b + 3 + dx .. b + 10 + dx]:
+//               four aligned 8-byte reads (b, b + 4, b + 8, b + 12) per part and v_alignbit give all of them -- no
+//               unaligned LDS access, no re-staging per tap.
 #include "common.hpp"
 
 namespace pds {
@@ -46,7 +49,9 @@ static_assert(CSX % 64 == 4 && CSD % 64 == 4, "conflict-free fragment reads");
 static_assert(lds_bytes(4) <= 80 * 1024, "two workgroups per CU");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WX3Args {
     Src a, b;
@@ -69,7 +74,9 @@ __device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo
 template <int V>
 using IC = std::integral_constant<int, V>;
 
-__device__ __forceinline__ f16x4 as_f16x4(unsigned lo, unsigned hi) { return __builtin_bit_cast(f16x4, u32x2{lo, hi}); }
+__device__ __forceinline__ f16x8 join8(u32x2 lo, u32x2 hi) {
+    return __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+}
 
 }  // namespace
 
@@ -101,16 +108,16 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
         for (int t = 0; t < 9; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses (elements): A: row m = lane & 15 of output block mb, positions 4 kg ..; B: channel n = lane & 15
-    const int frag_k = 4 * (lane >> 4);
+    const int frag_k = 8 * (lane >> 4);
     const _Float16* arow = dl + (lane & 15) * CSD + frag_k;
     const _Float16* brow = xs + (wave * 16 + (lane & 15)) * CSX + frag_k;
 
     // what a thread stages per step: 5 quads of two xhat rows (64 channels x 2 rows x 10 quads = 1280 slots), MB quads of dz
-    // registers for the next step's operands in flight during the MFMAs: the single-source 64 -> 64 form (144
-    // accumulator registers) has room for its xhat quads, the 16-output-channel form for everything; the two-source
-    // 64 -> 64 form loads after the MFMAs, two quads at a time
-    constexpr bool PREFETCH = !HAS_B || MB == 1, PREFETCH_DZ = MB == 1;
-    constexpr int PF = MB == 1 ? 5 : 3;   // quads in flight
+    // the 16-output-channel form has registers for the next step's operands in flight during its MFMAs; the 64 -> 64 forms
+    // (144 accumulator registers + 32 of A fragments) load after the MFMAs, a quad at a time -- measured with three of the
+    // five xhat quads in flight: 428 -> 471 us (the allocator spills inside the K loop); the other workgroup of the CU
+    // covers the latency
+    constexpr bool PREFETCH = MB == 1;
     f32x4 qa[5], qb[HAS_B ? 5 : 1], qz[MB];
 
     for (int unit = blockIdx.x; unit < A.units; unit += gridDim.x) {
@@ -232,58 +239,64 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
         for (int ry = ry0; ry < ry1; ++ry) {
             const int y0 = ry * TR;
             const bool more = ry + 1 < ry1;
-            if (PREFETCH && more) load_rows(y0 + 3, IC<0>{}, IC<PF>{});     // the next step's two new rows (and its dz): in flight
-            if (PREFETCH_DZ && more) load_dz(y0 + 2);    // during the MFMAs
+            if (PREFETCH && more) {   // the next step's two new rows and its dz: in flight during the MFMAs
+                load_rows(y0 + 3, IC<0>{}, IC<5>{});
+                load_dz(y0 + 2);
+            }
             const int ring = y0 & 3;   // slot of row y0 - 1
-            // ---- four K-steps of 16 positions: (row r2, half hs) ------------------------------------------------------
+            // ---- two K-steps of 32 positions (one row each) on v_mfma_f32_16x16x32_f16: a lane holds EIGHT consecutive
+            // positions of its row of A (dz) and of its channel of B (xhat); the sum over K does not care which eight, as
+            // long as A and B agree.  The kernel columns are the windows S[b + 3 + dx .. b + 10 + dx], b = 8 (lane >> 4):
+            // four aligned 8-byte reads (b, b + 4, b + 8, b + 12) per part and v_alignbit give all three.
 #pragma unroll 1
-            for (int ks = 0; ks < TR * 2; ++ks) {
-                const int r2 = ks >> 1, hs = ks & 1;
-                f16x4 ah[MB], al[MB];
+            for (int r2 = 0; r2 < TR; ++r2) {
+                f16x8 ah[MB], al[MB];
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
-                    ah[m] = *reinterpret_cast<const f16x4*>(arow + m * 16 * CSD + r2 * TWG + 16 * hs);
-                    al[m] = *reinterpret_cast<const f16x4*>(arow + DPART + m * 16 * CSD + r2 * TWG + 16 * hs);
+                    const _Float16* ap = arow + m * 16 * CSD + r2 * TWG;
+                    ah[m] = join8(*reinterpret_cast<const u32x2*>(ap), *reinterpret_cast<const u32x2*>(ap + 4));
+                    al[m] = join8(*reinterpret_cast<const u32x2*>(ap + DPART), *reinterpret_cast<const u32x2*>(ap + DPART + 4));
                 }
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    const _Float16* bp = brow + ((ring + r2 + dy) & 3) * RSX + 16 * hs;
-                    // three aligned groups per part: S[b .. b+3], S[b+4 .. b+7], S[b+8 .. b+11]
-                    u32x2 g[2][3];
+                    const _Float16* bp = brow + ((ring + r2 + dy) & 3) * RSX;
+                    u32x2 g[2][4];
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) g[p][k] = *reinterpret_cast<const u32x2*>(bp + p * XPART + 4 * k);
-                    f16x4 bf[2][3];   // [part][dx]: window S[b + 3 + dx .. b + 6 + dx]
+                        for (int k = 0; k < 4; ++k) g[p][k] = *reinterpret_cast<const u32x2*>(bp + p * XPART + 4 * k);
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const unsigned mid = __builtin_amdgcn_alignbit(g[p][1][1], g[p][1][0], 16);   // {G1.e1, G1.e2}
-                        bf[p][0] = as_f16x4(__builtin_amdgcn_alignbit(g[p][1][0], g[p][0][1], 16), mid);   // {G0.e3, G1.e0..e2}
-                        bf[p][1] = as_f16x4(g[p][1][0], g[p][1][1]);                                        // G1
-                        bf[p][2] = as_f16x4(mid, __builtin_amdgcn_alignbit(g[p][2][0], g[p][1][1], 16));    // {G1.e1..e3, G2.e0}
-                    }
-                    // small partial products first; consecutive MFMAs hit different accumulators
+                    for (int dx = 0; dx < 3; ++dx) {
+                        f16x8 bw[2];   // [part]: window S[b + 3 + dx .. b + 10 + dx]
 #pragma unroll
-                    for (int prod = 0; prod < 3; ++prod)
+                        for (int p = 0; p < 2; ++p) {
+                            const unsigned mid1 = __builtin_amdgcn_alignbit(g[p][1][1], g[p][1][0], 16);   // {G1.e1, G1.e2}
+                            const unsigned mid2 = __builtin_amdgcn_alignbit(g[p][2][1], g[p][2][0], 16);   // {G2.e1, G2.e2}
+                            const unsigned c12 = __builtin_amdgcn_alignbit(g[p][2][0], g[p][1][1], 16);    // {G1.e3, G2.e0}
+                            if (dx == 0)
+                                bw[p] = join8(u32x2{__builtin_amdgcn_alignbit(g[p][1][0], g[p][0][1], 16), mid1}, u32x2{c12, mid2});
+                            else if (dx == 1)
+                                bw[p] = join8(g[p][1], g[p][2]);
+                            else
+                                bw[p] = join8(u32x2{mid1, c12}, u32x2{mid2, __builtin_amdgcn_alignbit(g[p][3][0], g[p][2][1], 16)});
+                        }
+                        // small partial products first; consecutive MFMAs hit different accumulators
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx)
+                        for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
                             for (int m = 0; m < MB; ++m) {
-                                const f16x4 av = prod == 1 ? al[m] : ah[m];
-                                const f16x4 bv = prod == 0 ? bf[1][dx] : bf[0][dx];
-                                acc[m][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc[m][dy * 3 + dx], 0, 0, 0);
+                                const f16x8 av = prod == 1 ? al[m] : ah[m];
+                                const f16x8 bv = prod == 0 ? bw[1] : bw[0];
+                                acc[m][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][dy * 3 + dx], 0, 0, 0);
                             }
+                    }
                 }
             }
             __syncthreads();
             if (more) {
-                if (PREFETCH) {   // into the slots of rows y0 - 1 and y0
-                    if (PF < 5) load_rows(y0 + 3, IC<PF>{}, IC<5>{});
-                    store_rows(y0 + 3, IC<0>{}, IC<5>{});
-                } else {
-                    stage_rows(y0 + 3);
-                }
-                if (!PREFETCH_DZ) load_dz(y0 + 2);
+                if (!PREFETCH) load_dz(y0 + 2);
+                if (PREFETCH) store_rows(y0 + 3, IC<0>{}, IC<5>{});   // into the slots of rows y0 - 1 and y0
+                else stage_rows(y0 + 3);
                 store_dz(y0 + 2);
                 __syncthreads();
             }

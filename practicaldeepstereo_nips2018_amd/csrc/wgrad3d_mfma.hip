@@ -28,8 +28,7 @@ constexpr int RSX = 36;                         // xhat row stride
 constexpr int PSX = ROWS * RSX;                 // plane (ring slot) stride
 constexpr int XS = 3 * PSX + 26;                // xhat channel stride: 674 == 2 (mod 32)
 constexpr int DS = TY * TWG + 2;                // dz channel stride: 130 == 2 (mod 32)
-constexpr int XSLOTS = 16 * ROWS * COLS;        // staged xhat elements per plane
-constexpr int NSTG = (XSLOTS + THREADS - 1) / THREADS;   // 13 per thread
+constexpr int xslots(bool pair) { return (pair ? 8 : 16) * ROWS * COLS; }   // staged xhat elements per plane
 constexpr int NDZ = 16 * TY * TWG / THREADS;    // 8 per thread
 constexpr int TPW = 7;                          // taps per wave (4 x 7 >= 27)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -46,8 +45,13 @@ struct W3Args {
 
 }  // namespace
 
-template <bool HAS_B>
+// PAIR (layers with at most 8 input channels: the two full-resolution 8 -> 8 layers, the biggest of the hourglass): the 16
+// columns of an MFMA are 8 channels x TWO consecutive taps instead of 16 channels of which 8 are padding -- 14 tap pairs
+// instead of 27 taps per K-step.
+template <bool HAS_B, bool PAIR>
 __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A) {
+    constexpr int NACC = PAIR ? 4 : TPW;   // 14 pairs or 27 taps over 4 waves
+    constexpr int XSLOTS = xslots(PAIR), NSTG = (XSLOTS + THREADS - 1) / THREADS;   // 13 (7) staged elements per thread
     __shared__ __attribute__((aligned(16))) float xl[16 * XS];
     __shared__ __attribute__((aligned(16))) float dzl[16 * DS];
     __shared__ f32x4 coef[16];   // per input channel: scale and shift of the two sources (deferred InstanceNorm)
@@ -61,12 +65,13 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A
     const size_t bstride = HAS_B && A.b.bcast_d ? (size_t)plane : vol;  // channel stride of the second source
     const int bz = HAS_B && A.b.bcast_d ? 0 : plane;                    // its plane stride
 
-    f32x4 acc[TPW];
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const float* arow = dzl + (lane & 15) * DS + (lane >> 4);
-    const float* brow = xl + (lane & 15) * XS + (lane >> 4);
+    const float* brow = xl + (lane & (PAIR ? 7 : 15)) * XS + (lane >> 4);
+    const bool second = PAIR && (lane & 8);   // this lane's column belongs to the second tap of the pair
 
     for (int unit = blockIdx.x; unit < A.units; unit += gridDim.x) {
         int r = unit;
@@ -179,20 +184,28 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A
                 load_dz(z + 1);
             }
             // plane z - 1 + dzt sits in ring slot (z + dzt + 2) % 3
-            int boff[TPW];
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int tap = min(wave + 4 * i, 26);   // taps w, w + 4, ...: wave-uniform
+            auto tap_offset = [&](int tap) {
                 const int dzt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                boff[i] = ((z + dzt + 2) % 3) * PSX + dy * RSX + dx;
+                return ((z + dzt + 2) % 3) * PSX + dy * RSX + dx;
+            };
+            int boff[NACC];
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                if (PAIR) {   // pairs w, w + 4, ...: taps 2 p and 2 p + 1 (the 14th pair's second tap does not exist)
+                    const int p = min(wave + 4 * i, 13);
+                    const int o0 = tap_offset(2 * p), o1 = tap_offset(min(2 * p + 1, 26));
+                    boff[i] = second ? o1 : o0;
+                } else {
+                    boff[i] = tap_offset(min(wave + 4 * i, 26));   // taps w, w + 4, ...: wave-uniform
+                }
             }
             for (int rr = 0; rr < rows; ++rr) {
 #pragma unroll 2
                 for (int ks = 0; ks < TWG / 4; ++ks) {
                     const float af = arow[rr * TWG + ks * 4];
 #pragma unroll
-                    for (int i = 0; i < TPW; ++i) {
-                        if (i < TPW - 1 || wave < 3) {   // tap 27 does not exist
+                    for (int i = 0; i < NACC; ++i) {
+                        if (PAIR ? (i < 3 || wave < 2) : (i < TPW - 1 || wave < 3)) {   // pair 14 / tap 27 does not exist
                             const float bf = brow[boff[i] + rr * RSX + ks * 4];
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
                         }
@@ -205,10 +218,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A
 
     // ---- one partial per workgroup: [Cout][Cin][27] ----------------------------------------------------------
     float* dst = A.partial + (size_t)blockIdx.x * A.Cout * A.Cin * 27;
-    const int c = c0 + (lane & 15);
+    const int c = c0 + (lane & (PAIR ? 7 : 15));
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int tap = wave + 4 * i;
+    for (int i = 0; i < NACC; ++i) {
+        const int tap = PAIR ? 2 * (wave + 4 * i) + (second ? 1 : 0) : wave + 4 * i;
         if (tap >= 27) continue;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -295,8 +308,13 @@ int launch_wgrad3d_mfma(const Src& a, const Src& b, const float* dz, float* dw, 
     A.zc = P.zc;
     A.zchunks = P.zchunks;
     A.units = P.units;
-    if (b.p) hipLaunchKernelGGL((wgrad3d_mfma_kernel<true>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
-    else hipLaunchKernelGGL((wgrad3d_mfma_kernel<false>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
+    if (in.c <= 8) {
+        if (b.p) hipLaunchKernelGGL((wgrad3d_mfma_kernel<true, true>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
+        else hipLaunchKernelGGL((wgrad3d_mfma_kernel<false, true>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
+    } else {
+        if (b.p) hipLaunchKernelGGL((wgrad3d_mfma_kernel<true, false>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
+        else hipLaunchKernelGGL((wgrad3d_mfma_kernel<false, false>), dim3(P.wgs, pairs), dim3(THREADS), 0, s, A);
+    }
     if (int rc = check_launch("wgrad3d_mfma")) return rc;
     return launch_wgrad_reduce_f32(scratch, (size_t)out.c * in.c * 27, P.wgs, dw, accumulate, s);
 }

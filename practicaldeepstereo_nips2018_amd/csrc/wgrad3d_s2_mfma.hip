@@ -74,10 +74,15 @@ __device__ __forceinline__ float xhat_value(const Src& a, const Src& b, int n, i
 
 }  // namespace
 
-// SMALL_NORM: the small-grid tensor is the normalised one (transposed convolution); otherwise the big-grid one is
-template <int K, bool SMALL_NORM>
+// SMALL_NORM: the small-grid tensor is the normalised one (transposed convolution); otherwise the big-grid one is.
+// NT: taps per column group.  A big-grid tensor of 8 (4) channels would fill 8 (4) of the 16 MFMA columns; instead the
+// columns hold 8 channels x 2 taps (4 channels x 4 taps): half (a quarter) of the MFMAs for the full-resolution layers.
+template <int K, bool SMALL_NORM, int NT>
 __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args A) {
     using C = Cfg<K>;
+    constexpr int CBP = 16 / NT;                         // channels per column group (== Cb when NT > 1)
+    constexpr int GROUPS = (C::TAPS + NT - 1) / NT;      // column groups: taps g NT .. g NT + NT - 1
+    constexpr int GPW = (GROUPS + 3) / 4;                // groups per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // big tile: [rows][XS] with rows = min(16, Cb) (+ one all-zero row that the lanes beyond Cb read): few-channel layers
     // (8 -> 4 at full half-resolution) need 20 KB instead of 70, so more workgroups fit on a CU
@@ -92,19 +97,21 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
     const size_t plane_s = (size_t)A.Hs * A.Ws, vol_s = (size_t)A.Ds * plane_s;
     const size_t plane_b = (size_t)A.Hb * A.Wb, vol_b = (size_t)A.Db * plane_b;
 
-    // tap -> LDS offset of its B fragment row (wave-uniform): row (kz, ky), parity half and shift of kx
-    int toff[C::TPW];
+    // tap -> LDS offset of its B fragment row: row (kz, ky), parity half and shift of kx (wave-uniform for NT == 1; with
+    // NT > 1 the lane's column selects one of the group's taps)
+    const int tj = (lane & 15) / CBP;
+    int toff[GPW];
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i) {
-        const int tap = min(wave + 4 * i, C::TAPS - 1);
+    for (int i = 0; i < GPW; ++i) {
+        const int tap = min((wave + 4 * i) * NT + tj, C::TAPS - 1);
         const int rr = tap / K, kx = tap % K;
         toff[i] = rr * RS + ((kx & 1) ? HS : 0) + ((kx + 1) >> 1) - ((kx & 1) ? 1 : 0);
     }
     // kx = 0: odd[j], 1: even[j], 2: odd[j + 1], 3: even[j + 1]   (odd[j] = B[2(x0+j) - 1], even[j] = B[2(x0+j)])
 
-    f32x4 acc[C::TPW];
+    f32x4 acc[GPW];
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < GPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // channel rows beyond the tensors' channel counts are zeroed once and never staged (few-channel layers: 8 -> 4)
     const int nb = min(16, A.Cb - b0), ns = min(16, A.Cs - s0);
@@ -231,13 +238,13 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
         __syncthreads();
 
         const float* arow = sl + (lane & 15) * DS + (lane >> 4);
-        const float* brow = bl + min(lane & 15, brows - 1) * C::XS + (lane >> 4);
+        const float* brow = bl + min((lane & 15) & (CBP - 1), brows - 1) * C::XS + (lane >> 4);
 #pragma unroll 2
         for (int ks = 0; ks < TWG / 4; ++ks) {
             const float af = arow[ks * 4];
 #pragma unroll
-            for (int i = 0; i < C::TPW; ++i) {
-                if (wave + 4 * i < C::TAPS) {   // wave-uniform
+            for (int i = 0; i < GPW; ++i) {
+                if (wave + 4 * i < GROUPS) {   // wave-uniform
                     const float bf = brow[toff[i] + ks * 4];
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
                 }
@@ -248,11 +255,11 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
 
     // ---- one partial per workgroup: [Cs][Cb][K^3] ------------------------------------------------------------
     float* dst = A.partial + (size_t)blockIdx.x * A.Cs * A.Cb * C::TAPS;
-    const int bc = b0 + (lane & 15);
+    const int bc = b0 + ((lane & 15) & (CBP - 1));
 #pragma unroll
-    for (int i = 0; i < C::TPW; ++i) {
-        const int tap = wave + 4 * i;
-        if (tap >= C::TAPS) continue;
+    for (int i = 0; i < GPW; ++i) {
+        const int tap = (wave + 4 * i) * NT + tj;
+        if (wave + 4 * i >= GROUPS || tap >= C::TAPS) continue;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int scn = s0 + 4 * (lane >> 4) + rr;
@@ -388,9 +395,16 @@ static void s2_roles(int transposed, const Geom& in, const Geom& out, Geom& smal
 
 static int wgrad3d_s2_workgroups(const Geom& small, int pairs) {
     const size_t items = (size_t)small.n * small.d * small.h * ((small.w + TWG - 1) / TWG);
-    size_t wgs = items / 4;                       // >= ~4 items per workgroup so the partial write amortises
+    size_t wgs = items / 4;                       // >= ~4 items per workgroup so the partial write amortises ...
     const size_t cap = (size_t)(2048 / pairs) > 0 ? (size_t)(2048 / pairs) : 1;
     if (wgs > cap) wgs = cap;
+    // ... unless that leaves a quarter of the CUs idle: the deepest level of the hourglass (27 items, 32 channel pairs)
+    // is a chain of 4-5 items on 6 workgroups per pair -- one item per workgroup there (measured: 166 -> 92 us and
+    // 139 -> 124 us; the same rule applied to the levels above it costs more in partial sums than it gains)
+    if (wgs * pairs < 200) {
+        const size_t fill = (size_t)(1024 / pairs) > 0 ? (size_t)(1024 / pairs) : 1;
+        wgs = items < fill ? items : fill;
+    }
     return wgs < 1 ? 1 : (int)wgs;
 }
 
@@ -428,18 +442,24 @@ int launch_wgrad3d_s2_mfma(int transposed, const Src& a, const Src& b, const flo
     const int taps = transposed ? 64 : 27;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<4, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<4, true, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<3, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3d_s2_mfma_kernel<3, false, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
     const int nbm = big.c < 16 ? big.c + 1 : 16;
+    const int nt = big.c == 8 ? 2 : big.c == 4 ? 4 : 1;   // taps per column group (kernel comment)
+    const dim3 grid(wgs, pairs);
     if (transposed) {
         const size_t lds = (size_t)(nbm * Cfg<4>::XS + 16 * DS) * sizeof(float);
-        hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<4, true>), dim3(wgs, pairs), dim3(THREADS), lds, s, A);
+        if (nt == 4) hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<4, true, 4>), grid, dim3(THREADS), lds, s, A);
+        else if (nt == 2) hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<4, true, 2>), grid, dim3(THREADS), lds, s, A);
+        else hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<4, true, 1>), grid, dim3(THREADS), lds, s, A);
     } else {
         const size_t lds = (size_t)(nbm * Cfg<3>::XS + 16 * DS) * sizeof(float);
-        hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<3, false>), dim3(wgs, pairs), dim3(THREADS), lds, s, A);
+        if (nt == 4) hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<3, false, 4>), grid, dim3(THREADS), lds, s, A);
+        else if (nt == 2) hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<3, false, 2>), grid, dim3(THREADS), lds, s, A);
+        else hipLaunchKernelGGL((wgrad3d_s2_mfma_kernel<3, false, 1>), grid, dim3(THREADS), lds, s, A);
     }
     if (int rc = check_launch("wgrad3d_s2_mfma")) return rc;
     return launch_wgrad_reduce_f32(scratch, (size_t)small.c * big.c * taps, wgs, dw, accumulate, s);
