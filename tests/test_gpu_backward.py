@@ -290,6 +290,50 @@ def test_standalone_blocks_backward(dev):
     check_param_grads(exp, '_e', gp)
 
 
+def test_standalone_blocks_backward_eight_features_odd_sizes(dev):
+    """The round-4 backward kernels behind 8-channel layers (tap pairs / tap groups in the MFMA columns of the 3-D weight
+    gradients, column-pair data gradients with 8-channel blocks) on odd depths, heights and widths: the last plane, row
+    and column pair are partial, and an odd plane / row has two contributing taps per axis in the strided convolution."""
+    g = torch.Generator().manual_seed(21)
+    con = helpers.seeded(lambda: pds.ContractionBlock3d(8), seed=22).to(dev)
+    x = torch.randn(1, 8, 7, 9, 15, generator=g).to(dev).requires_grad_(True)
+    wd, wsm = torch.randn(1, 16, 4, 5, 8, generator=g), torch.randn(1, 16, 4, 5, 8, generator=g)
+    down, smooth = con(x)
+    ((down * wd.to(dev)).sum() + (smooth * wsm.to(dev)).sum()).backward()
+    params = helpers.prefixed(con.state_dict(), '_c')
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    d64, s64 = oracle.contraction_block_3d(p64, '_c', x64)
+    ((d64 * wd.double()).sum() + (s64 * wsm.double()).sum()).backward()
+    assert relative_error(x.grad, x64.grad) <= REL_TOL
+    check_param_grads(con, '_c', {k: v.grad for k, v in p64.items()})
+
+    exp = helpers.seeded(lambda: pds.ExpansionBlock3d(8), seed=23).to(dev)
+    xi = torch.randn(1, 8, 3, 5, 7, generator=g).to(dev).requires_grad_(True)
+    sc = torch.randn(1, 4, 6, 10, 14, generator=g).to(dev).requires_grad_(True)
+    wo = torch.randn(1, 4, 6, 10, 14, generator=g)
+    out = exp(xi, sc)
+    (out * wo.to(dev)).sum().backward()
+    params = helpers.prefixed(exp.state_dict(), '_e')
+    ref, (gxi, gsc), gp = oracle_grads(lambda p, a, b: oracle.expansion_block_3d(p, '_e', a, b), [xi, sc], params, wo)
+    assert relative_error(out, ref) <= 1e-4
+    assert relative_error(xi.grad, gxi) <= REL_TOL and relative_error(sc.grad, gsc) <= REL_TOL
+    check_param_grads(exp, '_e', gp)
+
+    # a 16 -> 8 expansion: the transposed layer's dz has 8 channels (two taps per column group in its weight gradient)
+    exp = helpers.seeded(lambda: pds.ExpansionBlock3d(16), seed=24).to(dev)
+    xi = torch.randn(2, 16, 3, 4, 9, generator=g).to(dev).requires_grad_(True)
+    sc = torch.randn(2, 8, 6, 8, 18, generator=g).to(dev).requires_grad_(True)
+    wo = torch.randn(2, 8, 6, 8, 18, generator=g)
+    out = exp(xi, sc)
+    (out * wo.to(dev)).sum().backward()
+    params = helpers.prefixed(exp.state_dict(), '_e')
+    ref, (gxi, gsc), gp = oracle_grads(lambda p, a, b: oracle.expansion_block_3d(p, '_e', a, b), [xi, sc], params, wo)
+    assert relative_error(out, ref) <= 1e-4
+    assert relative_error(xi.grad, gxi) <= REL_TOL and relative_error(sc.grad, gsc) <= REL_TOL
+    check_param_grads(exp, '_e', gp)
+
+
 def test_config5_full_size_training_step(dev):
     """BASELINE configs[4] on one GPU: the reference's training step (pds_trainer.py:35-46: train-mode network ->
     SubpixelCrossEntropy -> backward; RMSprop lr 1e-2, train_on_flyingthings3d.py:68) at the full 960x540, D=192 size.
