@@ -973,6 +973,12 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
                           std::vector<char>& written) {
     static const bool debug_arena = getenv("PDS_DEBUG_ARENA") != nullptr;
     const std::vector<char> preset(written);  // gradients that live in the caller's tensors: never taken over
+    std::vector<int> producer(T.tensors.size(), -1), consumers(T.tensors.size(), 0);
+    for (size_t j = 0; j < T.layers.size(); ++j) {
+        producer[T.layers[j].out] = (int)j;
+        if (T.layers[j].a >= 0) ++consumers[T.layers[j].a];
+        if (T.layers[j].b >= 0) ++consumers[T.layers[j].b];
+    }
     for (int li = (int)T.layers.size() - 1; li >= 0; --li) {
         const TapeLayer& L = T.layers[li];
         const TapeTensor& out = T.tensors[L.out];
@@ -1006,15 +1012,35 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
             }
             written[id] = 1;
         };
-        if (L.type == 2) {  // plain sum: the gradient flows unchanged to both terms
-            // Every consumer of the sum has delivered its share by now, so its gradient buffer is dead after this
-            // layer: ONE term may simply take it over instead of receiving a copy (a 425 MB copy per residual sum of
-            // Matching) -- but only a buffer of this arena, never the caller's gradient tensor.
-            const bool mine = !preset[L.out];
-            const bool a_takes = mine && L.a >= 0 && T.tensors[L.a].needs_grad && !T.tensors[L.a].bcast_d && !dhat[L.a] &&
-                                 !written[L.a];
-            route(L.a, g, L.out_g, a_takes);
-            route(L.b, g, L.out_g, mine && !a_takes);
+        // One gradient for BOTH inputs of a layer (the terms of a sum, the two sources of a convolution).  `grad_in` is an
+        // arena buffer nobody else reads after this layer (`mine`), so ONE input may take it over instead of receiving a
+        // copy.  Both may even share it when one of them (`ro`) only ever reads it -- this layer is its single consumer,
+        // so nothing is accumulated into it -- and is done reading before anything is accumulated into the other (`acc`):
+        // ro's gradient is read when ro's producer is processed, so no layer between that producer and this one may
+        // consume acc.  The residual blocks have exactly this shape (ro = the block's last convolution, acc = its input):
+        // a 425 MB copy per residual sum / two-source layer of Matching.
+        auto route_pair = [&](int a, int b, const float* grad_in, const Geom& in_g, bool mine) {
+            auto fresh = [&](int id) {
+                return mine && id >= 0 && T.tensors[id].needs_grad && !T.tensors[id].bcast_d && !dhat[id] && !written[id];
+            };
+            auto may_share = [&](int ro, int acc) {
+                if (consumers[ro] != 1 || producer[ro] < 0) return false;
+                for (int j = producer[ro] + 1; j < li; ++j)
+                    if (T.layers[j].a == acc || T.layers[j].b == acc) return false;
+                return true;
+            };
+            const bool fa = fresh(a), fb = fresh(b);
+            if (fa && fb && a != b && (may_share(a, b) || may_share(b, a))) {
+                route(a, grad_in, in_g, true);
+                dhat[b] = dhat[a];
+                written[b] = 1;
+                return;
+            }
+            route(a, grad_in, in_g, fa);
+            route(b, grad_in, in_g, fb && !fa);
+        };
+        if (L.type == 2) {  // plain sum: the gradient flows unchanged to both terms (every consumer of the sum has
+            route_pair(L.a, L.b, g, L.out_g, !preset[L.out]);   // delivered its share: the buffer is dead after this layer)
             continue;
         }
         if (L.type == 3) {  // space-to-depth: the adjoint is the inverse permutation
@@ -1141,10 +1167,7 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         } else if (!c.plan) {
             c.run(launch_bwd_data(L.type, L.kd, L.stride, dz, weight, dx, L.in_g, L.out_g, c.s));
         }
-        // dx goes to both sources of a two-source layer: only one of them may adopt the buffer
-        const bool a_takes = L.a >= 0 && T.tensors[L.a].needs_grad && !T.tensors[L.a].bcast_d;
-        route(L.a, dx, L.in_g, true);
-        route(L.b, dx, L.in_g, !a_takes);
+        route_pair(L.a, L.b, dx, L.in_g, true);   // dx goes to both sources of a two-source layer
     }
 }
 

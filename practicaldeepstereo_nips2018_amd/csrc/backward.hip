@@ -445,7 +445,10 @@ __device__ __forceinline__ void bwd2_reduce_store(float (&acc0)[CB], float (&acc
 
 // transposed conv (kernel (KD,4,4), stride (KD == 4 ? 2 : 1, 2, 2), pad 1; weight [Cin, Cout, KD, 4, 4]):
 //   dx[c][i] = sum_oc sum_k dz[oc][s*i - 1 + k] * W[c][oc][k]
-template <int KD, int CB, int OCG>
+// VEC (one row per wave, dz rows 16-byte aligned): the four inner columns of a lane's six are ONE aligned 16-byte load
+// (the lanes' quads are contiguous: 1 KB per instruction) instead of four 4-byte loads at a 16-byte stride, which cost the
+// texture path as much each.
+template <int KD, int CB, int OCG, bool VEC>
 __global__ __launch_bounds__(256) void deconv_bwd_data2_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                                float* __restrict__ dx, const BwdGeom G,
                                                                const Bwd2Launch Q) {
@@ -480,6 +483,7 @@ __global__ __launch_bounds__(256) void deconv_bwd_data2_kernel(const float* __re
         cv[t] = ox >= 0 && ox < G.Wo;
         col[t] = min(max(ox, 0), G.Wo - 1);
     }
+    if (VEC) col[1] = min(col[1], G.Wo - 4);   // lanes past the end of the row: any aligned quad inside it (masked by cv)
     float acc0[CB], acc1[CB];
 #pragma unroll
     for (int c = 0; c < CB; ++c) acc0[c] = acc1[c] = 0.f;
@@ -497,8 +501,17 @@ __global__ __launch_bounds__(256) void deconv_bwd_data2_kernel(const float* __re
                     const bool yv = oy >= 0 && oy < G.Ho;
                     const float* pr = pz + (size_t)min(max(oy, 0), G.Ho - 1) * G.Wo;
                     float v[6];
+                    if (VEC) {
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        const f32x4 m = *reinterpret_cast<const f32x4*>(pr + col[1]);   // columns 4 j .. 4 j + 3
+                        v[0] = pr[col[0]];
+                        v[5] = pr[col[5]];
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) v[t] = pr[col[t]];
+                        for (int t = 0; t < 4; ++t) v[1 + t] = m[t];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) v[t] = pr[col[t]];
+                    }
 #pragma unroll
                     for (int t = 0; t < 6; ++t) v[t] = (yv && cv[t]) ? v[t] : 0.f;
 #pragma unroll
@@ -606,10 +619,17 @@ void launch_bwd2_variant(int transposed, int kd, const float* dz, const float* w
     const unsigned wgs = (unsigned)(((size_t)Q.units * OCG + 3) / 4);
     if (!transposed)
         hipLaunchKernelGGL((conv_s2_bwd_data2_kernel<CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
-    else if (kd == 4)
-        hipLaunchKernelGGL((deconv_bwd_data2_kernel<4, CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
-    else
-        hipLaunchKernelGGL((deconv_bwd_data2_kernel<3, CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+    else {
+        const bool vec = Q.ry_shift == 0 && (G.Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0;
+        if (kd == 4 && vec)
+            hipLaunchKernelGGL((deconv_bwd_data2_kernel<4, CB, OCG, true>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+        else if (kd == 4)
+            hipLaunchKernelGGL((deconv_bwd_data2_kernel<4, CB, OCG, false>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+        else if (vec)
+            hipLaunchKernelGGL((deconv_bwd_data2_kernel<3, CB, OCG, true>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+        else
+            hipLaunchKernelGGL((deconv_bwd_data2_kernel<3, CB, OCG, false>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
+    }
 }
 
 // transposed (kd 3 or 4) or strided convolution (kd 3, stride 2)
