@@ -445,7 +445,7 @@ __device__ __forceinline__ void bwd2_reduce_store(float (&acc0)[CB], float (&acc
 
 // transposed conv (kernel (KD,4,4), stride (KD == 4 ? 2 : 1, 2, 2), pad 1; weight [Cin, Cout, KD, 4, 4]):
 //   dx[c][i] = sum_oc sum_k dz[oc][s*i - 1 + k] * W[c][oc][k]
-// VEC (one row per wave, dz rows 16-byte aligned): the four inner columns of a lane's six are ONE aligned 16-byte load
+// VEC (dz rows 16-byte aligned): the four inner columns of a lane's six are ONE aligned 16-byte load
 // (the lanes' quads are contiguous: 1 KB per instruction) instead of four 4-byte loads at a 16-byte stride, which cost the
 // texture path as much each.
 template <int KD, int CB, int OCG, bool VEC>
@@ -620,7 +620,7 @@ void launch_bwd2_variant(int transposed, int kd, const float* dz, const float* w
     if (!transposed)
         hipLaunchKernelGGL((conv_s2_bwd_data2_kernel<CB, OCG>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
     else {
-        const bool vec = Q.ry_shift == 0 && (G.Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0;
+        const bool vec = (G.Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0;
         if (kd == 4 && vec)
             hipLaunchKernelGGL((deconv_bwd_data2_kernel<4, CB, OCG, true>), dim3(wgs), dim3(256), 0, s, dz, w, dx, G, Q);
         else if (kd == 4)
