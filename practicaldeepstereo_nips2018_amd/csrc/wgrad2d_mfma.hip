@@ -246,14 +246,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_f32_kernel(const float* __re
     const size_t i = (size_t)blockIdx.x * 64 + col;
     double s = 0.0;
     if (i < wcount) {
+        // sixteen independent loads in flight per lane: a 64 -> 64 layer has 512 partials and only 576 workgroups, so the
+        // kernel is a chain of load round trips (four in flight: 43 us for 75 MB)
         int k = pg;
-        for (; k + 12 < parts; k += 16) {
-            const float v0 = partial[(size_t)k * wcount + i], v1 = partial[(size_t)(k + 4) * wcount + i];
-            const float v2 = partial[(size_t)(k + 8) * wcount + i], v3 = partial[(size_t)(k + 12) * wcount + i];
-            s += (double)v0;
-            s += (double)v1;
-            s += (double)v2;
-            s += (double)v3;
+        for (; k + 60 < parts; k += 64) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = partial[(size_t)(k + 4 * j) * wcount + i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += (double)v[j];
         }
         for (; k < parts; k += 4) s += (double)partial[(size_t)k * wcount + i];
     }
@@ -281,7 +282,8 @@ bool wgrad2d_mfma_supported(int transposed, int kd, int stride, const Src& b, co
 
 static int wgrad2d_workgroups(const Geom& in) {
     const size_t items = (size_t)in.n * in.d * in.h * ((in.w + TWG - 1) / TWG);
-    size_t wgs = items / 8;  // at least ~8 items per workgroup so the partial write amortises
+    size_t wgs = items / 8;  // at least ~8 items per workgroup so the partial write amortises ...
+    if (wgs < 256) wgs = items / 2 < 256 ? items / 2 : 256;   // ... but one workgroup per CU first (single-plane layers)
     if (wgs > 512) wgs = 512;
     return wgs < 1 ? 1 : (int)wgs;
 }
