@@ -28,7 +28,9 @@
 //               on gfx950 -- tools/ubench/mfma_rate.hip: 1.10 against 2.12 PFLOP/s chip-wide -- and bounded the kernel:
 //               606 -> 428 us per 64 -> 64 layer); the three kernel columns are the windows S[b + 3 + dx .. b + 10 + dx]:
 //               four aligned 8-byte reads (b, b + 4, b + 8, b + 12) per part and v_alignbit give all of them -- no
-//               unaligned LDS access, no re-staging per tap.
+//               unaligned LDS access, no re-staging per tap.  (A v_mfma_f32_32x32x16_f16 form -- wave = 32 input channels x
+//               32 output channels, the rate of the pipe from a single wave where the 16 x 16 forms need two -- was built
+//               and measured: 428 -> 564 us; its K-step is 16 positions, so the tap windows are rebuilt twice per row.)
 #include "common.hpp"
 
 namespace pds {
