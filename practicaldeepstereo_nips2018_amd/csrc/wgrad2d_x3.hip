@@ -30,7 +30,11 @@
 //               four aligned 8-byte reads (b, b + 4, b + 8, b + 12) per part and v_alignbit give all of them -- no
 //               unaligned LDS access, no re-staging per tap.  (A v_mfma_f32_32x32x16_f16 form -- wave = 32 input channels x
 //               32 output channels, the rate of the pipe from a single wave where the 16 x 16 forms need two -- was built
-//               and measured: 428 -> 564 us; its K-step is 16 positions, so the tap windows are rebuilt twice per row.)
+//               and measured: 428 -> 564 us; its K-step is 16 positions, so the tap windows are rebuilt twice per row.
+//               So was ONE workgroup of eight waves per CU -- both waves of a SIMD in the matrix phase at the same time, a
+//               six-row ring and double-buffered dz behind one barrier per step, the next step's operands in registers:
+//               470-555 us; its waves stage together and multiply together, so neither the memory path nor the matrix
+//               pipe ever works while the other does, which the two independent workgroups of this form provide.)
 #include "common.hpp"
 
 namespace pds {
