@@ -168,6 +168,127 @@ __global__ __launch_bounds__(256) void bias_partial_reduce_kernel(const double* 
     if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One pass for per-plane groups (MatchingOperation: one InstanceNorm group per (channel, disparity plane), 34 560 elements
+// at full size).  The two kernels above read g and t twice (statistics, then dz): 2.1 GB per layer of MatchingOperation.
+// A plane fits the REGISTERS of one 1024-thread workgroup (nine 16-byte quads of g and of t per thread, all eighteen
+// loads in flight): statistics and dz from one read -- 1.27 GB.  Sums in fp64 as above; the group's (Q, S1) go to the same
+// `qs` records, the plane's sum of dz to the bias partials, max |dz| to the same slots.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPlaneThreads = 1024, kPlaneQuads = 9;
+
+__global__ __launch_bounds__(kPlaneThreads) void in_bwd_plane_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                                   const Geom geom, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, float* __restrict__ dz,
+                                                                   double* __restrict__ qs, double* __restrict__ bias_partial,
+                                                                   float* __restrict__ dz_amax) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int grp = blockIdx.x;                 // (n * C + c) * D + d
+    const int c = (grp / geom.d) % geom.c;
+    const int quads = (int)(geom.plane() >> 2);
+    const size_t base = (size_t)grp * geom.plane();
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + base);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + base);
+    f32x4 gv[kPlaneQuads], tv[kPlaneQuads];
+#pragma unroll
+    for (int k = 0; k < kPlaneQuads; ++k) {
+        const int q = threadIdx.x + k * kPlaneThreads;
+        const bool ok = q < quads;
+        gv[k] = g4[ok ? q : 0];
+        tv[k] = t4[ok ? q : 0];
+        if (!ok) gv[k] = f32x4{0.f, 0.f, 0.f, 0.f};   // contributes nothing to the sums; never stored
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPlaneQuads; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += gv[k][e];
+            s2 += (double)gv[k][e] * tv[k][e];
+        }
+    __shared__ double red[kPlaneThreads / 64][2];
+    __shared__ double tot[3];
+    __shared__ float redmax[kPlaneThreads / 64];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int w = 0; w < kPlaneThreads / 64; ++w) {
+            a1 += red[w][0];
+            a2 += red[w][1];
+        }
+        const double q = (double)rstd[grp] * (a2 - (double)mean[grp] * a1);
+        tot[0] = a1;
+        tot[1] = q;
+        qs[2 * grp] = q;
+        qs[2 * grp + 1] = a1;
+    }
+    __syncthreads();
+    const double count = (double)geom.plane();
+    const float mu = mean[grp], r = rstd[grp], a = gamma[c] * r;
+    const float b1 = (float)(tot[0] / count), b2 = (float)(tot[1] / count);
+    float sum = 0.f, seen = 0.f;
+    f32x4* o4 = reinterpret_cast<f32x4*>(dz + base);
+#pragma unroll
+    for (int k = 0; k < kPlaneQuads; ++k) {
+        const int q = threadIdx.x + k * kPlaneThreads;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float n = (tv[k][e] - mu) * r;
+            const float dt = a * (gv[k][e] - b1 - n * b2);
+            v[e] = tv[k][e] > 0.f ? dt : dt * kLeakySlope;
+        }
+        if (q < quads) {
+            o4[q] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sum += v[e];
+                seen = fmaxf(seen, fabsf(v[e]));
+            }
+        }
+    }
+    const double ws = wave_sum((double)sum);
+    if (dz_amax) seen = wave_max(seen == seen ? seen : __builtin_inff());
+    __syncthreads();   // red is reused
+    if (lane == 0) {
+        red[wave][0] = ws;
+        redmax[wave] = seen;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = 0.0;
+        float m = 0.f;
+        for (int w = 0; w < kPlaneThreads / 64; ++w) {
+            b += red[w][0];
+            m = fmaxf(m, redmax[w]);
+        }
+        bias_partial[grp] = b;
+        if (dz_amax) {   // as in_bwd_apply_kernel: one guarded atomic per workgroup
+            float* slot = dz_amax + ((blockIdx.x * 7u) & (kDzAmaxSlots - 1));
+            if (m > *reinterpret_cast<volatile float*>(slot))
+                atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+        }
+    }
+}
+
+static bool in_bwd_plane_supported(const float* g, const float* t, const float* dz, const Geom& geom, int per_plane) {
+    static const bool enabled = []() {  // PDS_IN_BWD_PLANE=0 keeps the two-pass kernels (A/B, debugging)
+        const char* e = getenv("PDS_IN_BWD_PLANE");
+        return !(e && e[0] == '0');
+    }();
+    const size_t px = geom.plane();
+    return enabled && per_plane && (px & 3) == 0 && px <= (size_t)kPlaneThreads * kPlaneQuads * 4 &&
+           ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
+}
+
 static unsigned plane_tiles(const Geom& g) {
     unsigned t = (unsigned)((g.plane() + 1023) / 1024);
     return t < 1 ? 1 : (t > 64 ? 64 : t);
@@ -186,6 +307,19 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
     double* partials = scratch;
     double* qs = scratch + (size_t)geom.n * geom.c * geom.d * tiles * 2;
     double* bias_partial = qs + (size_t)geom.n * geom.c * geom.d * 2;
+    if (in_bwd_plane_supported(g, t, dz, geom, per_plane)) {
+        // the maxima are collected by the kernel that also produces the records in_bwd_params_kernel sums, so the slots
+        // are cleared ahead of it instead of by that kernel
+        if (dz_amax && hipMemsetAsync(dz_amax, 0, kDzAmaxSlots * sizeof(float), s) != hipSuccess)
+            return set_error(-1, "in_bwd: clearing the range slots failed");
+        hipLaunchKernelGGL(in_bwd_plane_kernel, dim3(geom.n * geom.c * geom.d), dim3(kPlaneThreads), 0, s, g, t, geom, mean,
+                           rstd, gamma, dz, qs, bias_partial, dz_amax);
+        hipLaunchKernelGGL(in_bwd_params_kernel, dim3(geom.c), dim3(64), 0, s, qs, geom.n, geom.c, geom.d, dgamma, dbeta,
+                           accumulate_params, static_cast<float*>(nullptr));
+        hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(geom.c), dim3(256), 0, s, bias_partial, geom.n, geom.c,
+                           geom.d, dbias, accumulate_params);
+        return check_launch("in_bwd_plane");
+    }
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(tiles, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
                        partials);
     const int inner = per_plane ? geom.d : 1;

@@ -47,6 +47,7 @@ def test_alternative_paths(hip_library, switch):
 BACKWARD_SWITCHES = [
     {'PDS_WGRAD2D_X3': '0'},          # 2-D weight gradients on the exact-fp32 MFMA kernel
     {'PDS_BWD_DATA_V2': '0'},         # stride-2 data gradients on the one-position-per-thread kernels of round 2
+    {'PDS_IN_BWD_PLANE': '0'},        # InstanceNorm backward of per-plane groups on the two-pass kernels
     {'PDS_WGRAD3D_MFMA': '0', 'PDS_WGRAD3D_S2_MFMA': '0'},   # 3-D weight gradients on the VALU kernels
 ]
 
