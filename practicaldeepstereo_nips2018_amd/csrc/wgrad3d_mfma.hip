@@ -52,7 +52,11 @@ template <bool HAS_B, bool PAIR>
 __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A) {
     constexpr int NACC = PAIR ? 4 : TPW;   // 14 pairs or 27 taps over 4 waves
     constexpr int XSLOTS = xslots(PAIR), NSTG = (XSLOTS + THREADS - 1) / THREADS;   // 13 (7) staged elements per thread
-    __shared__ __attribute__((aligned(16))) float xl[16 * XS];
+    // channel stride: 2 (mod 32) for 16 channels x 2 positions per half-wave; the tap-pair form reads (8 channels, 2 taps,
+    // 2 positions) at c XSK + {0, 1 (mostly)} + {0, 1}: 4 (mod 32) keeps the channels apart (with 2, a quarter of the lanes
+    // of every read collided with the next channel)
+    constexpr int XSK = PAIR ? XS + 2 : XS;
+    __shared__ __attribute__((aligned(16))) float xl[(PAIR ? 8 : 16) * XSK];
     __shared__ __attribute__((aligned(16))) float dzl[16 * DS];
     __shared__ f32x4 coef[16];   // per input channel: scale and shift of the two sources (deferred InstanceNorm)
 
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const float* arow = dzl + (lane & 15) * DS + (lane >> 4);
-    const float* brow = xl + (lane & (PAIR ? 7 : 15)) * XS + (lane >> 4);
+    const float* brow = xl + (lane & (PAIR ? 7 : 15)) * XSK + (lane >> 4);
     const bool second = PAIR && (lane & 8);   // this lane's column belongs to the second tap of the pair
 
     for (int unit = blockIdx.x; unit < A.units; unit += gridDim.x) {
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad3d_mfma_kernel(const W3Args A
             const int y = y0 - 1 + row, x = x0 - 1 + col, ch = c0 + c;
             const bool slot = e < XSLOTS;
             const bool ok = slot && ch < A.Cin && y >= 0 && y < A.H && x >= 0 && x < A.W;
-            xdst[j] = slot ? c * XS + row * RSX + col : -1;
+            xdst[j] = slot ? c * XSK + row * RSX + col : -1;
             xoff[j] = ok ? c * (int)vol + y * A.W + x : -1;   // 16 channel volumes stay below 2^31 elements (launcher)
         }
         const float* abase = A.a.p + (size_t)(n * A.Cin + c0) * vol;

@@ -269,6 +269,10 @@ __global__ __launch_bounds__(THREADS) void wgrad3d_s2_mfma_kernel(const WS2Args 
 }
 
 int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, float* dw, int accumulate, hipStream_t s);
+bool wgrad3d_s2_rolling_supported(int transposed, const Src& b, const Geom& small, const Geom& big, const float* dz,
+                                  const Src& a);   // wgrad3d_s2r.hip
+int launch_wgrad3d_s2_rolling(int transposed, const Src& a, const Src& b, const float* dz, float* dw, const Geom& small,
+                              const Geom& big, int accumulate, float* scratch, int max_wgs, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of the full-resolution transposed convolution k(3,4,4) s(1,2,2) p1, Cin <= 5 -> Cout = 1 (reference
@@ -463,6 +467,12 @@ int launch_wgrad3d_s2_mfma(int transposed, const Src& a, const Src& b, const flo
                            const Geom& out, int accumulate, float* scratch, hipStream_t s) {
     Geom small, big;
     s2_roles(transposed, in, out, small, big);
+    {   // the full-resolution layers (4 or 8 big-grid channels): rolling form, wgrad3d_s2r.hip
+        const int pairs0 = ((small.c + 15) / 16) * ((big.c + 15) / 16);
+        if (wgrad3d_s2_rolling_supported(transposed, b, small, big, dz, a))
+            return launch_wgrad3d_s2_rolling(transposed, a, b, dz, dw, small, big, accumulate, scratch,
+                                             wgrad3d_s2_workgroups(small, pairs0), s);
+    }
     WS2Args A;
     A.a = a;
     A.b = b;

@@ -320,6 +320,35 @@ def test_standalone_blocks_backward_eight_features_odd_sizes(dev):
     assert relative_error(xi.grad, gxi) <= REL_TOL and relative_error(sc.grad, gsc) <= REL_TOL
     check_param_grads(exp, '_e', gp)
 
+    # shapes the rolling stride-2 weight-gradient kernel takes (widths that are multiples of 4 on both grids; the switch
+    # test runs this test with PDS_WGRAD3D_S2_ROLLING=2, which sends them there however small they are)
+    for features, shape in ((8, (1, 8, 6, 10, 16)), (8, (2, 8, 5, 7, 8))):
+        con = helpers.seeded(lambda: pds.ContractionBlock3d(features), seed=25).to(dev)
+        x = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+        down, smooth = con(x)
+        wd, wsm = torch.randn(*down.shape, generator=g), torch.randn(*smooth.shape, generator=g)
+        ((down * wd.to(dev)).sum() + (smooth * wsm.to(dev)).sum()).backward()
+        params = helpers.prefixed(con.state_dict(), '_c')
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+        d64, s64 = oracle.contraction_block_3d(p64, '_c', x64)
+        ((d64 * wd.double()).sum() + (s64 * wsm.double()).sum()).backward()
+        assert relative_error(x.grad, x64.grad) <= REL_TOL
+        check_param_grads(con, '_c', {k: v.grad for k, v in p64.items()})
+    for features, shape in ((8, (1, 8, 3, 5, 8)), (16, (2, 16, 3, 4, 8))):
+        exp = helpers.seeded(lambda: pds.ExpansionBlock3d(features), seed=26).to(dev)
+        xi = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+        big = (shape[0], features // 2, 2 * shape[2], 2 * shape[3], 2 * shape[4])
+        sc = torch.randn(*big, generator=g).to(dev).requires_grad_(True)
+        wo = torch.randn(*big, generator=g)
+        out = exp(xi, sc)
+        (out * wo.to(dev)).sum().backward()
+        params = helpers.prefixed(exp.state_dict(), '_e')
+        ref, (gxi, gsc), gp = oracle_grads(lambda p, a, b: oracle.expansion_block_3d(p, '_e', a, b), [xi, sc], params, wo)
+        assert relative_error(out, ref) <= 1e-4
+        assert relative_error(xi.grad, gxi) <= REL_TOL and relative_error(sc.grad, gsc) <= REL_TOL
+        check_param_grads(exp, '_e', gp)
+
     # a 16 -> 8 expansion: the transposed layer's dz has 8 channels (two taps per column group in its weight gradient)
     exp = helpers.seeded(lambda: pds.ExpansionBlock3d(16), seed=24).to(dev)
     xi = torch.randn(2, 16, 3, 4, 9, generator=g).to(dev).requires_grad_(True)

@@ -48,6 +48,8 @@ BACKWARD_SWITCHES = [
     {'PDS_WGRAD2D_X3': '0'},          # 2-D weight gradients on the exact-fp32 MFMA kernel
     {'PDS_BWD_DATA_V2': '0'},         # stride-2 data gradients on the one-position-per-thread kernels of round 2
     {'PDS_IN_BWD_PLANE': '0'},        # InstanceNorm backward of per-plane groups on the two-pass kernels
+    {'PDS_WGRAD3D_S2_ROLLING': '2'},  # the rolling stride-2 weight-gradient kernel also for small layers
+    {'PDS_WGRAD3D_S2_ROLLING': '0'},  # ... and never
     {'PDS_WGRAD3D_MFMA': '0', 'PDS_WGRAD3D_S2_MFMA': '0'},   # 3-D weight gradients on the VALU kernels
 ]
 
@@ -60,7 +62,8 @@ def test_alternative_backward_paths(hip_library, switch):
            'tests/test_gpu_backward.py::test_matching_operation_backward',
            'tests/test_gpu_backward.py::test_matching_training_route_backward',
            'tests/test_gpu_backward.py::test_regularization_backward',
-           'tests/test_gpu_backward.py::test_standalone_blocks_backward']
+           'tests/test_gpu_backward.py::test_standalone_blocks_backward',
+           'tests/test_gpu_backward.py::test_standalone_blocks_backward_eight_features_odd_sizes']
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = out.stdout.decode(errors='replace')[-2000:]
     assert out.returncode == 0, tail
