@@ -777,9 +777,12 @@ int launch_bwd_data2(int transposed, int kd, const float* dz, const float* w, fl
     Q.segs = (pairs + pw - 1) / pw;
     const int rows = transposed ? G.Hi : (G.Hi + 1) / 2;   // rows per parity for the strided convolution
     Q.yblocks = (rows + ry - 1) / ry;
-    const int cb = (G.Cin % 8 == 0) ? 8 : 4;
+    // 8 input channels per wave share its loads best; the deep levels (a few hundred units) take 4 for twice the waves
+    int cb = (G.Cin % 8 == 0) ? 8 : 4;
+    const int per_cb = G.N * G.Di * (transposed ? 1 : 2) * Q.yblocks * Q.segs;
+    if (cb == 8 && per_cb * (G.Cin / 8) < 512) cb = 4;
     Q.cbs = (G.Cin + cb - 1) / cb;
-    Q.units = G.N * Q.cbs * G.Di * (transposed ? 1 : 2) * Q.yblocks * Q.segs;
+    Q.units = per_cb * Q.cbs;
     // enough waves to fill the chip (256 CUs x 16 wave slots) before the output channels stay with one wave
     int ocg = 1;
     while (ocg < 4 && (size_t)Q.units * ocg < 4096 && G.Cout >= 8 * ocg) ocg *= 2;
