@@ -36,7 +36,7 @@ struct WArgs {
 
 }  // namespace
 
-template <int MBW, bool HAS_B>
+template <int MBW, bool HAS_B, bool PARTIAL = false>
 __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A) {
     constexpr int PARTS = 4 / MBW;          // waves sharing one output block split the column blocks
     constexpr int NB = NBLK / PARTS;        // column blocks per wave
@@ -53,6 +53,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // a partial channel group (the 12-channel space-to-depth layer of the embedding): the 16-channel blocks beyond Cin are
+    // neither staged nor multiplied (their accumulators stay zero and are never written)
+    // (a separate instantiation: the checks cost the full groups 134 -> 172 us per single-plane layer)
+    const int cblocks = PARTIAL ? min(CG / 16, (A.Cin - cg0 + 15) / 16) : CG / 16;
     // 16-byte staging needs rows that start 16-byte aligned
     const bool vec_ok = (A.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.a.p) | reinterpret_cast<uintptr_t>(A.b.p)) & 15) == 0;
     for (int item = blockIdx.x; item < A.items; item += gridDim.x) {
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
             for (int itl = 0; itl < FLY; ++itl) {
                 const int it = it0 + itl;
                 const int cr = min(wave * (RPI * ITER) + it * RPI + rs, CG * 3 - 1), c = cr / 3, rr = cr - c * 3;
+                if (PARTIAL && c >= 16 * cblocks) continue;
                 const int yy = y - 1 + rr;
                 const bool chok = cg0 + c < A.Cin;
                 const int ch = min(cg0 + c, A.Cin - 1);
@@ -215,8 +220,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_mfma_kernel(const WArgs A)
                 const int nb = part * NB + i;           // column block: tap = nb / 4, channel block = nb % 4
                 const int t = nb / (CG / 16), cb = nb % (CG / 16);
                 const int dy = t / 3, dx = t % 3;
-                const float bf = brow[cb * 16 * XS + dy * RSX + ks * 4 + dx];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
+                if (!PARTIAL || cb < cblocks) {   // workgroup-uniform
+                    const float bf = brow[cb * 16 * XS + dy * RSX + ks * 4 + dx];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -315,7 +322,9 @@ int launch_wgrad2d_mfma(const Src& a, const Src& b, const Src& dzs, float* dw, c
     A.items = in.n * in.d * in.h * A.segs;
     const int wgs = wgrad2d_workgroups(in);
     dim3 grid(wgs, (in.c + CG - 1) / CG);
-    if (out.c == 64) {
+    if (out.c == 64 && in.c < CG && !b.p) {   // one partial channel group (the embedding's 12-channel layer)
+        hipLaunchKernelGGL((wgrad2d_mfma_kernel<4, false, true>), grid, dim3(THREADS), 0, s, A);
+    } else if (out.c == 64) {
         if (b.p) hipLaunchKernelGGL((wgrad2d_mfma_kernel<4, true>), grid, dim3(THREADS), 0, s, A);
         else hipLaunchKernelGGL((wgrad2d_mfma_kernel<4, false>), grid, dim3(THREADS), 0, s, A);
     } else {
