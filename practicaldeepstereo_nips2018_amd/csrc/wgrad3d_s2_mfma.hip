@@ -312,6 +312,89 @@ __global__ __launch_bounds__(256) void wgrad_up_full_mfma_kernel(const UFArgs A)
     const int nn = lane & 15;
     const float* arow = sl + nn * DS + (lane >> 4);
     const float* brow = bl + (nn >> 2) * UF_RS + (nn & 1) * UF_HS + ((nn & 3) >> 1) + (lane >> 4);
+    if (vec_ok) {
+        // 16-byte loads, and the NEXT item's operands requested before this item's MFMAs: a wave works alone on its items
+        // (no workgroup barrier), so without the prefetch every item waited out a full global-load round trip -- 5.4 us
+        // per item for 8 MFMAs
+        f32x4 vz, vx[2];
+        float hv = 0.f;
+        bool okz = false, okx[2] = {false, false};
+        auto load_item = [&](int item) __attribute__((always_inline)) {
+            int r = item;
+            const int seg = r % A.segs;
+            r /= A.segs;
+            const int iy = r % A.Hi;
+            r /= A.Hi;
+            const int oz = r % A.Di;
+            const int n = r / A.Di;
+            const int x0 = seg * TWG;
+            const float* pz = A.dz + ((size_t)n * A.Di + oz) * plane_o;
+            {
+                const int kh = lane >> 4, q = lane & 15;
+                const int oy = 2 * iy - 1 + kh, ox = 2 * x0 + 4 * q;
+                okz = oy >= 0 && oy < Ho && ox < Wo;
+                vz = *reinterpret_cast<const f32x4*>(pz + (size_t)min(max(oy, 0), Ho - 1) * Wo + min(ox, Wo - 4));
+                hv = 0.f;
+                if (lane < 8) {   // halo columns 2 x0 - 1 and 2 x0 + 64
+                    const int hk = lane >> 1, side = lane & 1;
+                    const int hy = 2 * iy - 1 + hk, hx = side ? 2 * x0 + 64 : 2 * x0 - 1;
+                    if (hy >= 0 && hy < Ho && hx >= 0 && hx < Wo) hv = pz[(size_t)hy * Wo + hx];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = lane + 64 * j;
+                okx[j] = false;
+                vx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < A.Cin * 3 * (TWG / 4)) {
+                    const int q = e % (TWG / 4), ck = e / (TWG / 4);
+                    const int c = ck / 3, kd = ck - c * 3;
+                    const int iz = oz + 1 - kd, ix = x0 + 4 * q;
+                    okx[j] = iz >= 0 && iz < A.Di && ix < A.Wi;
+                    const int g = n * A.Cin + c;
+                    const float sa = A.a.scale ? A.a.scale[g] : 1.f, ha = A.a.scale ? A.a.shift[g] : 0.f;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(
+                        A.a.p + ((size_t)g * A.Di + min(max(iz, 0), A.Di - 1)) * plane_i + (size_t)iy * A.Wi + min(ix, A.Wi - 4));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) vx[j][k] = fmaf(sa, v[k], ha);
+                }
+            }
+        };
+        auto store_item = [&]() __attribute__((always_inline)) {
+            const int kh = lane >> 4, q = lane & 15;
+            float* row = bl + kh * UF_RS;
+            // columns xx = 4 q + 1 .. 4 q + 4 of the staged row: odd half [2 q], even [2 q + 1], odd [2 q + 1], even [2 q + 2]
+            *reinterpret_cast<float2*>(row + UF_HS + 2 * q) = make_float2(okz ? vz[0] : 0.f, okz ? vz[2] : 0.f);
+            row[2 * q + 1] = okz ? vz[1] : 0.f;
+            row[2 * q + 2] = okz ? vz[3] : 0.f;
+            if (lane < 8) bl[(lane >> 1) * UF_RS + ((lane & 1) ? UF_HS + TWG : 0)] = hv;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = lane + 64 * j;
+                if (e < A.Cin * 3 * (TWG / 4)) {
+                    const int q2 = e % (TWG / 4), ck = e / (TWG / 4);
+                    const int c = ck / 3, kd = ck - c * 3;
+                    float* dst = sl + (c * 4 + kd) * DS + 4 * q2;
+                    *reinterpret_cast<float2*>(dst) = make_float2(okx[j] ? vx[j][0] : 0.f, okx[j] ? vx[j][1] : 0.f);
+                    *reinterpret_cast<float2*>(dst + 2) = make_float2(okx[j] ? vx[j][2] : 0.f, okx[j] ? vx[j][3] : 0.f);
+                }
+            }
+        };
+        if (gwave < A.items) load_item(gwave);
+        for (int item = gwave; item < A.items; item += nwaves) {
+            store_item();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (item + nwaves < A.items) load_item(item + nwaves);
+#pragma unroll
+            for (int ks = 0; ks < TWG / 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[ks * 4], brow[ks * 4], acc, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else
     for (int item = gwave; item < A.items; item += nwaves) {
         int r = item;
         const int seg = r % A.segs;
@@ -323,46 +406,6 @@ __global__ __launch_bounds__(256) void wgrad_up_full_mfma_kernel(const UFArgs A)
         const int x0 = seg * TWG;
         // dz rows 2 iy - 1 .. 2 iy + 2, columns 2 x0 - 1 .. 2 x0 + 64, split by column parity
         const float* pz = A.dz + ((size_t)n * A.Di + oz) * plane_o;
-        if (vec_ok) {
-            // 16-byte loads (the element loops below spend ~20 instructions of index arithmetic per staged float: the kernel
-            // ran at 0.9 TB/s of staged data): a dz row is 16 aligned quads = one per lane over the four rows, plus its
-            // two halo columns; the 12 xhat rows are 96 quads
-            {
-                const int kh = lane >> 4, q = lane & 15;
-                const int oy = 2 * iy - 1 + kh, ox = 2 * x0 + 4 * q;
-                const bool ok = oy >= 0 && oy < Ho && ox < Wo;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(pz + (size_t)min(max(oy, 0), Ho - 1) * Wo + min(ox, Wo - 4));
-                float* row = bl + kh * UF_RS;
-                // columns xx = 4 q + 1 .. 4 q + 4 of the staged row: odd half [2 q], even [2 q + 1], odd [2 q + 1], even [2 q + 2]
-                *reinterpret_cast<float2*>(row + UF_HS + 2 * q) = make_float2(ok ? v[0] : 0.f, ok ? v[2] : 0.f);
-                row[2 * q + 1] = ok ? v[1] : 0.f;
-                row[2 * q + 2] = ok ? v[3] : 0.f;
-                if (lane < 8) {   // halo columns 2 x0 - 1 (even half [0]) and 2 x0 + 64 (odd half [32])
-                    const int hk = lane >> 1, side = lane & 1;
-                    const int hy = 2 * iy - 1 + hk, hx = side ? 2 * x0 + 64 : 2 * x0 - 1;
-                    float hv = 0.f;
-                    if (hy >= 0 && hy < Ho && hx >= 0 && hx < Wo) hv = pz[(size_t)hy * Wo + hx];
-                    bl[hk * UF_RS + (side ? UF_HS + TWG : 0)] = hv;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int e = lane + 64 * j;
-                if (e < A.Cin * 3 * (TWG / 4)) {
-                    const int q = e % (TWG / 4), ck = e / (TWG / 4);
-                    const int c = ck / 3, kd = ck - c * 3;
-                    const int iz = oz + 1 - kd, ix = x0 + 4 * q;
-                    const bool ok = iz >= 0 && iz < A.Di && ix < A.Wi;
-                    const int g = n * A.Cin + c;
-                    const float sa = A.a.scale ? A.a.scale[g] : 1.f, ha = A.a.scale ? A.a.shift[g] : 0.f;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(
-                        A.a.p + ((size_t)g * A.Di + min(max(iz, 0), A.Di - 1)) * plane_i + (size_t)iy * A.Wi + min(ix, A.Wi - 4));
-                    float* dst = sl + (c * 4 + kd) * DS + 4 * q;
-                    *reinterpret_cast<float2*>(dst) = make_float2(ok ? fmaf(sa, v[0], ha) : 0.f, ok ? fmaf(sa, v[1], ha) : 0.f);
-                    *reinterpret_cast<float2*>(dst + 2) = make_float2(ok ? fmaf(sa, v[2], ha) : 0.f, ok ? fmaf(sa, v[3], ha) : 0.f);
-                }
-            }
-        } else {
         for (int e = lane; e < 4 * BCOLS; e += 64) {
             const int kh = e / BCOLS, xx = e - kh * BCOLS;
             const int oy = 2 * iy - 1 + kh, ox = 2 * x0 - 1 + xx;
@@ -382,7 +425,6 @@ __global__ __launch_bounds__(256) void wgrad_up_full_mfma_kernel(const UFArgs A)
                 v = fmaf(sa, A.a.p[((size_t)g * A.Di + iz) * plane_i + (size_t)iy * A.Wi + ix], ha);
             }
             sl[(c * 4 + kd) * DS + px] = v;
-        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
