@@ -75,7 +75,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void wgrad3d_s2r_kernel(const RArgs A
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int plane_s = A.Hs * A.Ws, plane_b = A.Hb * A.Wb;
-    const unsigned vol_s = (unsigned)A.Ds * plane_s, vol_b = (unsigned)A.Db * plane_b;
+    const unsigned vol_b = (unsigned)A.Db * plane_b;
 
     // lane's tap of column group i: taps g NT + tj, g = wave + 4 i
     const int tj = (lane & 15) / CB;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(R_THREADS, 2) void wgrad3d_s2r_kernel(const RArgs A
         }
 
         // ---- what this thread stages of a PAIR of big planes (Z, Z + 1): runs of 18 lanes ----------------------------
-        int boff[C::NSTG], bdst[C::NSTG];   // offset inside (channel block, plane 0) or -1; LDS row address or -1
+        // boff: offset inside (channel block, plane 0) or -1; bdst: (LDS row address << 3) | halo kind << 1 | plane of the pair, or -1
+        int boff[C::NSTG], bdst[C::NSTG];
 #pragma unroll
         for (int j = 0; j < C::NSTG; ++j) {
             const int e = tid + j * R_THREADS;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void wgrad3d_s2r_kernel(const RArgs A
             const bool ok = slot && c < A.Cb && Y >= 0 && Y < A.Hb && X >= 0 && X < A.Wb;
             boff[j] = ok ? c * (int)vol_b + Y * A.Wb + X : -1;
             // low bits: which of the pair's planes (bit 0), halo kind in bits 1-2 (0 quad, 1 left, 2 right)
-            bdst[j] = slot ? ((c * C::XS + row * C::RS) << 3) | (pl) | ((part < 16 ? 0 : part == 16 ? 1 : 2) << 1) | 0 : -1;
+            bdst[j] = slot ? ((c * C::XS + row * C::RS) << 3) | pl | ((part < 16 ? 0 : part == 16 ? 1 : 2) << 1) : -1;
             if (slot && part < 16) bdst[j] += (2 * part) << 3;
         }
         const float* bsrc = (SMALL_NORM ? A.dz : A.a.p) + (size_t)n * A.Cb * vol_b;
