@@ -307,17 +307,24 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
     double* partials = scratch;
     double* qs = scratch + (size_t)geom.n * geom.c * geom.d * tiles * 2;
     double* bias_partial = qs + (size_t)geom.n * geom.c * geom.d * 2;
-    if (in_bwd_plane_supported(g, t, dz, geom, per_plane)) {
+    // a whole-volume group that is small enough (the deep levels of the hourglass: 12 x 36 x 60 and below) is one "plane"
+    Geom view = geom;
+    if (!per_plane && (size_t)geom.d * geom.plane() <= (size_t)kPlaneThreads * kPlaneQuads * 4) {
+        view.w = geom.d * geom.h * geom.w;
+        view.h = 1;
+        view.d = 1;
+    }
+    if (in_bwd_plane_supported(g, t, dz, view, per_plane || view.d != geom.d || geom.d == 1)) {
         // the maxima are collected by the kernel that also produces the records in_bwd_params_kernel sums, so the slots
         // are cleared ahead of it instead of by that kernel
         if (dz_amax && hipMemsetAsync(dz_amax, 0, kDzAmaxSlots * sizeof(float), s) != hipSuccess)
             return set_error(-1, "in_bwd: clearing the range slots failed");
-        hipLaunchKernelGGL(in_bwd_plane_kernel, dim3(geom.n * geom.c * geom.d), dim3(kPlaneThreads), 0, s, g, t, geom, mean,
+        hipLaunchKernelGGL(in_bwd_plane_kernel, dim3(view.n * view.c * view.d), dim3(kPlaneThreads), 0, s, g, t, view, mean,
                            rstd, gamma, dz, qs, bias_partial, dz_amax);
-        hipLaunchKernelGGL(in_bwd_params_kernel, dim3(geom.c), dim3(64), 0, s, qs, geom.n, geom.c, geom.d, dgamma, dbeta,
+        hipLaunchKernelGGL(in_bwd_params_kernel, dim3(view.c), dim3(64), 0, s, qs, view.n, view.c, view.d, dgamma, dbeta,
                            accumulate_params, static_cast<float*>(nullptr));
-        hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(geom.c), dim3(256), 0, s, bias_partial, geom.n, geom.c,
-                           geom.d, dbias, accumulate_params);
+        hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(view.c), dim3(256), 0, s, bias_partial, view.n, view.c,
+                           view.d, dbias, accumulate_params);
         return check_launch("in_bwd_plane");
     }
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(tiles, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
