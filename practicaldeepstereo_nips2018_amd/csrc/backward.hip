@@ -79,25 +79,31 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(64) void in_bwd_params_kernel(const double* __restrict__ qs, int n_batch, int channels,
                                                            int inner, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate,
-                                                           float* __restrict__ dz_amax) {
+                                                           float* __restrict__ dz_amax,
+                                                           const double* __restrict__ bias_group = nullptr,
+                                                           float* __restrict__ dbias = nullptr) {
     const int c = blockIdx.x;
     // the slots the apply kernel (next launch) collects max |dz| in -- the range certificate of dz (Src::bound) for the
     // fp16-split weight- and data-gradient kernels -- start from zero
     if (dz_amax && c == 0)
         for (int i = threadIdx.x; i < kDzAmaxSlots; i += 64) dz_amax[i] = 0.f;
-    double q = 0.0, s = 0.0;
+    // (the one-pass kernel leaves ONE bias partial per group: its sum over the channel's groups rides along)
+    double q = 0.0, s = 0.0, b = 0.0;
     const int per_c = n_batch * inner;
     for (int i = threadIdx.x; i < per_c; i += 64) {
         const int n = i / inner, d = i % inner;
         const size_t grp = ((size_t)n * channels + c) * inner + d;
         q += qs[2 * grp];
         s += qs[2 * grp + 1];
+        if (bias_group) b += bias_group[grp];
     }
     q = wave_sum(q);
     s = wave_sum(s);
+    if (bias_group) b = wave_sum(b);
     if (threadIdx.x == 0) {
         dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
         dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+        if (bias_group) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)b;
     }
 }
 
@@ -322,9 +328,7 @@ int launch_in_bwd(const float* g, const float* t, const Geom& geom, int per_plan
         hipLaunchKernelGGL(in_bwd_plane_kernel, dim3(view.n * view.c * view.d), dim3(kPlaneThreads), 0, s, g, t, view, mean,
                            rstd, gamma, dz, qs, bias_partial, dz_amax);
         hipLaunchKernelGGL(in_bwd_params_kernel, dim3(view.c), dim3(64), 0, s, qs, view.n, view.c, view.d, dgamma, dbeta,
-                           accumulate_params, static_cast<float*>(nullptr));
-        hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(view.c), dim3(256), 0, s, bias_partial, view.n, view.c,
-                           view.d, dbias, accumulate_params);
+                           accumulate_params, static_cast<float*>(nullptr), static_cast<const double*>(bias_partial), dbias);
         return check_launch("in_bwd_plane");
     }
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(tiles, geom.d, geom.n * geom.c), dim3(256), 0, s, g, t, geom,
