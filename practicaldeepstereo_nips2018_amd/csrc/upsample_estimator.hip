@@ -45,15 +45,22 @@ struct FusedArgs {
 
 // WRITE_COST = true: training-mode forward, every finished plane is stored to the cost volume and no
 // estimator state is kept (T is ignored).
-// A workgroup is TWO waves on the same input tile: wave PY owns the output rows of parity PY (4 pixels per lane instead
-// of 2 x 4).  One wave per tile left a single wave per SIMD on the chip (1080 tiles on 1024 SIMDs): nothing hid the
-// LDS / scalar-load latencies of the sweep.
-constexpr int UTHREADS = 128;
-constexpr int UPOS = (NPOS + UTHREADS - 1) / UTHREADS;   // 2 staged positions per thread and channel
+// A tile is swept by 2 x DS waves: wave (PY, part) owns the output rows of parity PY (4 pixels per lane instead of 2 x 4)
+// and the candidate planes [part D / DS, (part + 1) D / DS).  Round 5: one wave per (tile, parity) put 2 160 waves on
+// 1 024 SIMDs -- some SIMDs carried three sweeps, most two, and the launch lasted as long as the three (the kernel is bound by
+// VALU issue and by the un-hidden scalar-load / LDS waits of so few waves, NOT by its halo re-reads: with the halo loads
+// redirected to the tile's own interior, -DPDS_UPS_NOHALO, the fabric traffic drops from 721 to 212 MB and the launch takes
+// the same 154 us; profiles/r05_upsample_fetch_calibration.txt).  With the plane range cut in DS = 2 parts the chip carries
+// 4 320 half-length sweeps (4.2 per SIMD, at most 5): better balance, twice the waves to hide each other's waits.  A part
+// sweeps T + 1 planes beyond either end of its range (window values only, never candidates), so the parts' states are exact
+// and the merge is a comparison of their maxima (ties: the lower plane, as estimator.py's argmax).
+constexpr int UHALF = 128;                               // threads that stage one part's planes (two waves)
+constexpr int UPOS = (NPOS + UHALF - 1) / UHALF;         // 2 staged positions per thread and channel
+constexpr int EO = HC / 2;                               // a halo row is stored as [even columns 17][odd columns 17]
 
-template <int CIN, int T, bool WRITE_COST, int PY>
-__device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)[CIN][NPOS + 4]) {
-    const int tid = threadIdx.x;
+template <int CIN, int T, bool WRITE_COST, int PY, int DS>
+__device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)[CIN][NPOS + 4], float* merge, const int part) {
+    const int tid = threadIdx.x & (UHALF - 1);
     const int lane = tid & 63;
     const int r = lane >> 4, cp = lane & 15;
     const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
@@ -62,16 +69,35 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
     const size_t cstride = (size_t)A.D * plane;
     const float* src = A.in + (size_t)b * CIN * cstride;
 
+    // candidate planes of this part, the input planes it sweeps and the common number of steps (barriers are shared)
+    const int per = (A.D + DS - 1) / DS;
+    const int lo = DS == 1 ? 0 : part * per, hi = DS == 1 ? A.D : min(A.D, lo + per);
+    const int pb = DS == 1 ? 0 : max(lo - T - 1, 0);         // first input plane: output plane pb + 1 is the first complete one
+    const int pe = WRITE_COST ? A.D : hi + T;                // last step: plane pe - 1 enters the window, centre = hi - 1
+    int nsteps = pe - pb + 1;
+    if (DS > 1) {
+#pragma unroll
+        for (int q = 0; q < DS; ++q) {
+            const int lq = q * per, hq = min(A.D, lq + per);
+            nsteps = max(nsteps, hq + T - max(lq - T - 1, 0) + 1);
+        }
+    }
+
     int goff[UPOS], loff[UPOS];
     bool inside[UPOS];
 #pragma unroll
     for (int k = 0; k < UPOS; ++k) {
-        const int p = min(tid + k * UTHREADS, NPOS - 1);
+        const int p = min(tid + k * UHALF, NPOS - 1);
         const int rr = p / HC, cc = p % HC;
         const int y = i0 - 1 + rr, x = j0 - 1 + cc;
         inside[k] = y >= 0 && y < A.Hi && x >= 0 && x < A.Wi;
+#ifdef PDS_UPS_NOHALO   // FETCH_SIZE calibration (wrong results by design): every tile reads its own 4 x 32 interior only,
+                        // with the same load instructions -- the launch then fetches exactly the input tensor's bytes
+        goff[k] = min(max(y, i0), min(i0 + TR, A.Hi) - 1) * A.Wi + min(max(x, j0), min(j0 + TC, A.Wi) - 1);
+#else
         goff[k] = min(max(y, 0), A.Hi - 1) * A.Wi + min(max(x, 0), A.Wi - 1);
-        loff[k] = p;
+#endif
+        loff[k] = rr * HC + (cc & 1) * EO + (cc >> 1);
     }
     float sc[CIN], sh[CIN];
 #pragma unroll
@@ -100,7 +126,7 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         best[o] = -INFINITY;
-        bi[o] = 0;
+        bi[o] = lo;
 #pragma unroll
         for (int t = 0; t < T; ++t) bprev[o][t] = bnext[o][t] = -INFINITY;
 #pragma unroll
@@ -112,29 +138,30 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
 #pragma unroll
     for (int o = 0; o < 2; ++o) acc[0][o] = acc[1][o] = acc[2][o] = f32x2{bias, bias};
 
-    PDS_FETCHP(stB, 0)
-    if (1 < A.D) PDS_FETCHP(stA, 1)
+    PDS_FETCHP(stB, pb)
+    if (pb + 1 < A.D) PDS_FETCHP(stA, pb + 1)
     PDS_STASHP(stB, 0)
     __syncthreads();
 
-    const int lbase = r * HC + 2 * cp;  // halo row r, halo column 2cp  (input column j0 + 2cp - 1)
+    // halo row r, halo columns 2cp .. 2cp + 3 (input columns j0 + 2cp - 1 ..): the even pair (v0, v2) = E[cp], E[cp + 1] and
+    // the odd pair (v1, v3) = O[cp], O[cp + 1] are the second operands of the packed FMAs below as they stand
+    const int lbase = r * HC + cp;
     // one plane step: sx holds plane p + 1 (requested a step ago), sy receives plane p + 2
-    auto plane_step = [&](const int p, float (&sx)[CIN][UPOS], float (&sy)[CIN][UPOS]) __attribute__((always_inline)) {
-        if (p < A.D) {
-            const int cur = p & 1;
-            if (p + 2 < A.D) PDS_FETCHP(sy, p + 2)
+    auto plane_step = [&](const int step, float (&sx)[CIN][UPOS], float (&sy)[CIN][UPOS]) __attribute__((always_inline)) {
+        const int p = pb + step;
+        if (p < A.D && p <= pe) {
+            const int cur = step & 1;
+            if (p + 2 < A.D && p + 2 <= pe) PDS_FETCHP(sy, p + 2)
 #pragma nounroll
             for (int c = 0; c < CIN; ++c) {  // not unrolled: keeps only 3 x 16 weight SGPRs live
-                // the two halo rows this output-row parity uses: vr = 1 (tap kh = 1 / 2) and vr = 0 / 2 (kh = 3 / 0).  The four
-                // input columns v0 .. v3 of a row arrive as the pairs (v0, v2) and (v1, v3) (ds_read2_b32 with offsets 0 / 2
-                // and 1 / 3), which are the second operands of the packed FMAs below as they stand.
+                // the two halo rows this output-row parity uses: vr = 1 (tap kh = 1 / 2) and vr = 0 / 2 (kh = 3 / 0)
                 f32x2 r02[2], r13[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int vr = (a == 0) ? 1 : (PY == 0 ? 0 : 2);
                     const float* row = &tile[cur][c][lbase + vr * HC];
-                    r02[a] = f32x2{row[0], row[2]};
-                    r13[a] = f32x2{row[1], row[3]};
+                    r02[a] = f32x2{row[0], row[1]};
+                    r13[a] = f32x2{row[EO], row[EO + 1]};
                 }
                 // the 3 x 16 taps of channel c as SGPR operands: explicit s_load_dwordx16 (hipcc turns plain reads of
                 // the weight pointer into vector loads parked in VGPRs, which spills this kernel); the three loads
@@ -165,9 +192,9 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
                     }
                 }
             }
-            if (p + 1 < A.D) PDS_STASHP(sx, cur ^ 1)
-            __syncthreads();
+            if (p + 1 < A.D && p + 1 <= pe) PDS_STASHP(sx, cur ^ 1)
         }
+        __syncthreads();
         if (WRITE_COST) {
             if (p >= 1) {  // store the finished plane p - 1
                 const int i = i0 + r, j = j0 + 2 * cp;
@@ -190,7 +217,7 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
 #pragma unroll
                 for (int t = 0; t < 2 * T; ++t) win[o][t] = win[o][t + 1];
                 win[o][2 * T] = k < A.D ? acc[0][o >> 1][o & 1] : -INFINITY;
-                const bool up = centre >= 0 && win[o][T] > best[o];  // strict: first occurrence wins
+                const bool up = centre >= lo && centre < hi && win[o][T] > best[o];  // strict: first occurrence wins
                 best[o] = up ? win[o][T] : best[o];
                 bi[o] = up ? centre : bi[o];
 #pragma unroll
@@ -207,15 +234,51 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
             acc[2][o] = f32x2{bias, bias};
         }
     };
-    const int last = A.D + (WRITE_COST ? 0 : T);   // + T flush steps that only drain the window
-    for (int p = 0; p <= last; p += 2) {
-        plane_step(p, stA, stB);
-        if (p + 1 <= last) plane_step(p + 1, stB, stA);
+    for (int step = 0; step < nsteps; step += 2) {
+        plane_step(step, stA, stB);
+        if (step + 1 < nsteps) plane_step(step + 1, stB, stA);
     }
 #undef PDS_FETCHP
 #undef PDS_STASHP
 
     if (WRITE_COST) return;
+    // the parts' states meet in LDS (the tiles are idle behind the last barrier): part q > 0 publishes, part 0 folds them in
+    // ascending order -- a later part wins only with a strictly larger maximum, i.e. the first occurrence wins
+    if (DS > 1) {
+        constexpr int ITEMS = 4 * (2 + 2 * T);
+        float* mine = merge + ((size_t)(part > 0 ? part - 1 : 0) * 2 + PY) * ITEMS * 64 + lane;
+        if (part > 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                mine[(o * (2 + 2 * T) + 0) * 64] = best[o];
+                mine[(o * (2 + 2 * T) + 1) * 64] = __int_as_float(bi[o]);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    mine[(o * (2 + 2 * T) + 2 + t) * 64] = bprev[o][t];
+                    mine[(o * (2 + 2 * T) + 2 + T + t) * 64] = bnext[o][t];
+                }
+            }
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int q = 1; q < DS; ++q) {
+            const float* theirs = merge + ((size_t)(q - 1) * 2 + PY) * ITEMS * 64 + lane;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float other = theirs[(o * (2 + 2 * T) + 0) * 64];
+                const bool up = other > best[o];
+                best[o] = up ? other : best[o];
+                bi[o] = up ? __float_as_int(theirs[(o * (2 + 2 * T) + 1) * 64]) : bi[o];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float pv = theirs[(o * (2 + 2 * T) + 2 + t) * 64], nv = theirs[(o * (2 + 2 * T) + 2 + T + t) * 64];
+                    bprev[o][t] = up ? pv : bprev[o][t];
+                    bnext[o][t] = up ? nv : bnext[o][t];
+                }
+            }
+        }
+    }
     // soft-arg-max around the best plane (estimator.py:84-91)
     const int planes = A.D;
     const int i = i0 + r, j = j0 + 2 * cp;
@@ -258,13 +321,18 @@ __device__ __forceinline__ void upsample_sweep(const FusedArgs& A, float (*tile)
     }
 }
 
-template <int CIN, int T, bool WRITE_COST>
-__global__ __launch_bounds__(UTHREADS) void upsample_full_subpixel_kernel(const FusedArgs A) {
-    __shared__ __attribute__((aligned(16))) float tile[2][CIN][NPOS + 4];
-    if ((threadIdx.x >> 6) == 0)
-        upsample_sweep<CIN, T, WRITE_COST, 0>(A, tile);
+template <int CIN, int T, bool WRITE_COST, int DS>
+__global__ __launch_bounds__(UHALF * DS) void upsample_full_subpixel_kernel(const FusedArgs A) {
+    constexpr int TILE = 2 * CIN * (NPOS + 4), MERGE = (DS - 1) * 2 * 4 * (2 + 2 * T) * 64;
+    constexpr int FLOATS = DS * TILE > MERGE ? DS * TILE : MERGE;
+    __shared__ __attribute__((aligned(16))) float lds[FLOATS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int part = wave >> 1;
+    float (*tile)[CIN][NPOS + 4] = reinterpret_cast<float (*)[CIN][NPOS + 4]>(lds + part * TILE);
+    if ((wave & 1) == 0)
+        upsample_sweep<CIN, T, WRITE_COST, 0, DS>(A, tile, lds, part);
     else
-        upsample_sweep<CIN, T, WRITE_COST, 1>(A, tile);
+        upsample_sweep<CIN, T, WRITE_COST, 1, DS>(A, tile, lds, part);
 }
 
 // [C][3][4][4] weights of the (3, 4, 4) transposed convolution -> the same table with the four kw taps of every kernel
@@ -308,11 +376,11 @@ int launch_upsample_estimator(const float* in, const float* scale, const float* 
     if (cin != 4) return set_error(-1, "upsample_estimator: unsupported channel count %d", cin);
     A.cost = nullptr;
     if (t <= 1)
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, false>), grid, dim3(UTHREADS), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, false, 2>), grid, dim3(2 * UHALF), 0, s, A);
     else if (t <= 2)
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2, false>), grid, dim3(UTHREADS), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 2, false, 2>), grid, dim3(2 * UHALF), 0, s, A);
     else
-        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4, false>), grid, dim3(UTHREADS), 0, s, A);
+        hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 4, false, 2>), grid, dim3(2 * UHALF), 0, s, A);
     return check_launch("upsample_full_subpixel");
 }
 
@@ -338,7 +406,7 @@ int launch_upsample_full(const float* in, const float* scale, const float* shift
     A.step = 0.f;
     A.crop_top = A.crop_left = 0;
     dim3 grid((wi + TC - 1) / TC, (hi_ + TR - 1) / TR, batch);
-    hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, true>), grid, dim3(UTHREADS), 0, s, A);
+    hipLaunchKernelGGL((upsample_full_subpixel_kernel<4, 1, true, 1>), grid, dim3(UHALF), 0, s, A);
     return check_launch("upsample_full");
 }
 

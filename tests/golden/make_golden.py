@@ -466,6 +466,102 @@ def g11_training_step():
     REPORT['g11_training_step'] = rep
 
 
+def injection_into_reference():
+    """The reference-side half of the drop-in claim (BASELINE.json north_star: "network.py/pds_trainer.py drop them in
+    unchanged"): the REFERENCE's own PdsNetwork (network.py:17-24) and PdsTrainer (pds_trainer.py:35-46, trainer.py:87-122)
+    are constructed around THIS package's modules, exactly as INTEGRATION.md section 1 shows, and exercised as far as a
+    GPU-less container allows: registration, state-dict keys in order, set_maximum_disparity reaching the injected
+    Matching, load_state_dict of a reference checkpoint, train()/eval() propagation, and a th.save / th.load round trip
+    in trainer.py:110-122's checkpoint format through the reference trainer's own _save_checkpoint / load_checkpoint.
+    No forward pass runs here (the modules have no CPU path by design); the GPU side of the same construction is
+    tests/test_gpu_parity.py.  The outcome goes to pinning_report.json."""
+    import tempfile
+    import practicaldeepstereo_nips2018_amd as pds_amd
+    from practical_deep_stereo import pds_trainer as ref_pds_trainer
+    rep = {}
+    torch.manual_seed(0)
+    reference = ref_network.PdsNetwork.default(191)
+    reference_state = {k: v.clone() for k, v in reference.state_dict().items()}
+    torch.manual_seed(123)   # different initial weights: load_state_dict below has to overwrite every tensor
+    injected = ref_network.PdsNetwork(
+        ref_size_adapter.SizeAdapter(), pds_amd.Embedding(),
+        pds_amd.Matching(0, pds_amd.MatchingOperation()), pds_amd.Regularization(), pds_amd.SubpixelMap())
+    assert type(injected).__module__ == 'practical_deep_stereo.network'
+    # (1) module registration and state-dict surface: same keys, same order, same shapes
+    keys, ref_keys = list(injected.state_dict().keys()), list(reference_state.keys())
+    assert keys == ref_keys, [k for k in keys if k not in ref_keys][:5]
+    assert all(injected.state_dict()[k].shape == reference_state[k].shape for k in keys)
+    assert [n for n, _ in injected.named_parameters()] == [n for n, _ in reference.named_parameters()]
+    rep['state_dict_keys'] = len(keys)
+    rep['state_dict_keys_equal_in_order'] = True
+    # (2) set_maximum_disparity (network.py:26-36) reaches the injected Matching
+    injected.set_maximum_disparity(191)
+    assert injected._matching._maximum_disparity == 47 and injected._maximum_disparity == 191
+    try:
+        injected.set_maximum_disparity(100)
+        raise AssertionError('ValueError expected')
+    except ValueError:
+        pass
+    rep['set_maximum_disparity_reaches_matching'] = True
+    # (3) a reference checkpoint loads (strict) and round-trips bit-exactly
+    differed = sum(int(not torch.equal(injected.state_dict()[k], reference_state[k])) for k in keys)
+    assert differed >= 60, differed   # every convolution weight (InstanceNorm affine terms start at 1 / 0 in both)
+    result = injected.load_state_dict(reference_state)
+    assert not result.missing_keys and not result.unexpected_keys
+    assert all(torch.equal(injected.state_dict()[k], reference_state[k]) for k in keys)
+    assert abs(checksum(injected.state_dict()) - checksum(reference_state)) == 0.0
+    rep['load_state_dict_round_trip_bit_exact'] = True
+    rep['parameter_checksum'] = checksum(injected.state_dict())
+    # (4) train() / eval() propagate to the injected modules (network.py:50 branches on .training)
+    injected.eval()
+    assert not any(m.training for m in injected.modules())
+    injected.train()
+    assert all(m.training for m in injected.modules())
+    rep['train_eval_propagate'] = True
+    # (5) the reference trainer around the injected network: its own checkpoint writer and reader
+    # (trainer.py:87-122), optimizer and scheduler as train_on_flyingthings3d.py builds them
+    with tempfile.TemporaryDirectory() as folder:
+        def make_trainer(network):
+            optimizer = torch.optim.RMSprop(network.parameters(), lr=1e-2)
+            scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=1, gamma=0.5)
+            return ref_pds_trainer.PdsTrainer({
+                'network': network, 'optimizer': optimizer, 'learning_rate_scheduler': scheduler,
+                'criterion': pds_amd.SubpixelCrossEntropy(), 'training_set_loader': [], 'test_set_loader': [],
+                'experiment_folder': folder, 'end_epoch': 2})
+        trainer = make_trainer(injected)
+        trainer._initialize_filenames()
+        trainer._training_losses, trainer._test_errors = [1.25], [7.5]
+        trainer._save_checkpoint()
+        filename = trainer._checkpoint_template.format(1)
+        assert os.path.exists(filename)
+        checkpoint = torch.load(filename)
+        assert sorted(checkpoint.keys()) == ['learning_rate_scheduler', 'network', 'optimizer', 'test_errors',
+                                             'training_losses']
+        assert list(checkpoint['network'].keys()) == ref_keys
+        # ... read back into a FRESH injected network by the reference trainer, and into the reference's own network
+        torch.manual_seed(7)
+        fresh = ref_network.PdsNetwork(
+            ref_size_adapter.SizeAdapter(), pds_amd.Embedding(),
+            pds_amd.Matching(0, pds_amd.MatchingOperation()), pds_amd.Regularization(), pds_amd.SubpixelMap())
+        fresh.set_maximum_disparity(191)
+        second = make_trainer(fresh)
+        second.load_checkpoint(filename)
+        assert second._current_epoch == 1 and second._training_losses == [1.25] and second._test_errors == [7.5]
+        assert all(torch.equal(fresh.state_dict()[k], reference_state[k]) for k in keys)
+        torch.manual_seed(9)
+        plain = ref_network.PdsNetwork.default(191)
+        make_trainer(plain).load_checkpoint(filename, load_only_network=True)
+        assert all(torch.equal(plain.state_dict()[k], reference_state[k]) for k in keys)
+    rep['reference_trainer_checkpoint_round_trip'] = True
+    # (6) this package's own PdsNetwork carries the same surface (what INTEGRATION.md section 1 offers as the short form)
+    torch.manual_seed(0)
+    own = pds_amd.PdsNetwork.default(191)
+    assert list(own.state_dict().keys()) == ref_keys
+    assert all(torch.equal(own.state_dict()[k], reference_state[k]) for k in keys)   # identical construction order
+    rep['own_network_seed0_equals_reference_seed0'] = True
+    REPORT['injection_into_reference'] = rep
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     if '--only' in sys.argv:  # regenerate one fixture, keep the rest of the report
@@ -488,6 +584,7 @@ if __name__ == '__main__':
     g10_errors()
     g11_training_step()
     g12_image_gradient()
+    injection_into_reference()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
     REPORT['torch'] = torch.__version__
