@@ -23,6 +23,9 @@ def main():
     ms = torch.randn(1, 8, 48, 144, 240, generator=g).to(dev)
     sc = torch.randn(1, 8, 144, 240, generator=g).to(dev)
     reg, est = net._regularization, net._estimator
+    for a in sys.argv:
+        if a.startswith('--window='):   # e.g. --window=2: SubpixelMap(half_support_window=2) -> one tap on either side
+            est = pds.SubpixelMap(half_support_window=int(a.split('=')[1]), disparity_step=2)
     with torch.no_grad():
         def step():
             return reg(ms, sc) if train else reg.forward_with_estimator(ms, sc, est)
