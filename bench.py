@@ -121,6 +121,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train-record', action='store_true',
+                    help='N = 1: skip the short config-5 (training step) record that rides on the default line')
     ap.add_argument('--streams', type=int, default=3, help='N = 1: HIP streams the pairs are dealt to (round-robin)')
     ap.add_argument('--sharded-streams', type=int, default=2,
                     help='N > 1: HIP streams the (sharded) pairs are dealt to on every rank; 1 = main stream + tail stream')
@@ -325,7 +327,52 @@ def cpu_baseline(net, ld, rd, shortcut, gpu_disparity, gpu_signatures=None, gpu_
     torch.set_num_threads(threads)
     base['single_thread'] = {'value': 1.0 / single, 'unit': 'pairs/s', 'cores': 1, 'ms_per_pair': single * 1e3,
                              'sample': 'one full pass of the same pair, torch.set_num_threads(1)'}
+    base['all_usable_cores'] = cpu_all_cores(params, ld, rd, shortcut, usable)
     return base, parity
+
+
+ALL_CORES_TIMEOUT_S = 75.0
+
+
+def cpu_all_cores(params, ld, rd, shortcut, usable):
+    """SURVEY.md 8d asks for the figure on ALL usable host cores next to the capped one.  oneDNN thrashes on this host
+    with hundreds of threads (282 s per pair was measured at 256), so the pass runs in a child process with a time limit:
+    a pass that does not finish within the limit is reported as slower than 1 / limit, not waited for."""
+    import subprocess
+    import tempfile
+    if usable <= 32:
+        return {'cores': usable, 'note': 'the capped figure above already uses every usable core'}
+    code = ("import sys, time, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from oracle import pds_oracle as oracle\n"
+            "blob = torch.load(sys.argv[1])\n"
+            "torch.set_num_threads(int(sys.argv[2]))\n"
+            "best = 1e30\n"
+            "with torch.no_grad():\n"
+            "    for i in range(2):\n"
+            "        t0 = time.perf_counter()\n"
+            "        oracle.hot_path(blob['params'], blob['ld'], blob['rd'], blob['shortcut'], %d)\n"
+            "        best = min(best, time.perf_counter() - t0)\n"
+            "        print('PASS', best, flush=True)\n" % (os.path.dirname(os.path.abspath(__file__)), MAX_DISPARITY))
+    with tempfile.TemporaryDirectory() as folder:
+        blob = os.path.join(folder, 'inputs.pt')
+        torch.save({'params': params, 'ld': ld, 'rd': rd, 'shortcut': shortcut}, blob)
+        t0 = time.perf_counter()
+        try:
+            out = subprocess.run([sys.executable, '-c', code, blob, str(usable)], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=ALL_CORES_TIMEOUT_S)
+            text = out.stdout.decode(errors='replace')
+        except subprocess.TimeoutExpired as e:
+            text = (e.stdout or b'').decode(errors='replace')
+        spent = time.perf_counter() - t0
+    passes = [float(t.split()[1]) for t in text.splitlines() if t.startswith('PASS')]
+    sample = ('the same pair, torch.set_num_threads(%d) = every usable core, child process limited to %d s '
+              '(PyTorch-CPU oracle)' % (usable, int(ALL_CORES_TIMEOUT_S)))
+    if not passes:
+        return {'value': None, 'unit': 'pairs/s', 'cores': usable, 'slower_than_pairs_per_s': 1.0 / spent,
+                'sample': sample + ': no pass finished within the limit'}
+    return {'value': 1.0 / passes[-1], 'unit': 'pairs/s', 'cores': usable, 'ms_per_pair': passes[-1] * 1e3,
+            'sample': sample + ': best of %d passes' % len(passes)}
 
 
 def gpu_baseline(net, ld, rd, shortcut, device, gpu_disparity):
@@ -351,6 +398,74 @@ def gpu_baseline(net, ld, rd, shortcut, device, gpu_disparity):
             'disparity_mae_vs_hip_path': float(delta.mean())}
 
 
+def train_record(device, steps=3, cpu=True):
+    """Config 5 on the default line: a short driver-visible record of the full-size training step --
+    train-mode PdsNetwork forward, SubpixelCrossEntropy, backward through the HIP modules, RMSprop -- with the same
+    step of the CPU oracle (ONE step: forward + loss + backward, no optimizer) timed on the host beside it."""
+    from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
+    torch.cuda.synchronize(device)
+    torch.cuda.reset_peak_memory_stats(device)
+    trainer = DataParallelTrainer(MAX_DISPARITY, device)
+    left, right, truth = synthetic_example(HEIGHT, WIDTH, MAX_DISPARITY, 1, device)
+    losses = [trainer.step(left, right, truth)]                # warm-up: workspaces, weight re-layout
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(trainer.step(left, right, truth))
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    trainer.optimizer.zero_grad(set_to_none=True)              # forward / backward split of one more (untimed) step
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    cost = trainer.network(left, right)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    trainer.criterion(cost, truth).backward()
+    torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
+    values = [float(v) for v in losses]
+    record = {'workload': 'configs[4] on one GPU: 960x540 pair, D=192, batch 1, train-mode PdsNetwork forward + '
+                          'SubpixelCrossEntropy + backward through the HIP modules + RMSprop (lr 1e-2), random-init '
+                          'weights seed 0, ground truth with an unknown band',
+              'steps': steps, 'steps_per_s': steps / elapsed, 'ms_per_step': elapsed / steps * 1e3,
+              'forward_ms': (t1 - t0) * 1e3, 'loss_backward_ms': (t2 - t1) * 1e3,
+              'first_loss': values[0], 'last_loss': values[-1],
+              'peak_memory_gb': torch.cuda.max_memory_allocated(device) / 2 ** 30}
+    if cpu:
+        try:
+            record['cpu_baseline'] = train_cpu_baseline(trainer.network, left, right, truth, values[0])
+        except Exception as e:   # a baseline leg must never take the line down
+            record['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    del trainer, cost
+    torch.cuda.empty_cache()
+    return record
+
+
+def train_cpu_baseline(network, left, right, truth, gpu_first_loss):
+    """ONE full-size training step (forward + loss + backward) of the CPU oracle on min(32, usable) host threads."""
+    from oracle import pds_oracle as oracle
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(usable, 32)))
+    # the parameters as they were at the first step (seed 0): the comparison of the loss value below needs them
+    torch.manual_seed(0)
+    from practicaldeepstereo_nips2018_amd.network import PdsNetwork
+    fresh = PdsNetwork.default(MAX_DISPARITY)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in fresh.state_dict().items()}
+    t0 = time.perf_counter()
+    cost = oracle.network_training_output(params, left.cpu(), right.cpu(), MAX_DISPARITY)
+    loss = oracle.subpixel_cross_entropy(cost, truth.cpu())
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    return {'ms_per_step': (t2 - t0) * 1e3, 'forward_ms': (t1 - t0) * 1e3, 'loss_backward_ms': (t2 - t1) * 1e3,
+            'cores': torch.get_num_threads(), 'kind': 'port', 'loss': float(loss),
+            'loss_difference_to_gpu_first_step': abs(float(loss) - gpu_first_loss),
+            'sample': 'one step (no warm-up, no optimizer update) of the PyTorch-CPU oracle with autograd on the same pair'}
+
+
 def train_main(args, world, rank, device, collectives=None):
     """--train: the config-5 line (same timing contract: W warm-up steps, then exactly K steps between barriers and
     synchronisations, MAX over ranks; rank 0 prints one JSON line)."""
@@ -370,9 +485,10 @@ def train_main(args, world, rank, device, collectives=None):
     elapsed = time.perf_counter() - t0
     in_sync = True
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor(windows, device=device, dtype=torch.float64)   # MAX over ranks of every region, then the median
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        windows = [float(v) for v in t.tolist()]
+        elapsed = sorted(windows)[len(windows) // 2]
         in_sync = trainer.replicas_in_sync()
     # forward / backward split of one more (untimed) step on rank 0's pair
     torch.cuda.synchronize(device)
@@ -546,10 +662,12 @@ def main():
             torch.cuda.synchronize(device)
             barrier()
             return time.perf_counter() - t0, results
-        elapsed, mine = timed_window()           # THE timed region: exactly --steps steps
+        first_elapsed, mine = timed_window()     # a timed region: exactly --steps steps between barriers + synchronisations
         disparity = dict(mine).get(0)
-        # further windows of the same length, informational (median / spread of the throughput)
-        windows = [elapsed] + [timed_window()[0] for _ in range(args.windows - 1)]
+        # --windows regions of exactly --steps steps each; "value" is the MEDIAN region (one 20-step region is 50 ms: a
+        # single host stall moves it by percent), the first and the spread ride along in "windows"
+        windows = [first_elapsed] + [timed_window()[0] for _ in range(args.windows - 1)]
+        elapsed = sorted(windows)[len(windows) // 2]
 
     def reference_results():
         """unsharded, sequential hot path of every pair (the bit-exactness reference of the schedules)"""
@@ -572,9 +690,10 @@ def main():
         torch.cuda.synchronize(device)
         sharded_ok = all(torch.equal(m, expected[i]) for i, m in mine) and len(mine) == args.steps
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor(windows, device=device, dtype=torch.float64)   # MAX over ranks of every region, then the median
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        windows = [float(v) for v in t.tolist()]
+        elapsed = sorted(windows)[len(windows) // 2]
         # untimed check: every disparity map this rank produced in the timed region equals the unsharded hot path
         # on the same inputs bit for bit (same kernels, same planes)
         expected = reference_results()
@@ -748,8 +867,9 @@ def main():
                     if X3 else 'SURVEY.md 8d counts'}
         ordered = sorted(args.steps / w for w in windows)
         line['windows'] = {'count': len(windows), 'median': ordered[len(ordered) // 2], 'min': ordered[0],
-                           'max': ordered[-1], 'unit': 'pairs/s',
-                           'note': 'windows of --steps steps each over %d distinct pairs; "value" is the first' % PAIRS}
+                           'max': ordered[-1], 'first': args.steps / windows[0], 'unit': 'pairs/s',
+                           'note': 'timed regions of exactly --steps steps each over %d distinct pairs; "value" and '
+                                   '"ms_per_step" are the median region' % PAIRS}
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():
                 signatures_g = net._matching(ld_g, rd_g)
@@ -764,6 +884,11 @@ def main():
                 line['gpu_baseline'] = gpu_baseline(net, ld_g, rd_g, sc_g, device, disparity)
             except Exception as e:   # a baseline leg must never take the line down
                 line['gpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if world == 1 and not args.no_train_record:
+            try:
+                line['train'] = train_record(device, cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                line['train'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -55,6 +55,16 @@ class RegularizationParams(ctypes.Structure):
                 ('upsample_full', ConvBlockParams)]
 
 
+def planned_bytes(nbytes, what):
+    """Result of a ``pds_*_workspace_bytes`` planning walk of a training route: zero means the walk FAILED (unsupported
+    shape, arena overflow ...), never "no workspace needed" -- surface the library's message instead of running the real
+    walk into a 256-byte arena."""
+    nbytes = int(nbytes)
+    if nbytes <= 0:
+        raise RuntimeError('%s: planning failed: %s' % (what, load().pds_last_error().decode(errors='replace')))
+    return nbytes
+
+
 def sources():
     return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hip'))
 

@@ -546,7 +546,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     const Geom g{batch, F, d_count, h, w};
     const bool fused = [&]() {
         static const bool enabled = []() {  // PDS_MATCHING_FUSED=0 selects the unfused sequence (A/B, debugging)
-            const char* e = getenv("PDS_MATCHING_FUSED");
+            const char* e = debug_switch("PDS_MATCHING_FUSED");
             return !(e && e[0] == '0');
         }();
         return enabled && fused_matching_supported(P, batch, h, w, d_count);
@@ -556,7 +556,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     // PDS_MATCHING_COLUMNS=0 keeps the whole-plane form.
     const bool columns = [&]() {
         static const bool enabled = []() {
-            const char* e = getenv("PDS_MATCHING_COLUMNS");
+            const char* e = debug_switch("PDS_MATCHING_COLUMNS");
             return !(e && e[0] == '0');
         }();
         return enabled && fused && !train && P.residual_blocks >= 1 && F % 8 == 0;

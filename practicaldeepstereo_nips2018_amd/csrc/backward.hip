@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kPlaneThreads) void in_bwd_plane_kernel(const float
 
 static bool in_bwd_plane_supported(const float* g, const float* t, const float* dz, const Geom& geom, int per_plane) {
     static const bool enabled = []() {  // PDS_IN_BWD_PLANE=0 keeps the two-pass kernels (A/B, debugging)
-        const char* e = getenv("PDS_IN_BWD_PLANE");
+        const char* e = debug_switch("PDS_IN_BWD_PLANE");
         return !(e && e[0] == '0');
     }();
     const size_t px = geom.plane();
@@ -815,7 +815,7 @@ int launch_bwd_data(int transposed, int kd, int stride, const float* dz, const f
                     const Geom& out, hipStream_t s) {
     BwdGeom G{in.n, in.c, in.d, in.h, in.w, out.c, out.d, out.h, out.w};
     static const bool v2 = []() {   // PDS_BWD_DATA_V2=0 keeps the one-position-per-thread kernels (A/B, debugging)
-        const char* e = getenv("PDS_BWD_DATA_V2");
+        const char* e = debug_switch("PDS_BWD_DATA_V2");
         return !(e && e[0] == '0');
     }();
     if (v2 && ((transposed && (kd == 3 || kd == 4)) || (!transposed && kd == 3 && stride == 2)))

@@ -7,10 +7,22 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/pds_hip.h"
 
 namespace pds {
+
+// Kernel-selection switches (DESIGN.md "Switches": PDS_X3, PDS_WINOGRAD, PDS_CONV3D_KS, ...) exist for A/B measurements and
+// for tests/test_gpu_switches.py.  They are honoured only when PDS_DEBUG_SWITCHES=1 is set as well, so that a stray
+// variable in a production environment cannot move the library off its measured-best, parity-tested default paths.
+inline const char* debug_switch(const char* name) {
+    static const bool armed = []() {
+        const char* e = std::getenv("PDS_DEBUG_SWITCHES");
+        return e && e[0] == '1';
+    }();
+    return armed ? std::getenv(name) : nullptr;
+}
 
 constexpr float kLeakySlope = 0.1f;  // reference network_blocks.py:57,71,84
 constexpr double kInEps = 1e-5;      // torch InstanceNorm default eps

@@ -679,7 +679,7 @@ namespace {
 
 bool c2t8_enabled() {
     static const bool on = []() {  // PDS_CONV2D_T8=0: conv2d_mfma.hip serves the layer (A/B)
-        const char* e = getenv("PDS_CONV2D_T8");
+        const char* e = debug_switch("PDS_CONV2D_T8");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -704,7 +704,7 @@ int launch_c2t8(const C2Args& A, hipStream_t s) {
 // full-width form: both-source-a-normalised launches on rows that fit the LDS (PDS_CONV2D_T8W=0: tiles of 16 x 32)
 bool c2t8_wide(const ConvLayer& L) {
     static const bool on = []() {
-        const char* e = getenv("PDS_CONV2D_T8W");
+        const char* e = debug_switch("PDS_CONV2D_T8W");
         return !(e && e[0] == '0');
     }();
     if (!on) return false;

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
 // ---------------------------------------------------------------------------------------------
 bool conv2d_wino_eligible(const ConvLayer& L) {
     static const bool enabled = []() {  // PDS_WINOGRAD=0 selects the direct kernel (A/B, debugging)
-        const char* e = getenv("PDS_WINOGRAD");
+        const char* e = debug_switch("PDS_WINOGRAD");
         return !(e && e[0] == '0');
     }();
     if (!enabled) return false;

@@ -268,7 +268,7 @@ int conv2d_wino16_tiles(int h, int w) { return ((h + TH - 1) / TH) * ((w + TWX -
 // The square tiles win when they compute fewer pixels than the 4 x 64 ones (both are 256 pixels per workgroup).
 bool conv2d_wino16_preferred(int h, int w) {
     static const bool enabled = []() {  // PDS_WINO_TILE16=0 keeps the 4 x 64 tiles everywhere (A/B, debugging)
-        const char* e = getenv("PDS_WINO_TILE16");
+        const char* e = debug_switch("PDS_WINO_TILE16");
         return !(e && e[0] == '0');
     }();
     if (!enabled || w % 4 != 0 || w < 4) return false;

@@ -907,7 +907,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A0) 
 // ---------------------------------------------------------------------------------------------
 bool conv2d_x3_supported(const ConvLayer& L) {
     static const bool enabled = []() {  // PDS_X3=0 keeps the exact-fp32 MFMA kernels (A/B, debugging)
-        const char* e = getenv("PDS_X3");
+        const char* e = debug_switch("PDS_X3");
         return !(e && e[0] == '0');
     }();
     if (!enabled) return false;
@@ -932,7 +932,7 @@ size_t conv2d_x3_packed_floats(int cin) { return x3_weight_dwords(cin, 3) + 64; 
 // fp16 form (three products) when the source carries a range certificate (Src::bound), else the range-safe bf16 form
 static bool x3_use_fp16(const ConvLayer& L) {
     static const bool enabled = []() {  // PDS_X3_FP16=0: every launch on the range-safe bf16 form (A/B, debugging)
-        const char* e = getenv("PDS_X3_FP16");
+        const char* e = debug_switch("PDS_X3_FP16");
         return !(e && e[0] == '0');
     }();
     return enabled && L.a.bounded;
@@ -971,7 +971,7 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
         j.mblocks = 2;
         j.kc = 4;
         j.taps = 9;
-        // 6: three-way bf16 split, 7: two-way fp16 split of 2^10 w; A-fragment order of v_mfma_f32_32x32x16_{bf16,f16}
+        // 6: three-way bf16 split, 7: two-way fp16 split of ws * w (ws: the power of two pack_wscale_kernel derives from max|w|); A-fragment order of v_mfma_f32_32x32x16_{bf16,f16}
         j.mode = fp16 ? 7 : 6;
         j.total = total + 16;   // + the queue counters (zeroed by the packing launch)
         if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");

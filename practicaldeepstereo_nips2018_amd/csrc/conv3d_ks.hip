@@ -289,7 +289,7 @@ namespace {
 
 bool ks_enabled() {
     static const bool on = []() {  // PDS_CONV3D_KS=0: conv3d_mfma.hip serves these layers (A/B)
-        const char* e = getenv("PDS_CONV3D_KS");
+        const char* e = debug_switch("PDS_CONV3D_KS");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -376,7 +376,7 @@ bool conv3d_ks_supported(const ConvLayer& L) {
     if (L.kd != 3 || L.stat_per_plane) return false;
     if ((L.a.scale && L.a.per_plane) || (L.b.scale && L.b.per_plane)) return false;
     static const size_t volume_limit = []() {   // PDS_CONV3D_KS_LIMIT: largest output volume served (experiments)
-        const char* e = getenv("PDS_CONV3D_KS_LIMIT");
+        const char* e = debug_switch("PDS_CONV3D_KS_LIMIT");
         return e ? (size_t)atol(e) : (size_t)30000;
     }();
     // the large 16-channel levels keep the tile-per-workgroup kernel: plenty of tiles there, and K is short

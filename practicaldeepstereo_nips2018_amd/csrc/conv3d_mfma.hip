@@ -361,7 +361,7 @@ int launch3(const Args3& A0, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
     static const bool xcd_map = []() {  // PDS_CONV3D_XCD_MAP=0: launch order = tile order (A/B)
-        const char* e = getenv("PDS_CONV3D_XCD_MAP");
+        const char* e = debug_switch("PDS_CONV3D_XCD_MAP");
         return !(e && e[0] == '0');
     }();
     A.xcd_run = (xcd_map && A.tiles >= 64) ? (A.tiles + 7) / 8 : 0;

@@ -365,7 +365,7 @@ int t8_choose_nb(int w) {
 
 bool t8_enabled() {
     static const bool on = []() {  // PDS_CONV3D_T8=0: the generic MFMA kernel serves these layers (A/B)
-        const char* e = getenv("PDS_CONV3D_T8");
+        const char* e = debug_switch("PDS_CONV3D_T8");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -421,7 +421,7 @@ int launch_conv3d_t8(const ConvLayer& L, hipStream_t s) {
     // layer (the caller's matching signatures): 112 against 85 us -- PDS_CONV3D_T8X=2 forces it for tests.
     const bool certified = L.a.bound && L.a.bound_n > 0 && (!L.b.p || (L.b.bound && L.b.bound_n > 0));
     static const bool force_x = []() {
-        const char* e = getenv("PDS_CONV3D_T8X");
+        const char* e = debug_switch("PDS_CONV3D_T8X");
         return e && e[0] == '2';
     }();
     if (conv3d_t8x_enabled() && (certified || (force_x && !L.b.p)))

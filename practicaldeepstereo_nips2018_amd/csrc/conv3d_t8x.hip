@@ -391,7 +391,7 @@ int launch_t8x(const TXArgs& A, int batch, hipStream_t s) {
 
 bool conv3d_t8x_enabled() {
     static const bool on = []() {  // PDS_CONV3D_T8X=0: the exact-fp32 kernel of conv3d_t8.hip serves these layers (A/B)
-        const char* e = getenv("PDS_CONV3D_T8X");
+        const char* e = debug_switch("PDS_CONV3D_T8X");
         return !(e && e[0] == '0');
     }();
     return on;

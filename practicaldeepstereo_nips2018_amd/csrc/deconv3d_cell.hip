@@ -441,7 +441,7 @@ namespace {
 
 bool cell_enabled() {
     static const bool on = []() {  // PDS_DECONV_CELL=0: the generic MFMA kernel serves these layers (A/B)
-        const char* e = getenv("PDS_DECONV_CELL");
+        const char* e = debug_switch("PDS_DECONV_CELL");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -521,7 +521,7 @@ int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s) {
     A.records = deconv3d_cell_records(L.in, L.out_g.c);
     const bool norm = L.a.scale != nullptr;
     static const bool split_on = []() {  // PDS_DECONV_CELL_X=0: exact-fp32 MFMAs also for certified sources (A/B)
-        const char* e = getenv("PDS_DECONV_CELL_X");
+        const char* e = debug_switch("PDS_DECONV_CELL_X");
         return !(e && e[0] == '0');
     }();
     // fp16-split form when the source carries a range certificate (inside the hourglass: always)

@@ -147,7 +147,7 @@ static void launch_t(const float* sim, float* disp, int batch, int planes, size_
     // the memory pipes is the number of waves: two pixels per lane (8-byte loads, twice the waves) measured fastest
     // (PDS_SUBPIXEL_VEC=1|2|4 selects another width for A/B)
     static const int vec_pref = []() {
-        const char* e = getenv("PDS_SUBPIXEL_VEC");
+        const char* e = debug_switch("PDS_SUBPIXEL_VEC");
         return e ? atoi(e) : 2;
     }();
     if (px % 4 == 0 && vec_pref == 4) {

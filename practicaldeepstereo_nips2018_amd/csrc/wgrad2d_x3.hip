@@ -325,7 +325,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad2d_x3_kernel(const WX3Args A)
 
 bool wgrad2d_x3_supported(const Src& a, const Src& b, const Src& dz, const Geom& in, const Geom& out) {
     static const bool enabled = []() {  // PDS_WGRAD2D_X3=0 keeps the exact-fp32 kernel (A/B, debugging)
-        const char* e = getenv("PDS_WGRAD2D_X3");
+        const char* e = debug_switch("PDS_WGRAD2D_X3");
         return !(e && e[0] == '0');
     }();
     if (!enabled || !(out.c == 64 || out.c <= 16) || in.c % CG != 0 || (in.w & 3) != 0) return false;

@@ -239,7 +239,7 @@ int launch_wgrad_reduce_f32(const float* partial, size_t wcount, int parts, floa
 
 bool wgrad3d_mfma_supported(int transposed, int kd, int stride, const Geom& in, const Geom& out) {
     static const bool enabled = []() {  // PDS_WGRAD3D_MFMA=0 selects the direct kernel (A/B, debugging)
-        const char* e = getenv("PDS_WGRAD3D_MFMA");
+        const char* e = debug_switch("PDS_WGRAD3D_MFMA");
         return !(e && e[0] == '0');
     }();
     if (!enabled || transposed || kd != 3 || stride != 1) return false;

@@ -455,7 +455,7 @@ static int up_full_workgroups(const Geom& in) {
 
 bool wgrad_up_full_mfma_supported(int transposed, int kd, const Src& b, const Geom& in, const Geom& out) {
     static const bool enabled = []() {
-        const char* e = getenv("PDS_WGRAD3D_S2_MFMA");
+        const char* e = debug_switch("PDS_WGRAD3D_S2_MFMA");
         return !(e && e[0] == '0');
     }();
     return enabled && transposed && kd == 3 && !b.p && in.c <= 4 && out.c == 1 && out.d == in.d && out.h == 2 * in.h &&
@@ -468,7 +468,7 @@ size_t wgrad_up_full_mfma_scratch_floats(const Geom& in) { return (size_t)up_ful
 // type: 0 convolution (kd 3, stride 2), 1 transposed convolution (kd 4: k4 s2 p1 on all three axes)
 bool wgrad3d_s2_mfma_supported(int transposed, int kd, int stride, const Geom& in, const Geom& out) {
     static const bool enabled = []() {  // PDS_WGRAD3D_S2_MFMA=0 selects the VALU kernels (A/B, debugging)
-        const char* e = getenv("PDS_WGRAD3D_S2_MFMA");
+        const char* e = debug_switch("PDS_WGRAD3D_S2_MFMA");
         return !(e && e[0] == '0');
     }();
     if (!enabled) return false;

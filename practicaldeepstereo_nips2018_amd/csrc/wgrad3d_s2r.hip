@@ -308,7 +308,7 @@ bool wgrad3d_s2_rolling_supported(int transposed, const Src& b, const Geom& smal
     // PDS_WGRAD3D_S2_ROLLING=0 keeps the one-row-per-item kernel (A/B, debugging); =2 takes this one for every layer of
     // the right shape, however small (tests)
     static const int mode = []() {
-        const char* e = getenv("PDS_WGRAD3D_S2_ROLLING");
+        const char* e = debug_switch("PDS_WGRAD3D_S2_ROLLING");
         return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1;
     }();
     if (!mode || !(big.c == 4 || big.c == 8) || small.c > 16) return false;

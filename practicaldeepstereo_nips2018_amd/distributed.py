@@ -33,8 +33,9 @@ def shard_range(number_of_planes, rank, world_size):
 #   'separate'   the same collectives one by one (every backend: gloo in the CPU tests)
 #   'single'     ONE all_gather_into_tensor into a rank-major staging buffer + a permuting copy (round 2's form: the
 #                most conservative use of the library)
-_GATHER_MODE = None
+_GATHER_MODE = None     # the form chosen last (what the bench line reports)
 _GATHER_NOTE = 'not decided yet (no gather has run)'
+_GATHER_MODES = {}      # (process group, device type) -> form: a CPU / gloo pre-flight must not decide for an RCCL group
 
 
 def _device_backend(group, device):
@@ -58,10 +59,14 @@ def _views(out, local_planes):
 
 
 def _gather_coalesced(out, local_planes, group):
-    from torch.distributed.distributed_c10d import _coalescing_manager
-    with _coalescing_manager(group=group, device=local_planes.device, async_ops=False):
-        for whole, mine in _views(out, local_planes):
-            dist.all_gather_into_tensor(whole, mine, group=group)
+    # ProcessGroup.allgather_into_tensor_coalesced is what torch's (private) _coalescing_manager itself ends in for
+    # all_gather_into_tensor; calling it directly leaves no half-open coalescing state behind when it raises
+    # (the context manager has no try / finally, a failure inside it poisoned every later collective)
+    pg = group if group is not None else dist.group.WORLD
+    views = _views(out, local_planes)
+    work = pg.allgather_into_tensor_coalesced([whole for whole, _ in views], [mine for _, mine in views])
+    if work is not None:
+        work.wait()
 
 
 def _gather_separate(out, local_planes, group):
@@ -94,7 +99,7 @@ def _choose_gather_mode(device, group):
     global _GATHER_MODE, _GATHER_NOTE
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = _device_backend(group, device)
-    order = ['coalesced', 'separate', 'single'] if backend == 'nccl' else ['separate', 'single']
+    order = ['coalesced', 'separate', 'single']
     batch, channels, d_local, h, w = 2, 3, 2, 3, 5
     def shard(r):
         base = torch.arange(batch * channels * d_local * h * w, dtype=torch.float32).view(batch, channels, d_local, h, w)
@@ -118,6 +123,7 @@ def _choose_gather_mode(device, group):
         if agreed:
             _GATHER_MODE = mode
             _GATHER_NOTE = 'backend %s; %s' % (backend, ', '.join(tried))
+            _GATHER_MODES[(group, torch.device(device).type)] = mode
             return mode
     raise RuntimeError('no form of the all-gather works on this process group: %s' % ', '.join(tried))
 
@@ -165,7 +171,7 @@ def _gather_planes_raw(local_planes, group):
     world_size = dist.get_world_size(group)
     batch, channels, d_local, h, w = local_planes.shape
     out = local_planes.new_empty((batch, channels, world_size * d_local, h, w))
-    mode = _GATHER_MODE or _choose_gather_mode(local_planes.device, group)
+    mode = _GATHER_MODES.get((group, local_planes.device.type)) or _choose_gather_mode(local_planes.device, group)
     _GATHER_FORMS[mode](out, local_planes, group)
     return out
 
@@ -298,6 +304,10 @@ class ShardedMatching(nn.Module):
     def forward(self, left_embedding, right_embedding):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self._group) == 1:
             return self._matching(left_embedding, right_embedding)
+        return gather_planes(self.local_planes(left_embedding, right_embedding), self._group)
+
+    def local_planes(self, left_embedding, right_embedding):
+        """This rank's slice [batch, C, D' / N, h, w] of the signatures -- the input of the all-gather."""
         planes = self._matching._maximum_disparity + 1
         shard = shard_range(planes, dist.get_rank(self._group), dist.get_world_size(self._group))
         if torch.is_grad_enabled():
@@ -309,10 +319,9 @@ class ShardedMatching(nn.Module):
                 self._hook_parameter_gradients()
         self._matching.set_disparity_shard(shard)
         try:
-            local = self._matching(left_embedding, right_embedding)
+            return self._matching(left_embedding, right_embedding)
         finally:
             self._matching.set_disparity_shard(None)
-        return gather_planes(local, self._group)
 
 
 class ShardedHotPath(object):
@@ -341,13 +350,42 @@ class ShardedHotPath(object):
         self._pending = []   # completion events of this rank's unfinished tails (GPU only)
         # streams > 1: whole pairs (this rank's planes, the all-gather and, on the owner, the tail) are dealt
         # round-robin to that many HIP streams (PairStreams below): the small per-rank shards of one pair leave the
-        # GPU under-used, the next pair fills it.  Collectives stay in program order on every rank (they are issued
-        # by one host thread and funnel through the process group's communication stream).
+        # GPU under-used, the next pair fills it.  The collectives do NOT ride on those streams: every all-gather of
+        # this object is enqueued on ONE dedicated stream, by the one host thread, in submission order -- the same
+        # order on every rank by construction, whatever the process group does internally -- and events tie it to
+        # the lane that produced its input and consumes its result (`_ordered_gather`).
         self._lanes = PairStreams(self._whole_pair, streams=streams) if streams > 1 else None
+        self._gather_stream = None
+        self.gathers_issued = 0      # (diagnostics / tests: collectives issued so far, identical on every rank)
+
+    def _ordered_gather(self, local_planes):
+        """all-gather of this rank's planes on the dedicated collective stream:
+        lane --(event: planes produced)--> gather stream: all-gather --(event: gathered)--> lane."""
+        self.gathers_issued += 1
+        if not local_planes.is_cuda:
+            return _gather_planes_raw(local_planes, self._group)
+        device = local_planes.device
+        lane = torch.cuda.current_stream(device)
+        if self._gather_stream is None:
+            self._gather_stream = torch.cuda.Stream(device)
+        produced = torch.cuda.Event()
+        produced.record(lane)
+        self._gather_stream.wait_event(produced)
+        with torch.cuda.stream(self._gather_stream):
+            gathered = _gather_planes_raw(local_planes, self._group)
+            done = torch.cuda.Event()
+            done.record(self._gather_stream)
+        local_planes.record_stream(self._gather_stream)   # allocated on the lane, read on the gather stream
+        gathered.record_stream(lane)                      # allocated on the gather stream, read on the lane
+        lane.wait_event(done)
+        return gathered
 
     def _whole_pair(self, index, left_embedding, right_embedding, shortcut_from_left):
         rank, world = self._world()
-        signatures = self._sharded(left_embedding, right_embedding)
+        if world == 1:
+            signatures = self._sharded(left_embedding, right_embedding)
+        else:
+            signatures = self._ordered_gather(self._sharded.local_planes(left_embedding, right_embedding))
         return self._tail(signatures, shortcut_from_left) if index % world == rank else None
 
     def _world(self):

@@ -7,9 +7,14 @@ signature, output layout ``[batch, features, disparity, y, x]`` and state-dict k
 
 * ``Matching`` with a ``MatchingOperation`` takes the fused path ``pds_matching_fwd``: the linear
   first convolution is factorised into conv_L(left) + shift_d(conv_R(right)) so the right
-  descriptor is convolved once for all disparities, the 64->64 convolutions run as exact-fp32 MFMA
-  implicit GEMMs over all disparity planes at once with LeakyReLU and the per-plane InstanceNorm
-  statistics fused, and the last convolution writes straight into the stacked layout.
+  descriptor is convolved once for all disparities; the 64->64 convolutions run as implicit GEMMs
+  over all disparity planes at once on the 16-bit matrix pipe -- every fp32 operand is split into
+  an fp16 high and low part (22 of 24 significand bits, scaled by exact powers of two taken from
+  range certificates of the data), three partial products per multiply, fp32 accumulation
+  (csrc/conv2d_x3.hip; NOT exact-fp32 products: measured 2-5e-7 of the output scale per layer
+  against fp64, the fp32 CPU reference itself is 3e-7) -- with LeakyReLU and the per-plane
+  InstanceNorm statistics fused, and the last convolution writes straight into the stacked layout.
+  Tensors without a certificate take a three-way bf16 split (six products) or exact-fp32 MFMAs.
 * ``Matching`` with any other callable builds cat([left, S_d(right)]) for all disparities with one
   HIP kernel (``pds_shift_concat_fwd``) and applies the callable per plane, like the reference.
 """
@@ -60,6 +65,12 @@ class MatchingOperation(nn.Module):
         """The factorised first layer needs the descriptor width to equal the feature width
         (128 -> 64 in the reference: two 64-channel descriptors)."""
         return self.number_of_descriptor_features == self.number_of_features
+
+    def supports_native_training(self):
+        """pds_matching_train_fwd / pds_matching_bwd differentiate the factorised first layer with the matrix-pipe weight
+        gradient kernels, which take 64 or at most 16 output channels (csrc/wgrad2d_mfma.hip: wgrad2d_mfma_supported);
+        other widths train through the generic shift / concat route, whose operation has a backward for any width."""
+        return self.supports_fused_matching() and (self.number_of_features == 64 or self.number_of_features <= 16)
 
     def native_params(self, tensor_of=None):
         """(PdsMatchingParams, keep-alive list) pointing at this module's parameters, or, with
@@ -216,9 +227,10 @@ class Matching(_lib.FrozenWeightsMixin, nn.Module):
                 return _FusedMatchingFunction.apply(self, left, right, begin, count,
                                                     *operation.parameters())
             _lib.warn_eval_with_grad(self)
-            # Training: the differentiable route keeps the factorised first layer (no [D', B, 128, h, w] concat) and
-            # every layer output for the backward pass (pds_matching_train_fwd / pds_matching_bwd).
-            return _TrainMatchingFunction.apply(self, left, right, begin, count, *operation.parameters())
+            if operation.supports_native_training():
+                # Training: the differentiable route keeps the factorised first layer (no [D', B, 128, h, w] concat) and
+                # every layer output for the backward pass (pds_matching_train_fwd / pds_matching_bwd).
+                return _TrainMatchingFunction.apply(self, left, right, begin, count, *operation.parameters())
         return self._forward_generic(left, right, begin, count)
 
     def _forward_generic(self, left, right, begin, count):
@@ -241,8 +253,9 @@ class _TrainMatchingFunction(torch.autograd.Function):
         params, keep = operation.native_params()
         out = torch.empty((batch, operation.number_of_signature_features, count, h, w),
                           dtype=torch.float32, device=left.device)
-        nbytes = lib.pds_matching_train_workspace_bytes(ctypes.byref(params), batch, h, w, count)
-        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=left.device)
+        nbytes = _lib.planned_bytes(lib.pds_matching_train_workspace_bytes(ctypes.byref(params), batch, h, w, count),
+                                    'pds_matching_train_workspace_bytes')
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=left.device)
         with torch.cuda.device(left.device):
             _lib.check(lib.pds_matching_train_fwd(
                 ctypes.byref(params), _lib.ptr(left), _lib.ptr(right), _lib.ptr(out), batch, h, w, begin, count,
@@ -266,8 +279,9 @@ class _TrainMatchingFunction(torch.autograd.Function):
         grads, tensor_of = _lib.gradient_buffers(operation)
         grad_params, keep_grads = operation.native_params(tensor_of)
         grad_left, grad_right = torch.empty_like(left), torch.empty_like(right)
-        nbytes = lib.pds_matching_bwd_workspace_bytes(ctypes.byref(params), batch, h, w, count)
-        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=left.device)
+        nbytes = _lib.planned_bytes(lib.pds_matching_bwd_workspace_bytes(ctypes.byref(params), batch, h, w, count),
+                                    'pds_matching_bwd_workspace_bytes')
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=left.device)
         fws = _lib.saved_workspace(ctx, 'matching')
         with torch.cuda.device(left.device):
             _lib.check(lib.pds_matching_bwd(

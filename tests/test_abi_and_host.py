@@ -1,6 +1,7 @@
 """CPU: the C-ABI library builds for gfx950, loads, and exports every symbol the header declares;
 host-side mirrors keep the reference's API surface (names, arguments, errors, state-dict keys)."""
 import ctypes
+import os
 import re
 
 import pytest
@@ -70,7 +71,11 @@ def test_network_maximum_disparity_rule():
 def test_state_dict_keys_match_reference_layout():
     net = helpers.seeded(lambda: pds.PdsNetwork.default(191))
     keys = list(net.state_dict().keys())
-    assert len(keys) == 122 + 0 or len(keys) > 100
+    # exactly the reference's 122 tensors, in its order: the list is pinned by the reference's own training step (G11)
+    assert len(keys) == 122
+    import numpy as np
+    with np.load(os.path.join(helpers.GOLDEN, 'g11_training_step.npz')) as z:
+        assert keys == [str(k) for k in z['parameter_names']]
     for k in ['_matching._operation._matching_operation_modules.0.weight',
               '_matching._operation._matching_operation_modules.1.convolutions.0.0.weight',
               '_matching._operation._matching_operation_modules.2.convolutions.1.2.bias',

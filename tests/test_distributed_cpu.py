@@ -248,15 +248,28 @@ def preflight_worker(rank, world, port, results):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         info = pdist.preflight_collectives(device='cpu')
-        ok = info['gather_mode'] in ('separate', 'single') and info['backend'] == 'gloo' and info['all_reduce'] == 'ok'
-        ok = ok and info['gather_mode'] in pdist.gather_description()
+        ok = info['gather_mode'] in ('coalesced', 'separate', 'single') and info['backend'] == 'gloo'
+        ok = ok and info['all_reduce'] == 'ok' and info['gather_mode'] in pdist.gather_description()
         g = torch.Generator().manual_seed(21)
         full = torch.randn(2, 8, 4 * world, 3, 5, generator=g)
         mine = full[:, :, 4 * rank:4 * rank + 4].contiguous()
-        for mode in ('separate', 'single'):
+        forms = ['separate', 'single'] + (['coalesced'] if info['gather_mode'] == 'coalesced' else [])
+        for mode in forms:   # (the coalesced form where this backend offers it: it is the public ProcessGroup method)
             out = torch.full_like(full, float('nan'))
             pdist._GATHER_FORMS[mode](out, mine, None)
             ok = ok and torch.equal(out, full)
+        # a failing 'coalesced' form must leave the process group usable: the chain moves on and later collectives work
+        real_coalesced = pdist._GATHER_FORMS['coalesced']
+        def broken_coalesced(out, local, group):
+            raise RuntimeError('injected failure in the coalesced form')
+        pdist._GATHER_FORMS['coalesced'] = broken_coalesced
+        try:
+            pdist._GATHER_MODES.clear()
+            mode = pdist._choose_gather_mode(torch.device('cpu'), None)
+        finally:
+            pdist._GATHER_FORMS['coalesced'] = real_coalesced
+        ok = ok and mode == 'separate' and 'coalesced failed' in pdist.gather_description()
+        ok = ok and torch.equal(pdist.gather_planes(mine), full)
         # (i) a form that raises on EVERY rank (an API error -- RCCL reports misuse as RuntimeError -- is the same
         # everywhere) and (ii) a form that completes but leaves a wrong result on ONE rank: all ranks must move on to
         # the next form together
@@ -269,11 +282,13 @@ def preflight_worker(rank, world, port, results):
                 if rank == 1:
                     out.view(-1)[3] += 1.0
             pdist._GATHER_FORMS['separate'] = broken
+            pdist._GATHER_FORMS['coalesced'] = broken
             try:
-                pdist._GATHER_MODE = None
+                pdist._GATHER_MODES.clear()
                 mode = pdist._choose_gather_mode(torch.device('cpu'), None)
             finally:
                 pdist._GATHER_FORMS['separate'] = real
+                pdist._GATHER_FORMS['coalesced'] = real_coalesced
             ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
         ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
         ok = ok and torch.equal(pdist.gather_planes(mine), full)

@@ -89,23 +89,39 @@ def test_matching_operation_backward(dev, n, h, w):
     print('matching operation worst parameter-gradient error', check_param_grads(op, '_m', gp))
 
 
-def test_matching_training_route_backward(dev):
-    """Matching(MatchingOperation) with gradients: shift/concat -> folded MatchingOperation (matching.py:34-63)."""
-    op = helpers.seeded(pds.MatchingOperation, seed=5).to(dev)
+@pytest.mark.parametrize('features,width,shard,blocks', [
+    (64, 12, None, 2),        # the default operation: native route (pds_matching_train_fwd / pds_matching_bwd)
+    (64, 13, (2, 4), 1),      # a disparity shard (d_begin > 0: partial sums in l0_combine_bwd) on an odd width
+    (64, 12, (5, 3), 0),      # no residual block between the two bare convolutions
+    (16, 9, None, 1),         # narrow features: still the native route
+    (32, 12, None, 2),        # a width the native backward does not take: shift / concat route
+    (48, 10, (1, 5), 1),
+])
+def test_matching_training_route_backward(dev, features, width, shard, blocks):
+    """Matching(MatchingOperation) with gradients (matching.py:34-63 under pds_trainer.py:40-46): the native route keeps
+    the factorised first layer and differentiates through it; widths it does not take fall back to shift / concat + the
+    operation's own backward.  Shards: the gradient of a shard's planes only."""
+    op = helpers.seeded(lambda: pds.MatchingOperation(2 * features, features, 8, blocks), seed=5).to(dev)
     net = pds.Matching(7, op)
+    assert op.supports_native_training() == (features in (64, 16))
+    net.set_disparity_shard(shard)
+    begin, count = shard if shard else (0, 8)
     g = torch.Generator().manual_seed(6)
-    left = torch.randn(2, 64, 8, 12, generator=g).to(dev).requires_grad_(True)
-    right = torch.randn(2, 64, 8, 12, generator=g).to(dev).requires_grad_(True)
-    weight = torch.randn(2, 8, 8, 8, 12, generator=g)
+    left = torch.randn(2, features, 8, width, generator=g).to(dev).requires_grad_(True)
+    right = torch.randn(2, features, 8, width, generator=g).to(dev).requires_grad_(True)
+    weight = torch.randn(2, 8, count, 8, width, generator=g)
     out = net(left, right)
-    assert out.shape == (2, 8, 8, 8, 12)
+    assert out.shape == (2, 8, count, 8, width)
     with torch.no_grad():
         fused = net(left, right)          # inference route (factorised first layer, MFMA)
     assert helpers.maxdiff(out, fused) <= 2e-5
     (out * weight.to(dev)).sum().backward()
     params = helpers.prefixed(op.state_dict(), '_m._operation')
-    ref, (gl, gr), gp = oracle_grads(lambda p, a, b: oracle.matching_with_operation(p, '_m', a, b, 7),
-                                     [left, right], params, weight)
+
+    def reference(p, a, b):
+        full = oracle.matching(a, b, 7, lambda x: oracle.matching_operation(p, '_m._operation', x, blocks))
+        return full[:, :, begin:begin + count]
+    ref, (gl, gr), gp = oracle_grads(reference, [left, right], params, weight)
     assert relative_error(out, ref) <= 1e-4
     assert relative_error(left.grad, gl) <= REL_TOL
     assert relative_error(right.grad, gr) <= REL_TOL

@@ -381,10 +381,17 @@ def test_config2_fp64_arbiter(dev):
     _, _, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     cpu = helpers.disparity_report(disp32, disp64)
     gpu = helpers.disparity_report(disparity, disp64)
-    print('config2 arbiter: cpu fp32 vs fp64', cpu, ' gpu vs fp64', gpu)
+    n = disparity.numel()
+    cpu_flips, gpu_flips = round(cpu['flips'] * n), round(gpu['flips'] * n)
+    print('config2 arbiter: cpu fp32 vs fp64', cpu, ' gpu vs fp64', gpu, ' flips cpu %d gpu %d' % (cpu_flips, gpu_flips))
+    # Gates.  An arg-max flip moves one pixel by ~100 px = 1.8e-4 of MAE at this size, so MAE is a
+    # flip counter in disguise: the GPU may flip at most two pixels more than the reference's own fp32 run does against
+    # fp64, its smooth error (non-flipped pixels) must be within 1e-4 px and no worse than 2x the reference's smooth error
+    # + 1e-5, and the raw MAE stays under north_star's 1e-3.
+    assert gpu_flips <= cpu_flips + 2, (gpu, cpu)
+    assert gpu['mae_noflip'] <= 1e-4, gpu
+    assert gpu['mae_noflip'] <= 2.0 * cpu['mae_noflip'] + 1e-5, (gpu, cpu)
     assert gpu['mae'] <= TOL_DISPARITY_MAE, gpu
-    assert gpu['mae'] <= 2.0 * cpu['mae'] + 3e-4, (gpu, cpu)
-    assert gpu['mae_noflip'] <= 1e-4
 
 
 def test_config4_kitti_shape_batch(dev):

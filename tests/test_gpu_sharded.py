@@ -51,13 +51,27 @@ def worker(rank, world, port, results):
                 if out is not None:
                     ok = ok and torch.equal(out, tail(net._matching(left, right), shortcut))
             # the same stream of pairs dealt to two HIP streams per rank (bench.py's N > 1 default)
+            # ... with the ranks deliberately skewed (rank 1 submits late, in bursts): every all-gather is issued on the
+            # object's ONE collective stream in submission order, so the skew can delay a pair but never mis-pair two
+            # collectives; twelve pairs, i.e. six rounds over both lanes
+            import time
             lanes = ShardedHotPath(net._matching, tail, streams=2)
-            dealt = [lanes.submit(left, right, shortcut) for _, left, right, shortcut in outputs]
+            dealt = []
+            for i in range(12):
+                if rank == 1 and i % 3 == 0:
+                    time.sleep(0.05)
+                if rank == 0 and i % 4 == 3:
+                    time.sleep(0.02)
+                _, left, right, shortcut = outputs[i % 4]
+                dealt.append(lanes.submit(left, right, shortcut))
             lanes.drain()
-            for i, (got, (want, _, _, _)) in enumerate(zip(dealt, outputs)):
+            ok = ok and lanes.gathers_issued == 12
+            for i, got in enumerate(dealt):
+                want = outputs[i % 4][0]
                 ok = ok and ((got is not None) == (i % world == rank))
                 if got is not None:
-                    ok = ok and torch.equal(got, want)
+                    reference = want if want is not None else tail(net._matching(*outputs[i % 4][1:3]), outputs[i % 4][3])
+                    ok = ok and torch.equal(got, reference)
             # the plain sharded module (all-gather on every rank) as well
             _, left, right, _ = outputs[0]
             ok = ok and torch.equal(ShardedMatching(net._matching)(left, right), net._matching(left, right))

@@ -25,6 +25,9 @@ SWITCHES = [
     {'PDS_DECONV_CELL_X': '0'},     # exact-fp32 MFMAs in the dense-cell transposed convolutions
     {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
     {'PDS_CONV2D_T8W': '0'},        # ... its 16 x 32-tile form instead of the full-width one
+    {'PDS_CONV3D_KS_LIMIT': '1000'},   # the K-split kernel only for the two deepest levels of the hourglass
+    {'PDS_SUBPIXEL_VEC': '1'},      # pixels per lane of the stand-alone SubpixelMap kernel
+    {'PDS_SUBPIXEL_VEC': '4'},
 ]
 
 
@@ -32,8 +35,10 @@ SWITCHES = [
 def test_alternative_paths(hip_library, switch):
     env = dict(os.environ)
     env.update(switch)
+    env['PDS_DEBUG_SWITCHES'] = '1'   # the library ignores kernel-selection variables without it (csrc/common.hpp)
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
            'tests/test_gpu_conv_block.py',
+           'tests/test_gpu_parity.py::test_subpixel_map_random_vs_oracle',
            'tests/test_gpu_parity.py::test_fused_matching_shapes_vs_oracle',
            'tests/test_gpu_parity.py::test_fused_matching_golden',
            'tests/test_gpu_parity.py::test_config1_hot_path_vs_golden',
@@ -58,6 +63,7 @@ BACKWARD_SWITCHES = [
 def test_alternative_backward_paths(hip_library, switch):
     env = dict(os.environ)
     env.update(switch)
+    env['PDS_DEBUG_SWITCHES'] = '1'
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
            'tests/test_gpu_backward.py::test_matching_operation_backward',
            'tests/test_gpu_backward.py::test_matching_training_route_backward',
@@ -67,3 +73,31 @@ def test_alternative_backward_paths(hip_library, switch):
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = out.stdout.decode(errors='replace')[-2000:]
     assert out.returncode == 0, tail
+
+
+def test_switches_are_ignored_without_the_debug_gate(hip_library):
+    """A stray kernel-selection variable must not move a production process off the default paths: without
+    PDS_DEBUG_SWITCHES=1 the library does not read them.  PDS_X3=0 would send the 64-channel layers to the exact-fp32
+    Winograd kernel, which the launch probe would show; here the probe must still see conv2d_x3 launches."""
+    code = (
+        "import ctypes, torch, practicaldeepstereo_nips2018_amd as pds\n"
+        "from practicaldeepstereo_nips2018_amd import _lib\n"
+        "lib = _lib.load(); dev = torch.device('cuda:0'); torch.manual_seed(0)\n"
+        "m = pds.Matching(7, pds.MatchingOperation()).to(dev).eval()\n"
+        "l, r = torch.randn(1, 64, 32, 64, device=dev), torch.randn(1, 64, 32, 64, device=dev)\n"
+        "_lib.check(lib.pds_probe_begin(b'conv2d_x3', 64), 'pds_probe_begin')\n"
+        "with torch.no_grad(): m(l, r)\n"
+        "torch.cuda.synchronize()\n"
+        "print('PROBE', lib.pds_probe_end(None, None, 64))\n")
+    for gate, expect_x3 in ((None, True), ('1', False)):
+        env = dict(os.environ)
+        env['PDS_X3'] = '0'
+        env.pop('PDS_DEBUG_SWITCHES', None)
+        if gate:
+            env['PDS_DEBUG_SWITCHES'] = gate
+        out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=600)
+        text = out.stdout.decode(errors='replace')
+        assert out.returncode == 0, text[-2000:]
+        launches = int([t for t in text.splitlines() if t.startswith('PROBE')][-1].split()[1])
+        assert (launches > 0) == expect_x3, (gate, launches)
