@@ -68,6 +68,7 @@ int conv2d_wino_tiles(const Geom& out_g);
 size_t conv2d_wino_packed_floats(int cin, int cout);
 int launch_conv2d_x3(const ConvLayer& L, hipStream_t s);          // conv2d_x3.hip (Cin -> 64, fp32 on the bf16 pipe)
 bool conv2d_x3_supported(const ConvLayer& L);
+bool conv2d_x3_cb8_ok(const ConvLayer& L, bool in_cb8, bool out_cb8);   // channel-blocked input / output (Src::cb8)
 int conv2d_x3_tiles(const ConvLayer& L);   // statistics records per plane (depends on the form chosen)
 size_t conv2d_x3_packed_floats(int cin);
 int launch_conv2d_t8(const ConvLayer& L, hipStream_t s);          // conv2d_t8.hip (64 -> 8 channels, bare)
@@ -225,8 +226,10 @@ struct DT {
     float* bound = nullptr;
     int bound_n = 0;
     bool bounded = false;
+    bool cb8 = false;      // stored channel-blocked ([N][D][C / 8][H][W][8], common.hpp Src::cb8)
     Src src() const {
         Src s{raw, scale, shift, per_plane, 0};
+        s.cb8 = cb8 ? 1 : 0;
         s.id = id;
         s.normed = normed ? 1 : 0;
         s.bound = bound;
@@ -311,6 +314,7 @@ struct ConvExtra {
     // a k5 s2 layer evaluated as k3 s1 over space-to-depth input (any kernel): weights to use instead of P.weight
     const float* weight_used = nullptr;
     int s2d_cin = 0;
+    bool out_cb8 = false;   // conv2d_x3 only: write the output channel-blocked (the consumer must accept Src::cb8)
     bool matching_extras() const { return l0A || side_out || plane_weight_sets > 0; }
 };
 
@@ -348,7 +352,9 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.d_begin = extra->d_begin;
         L.side_out = extra->side_out;
         L.plane_weight_sets = extra->plane_weight_sets;
+        L.out_cb8 = extra->out_cb8 ? 1 : 0;
     }
+    o.cb8 = L.out_cb8 != 0;
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
     // Winograd domain (plain single-source Cin -> 64 layers), 9 = conv2d on the bf16 pipe with three-way split operands
     int kind = 0;
@@ -365,6 +371,11 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
     if (kind == 9) L.packed = c.get<float>(conv2d_x3_packed_floats(in.c));
+    if ((a.cb8 || b.cb8 || L.out_cb8) && !(kind == 8 && !L.out_cb8) &&
+        !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
+        c.run(set_error(-1, "conv_block: a channel-blocked tensor reached a kernel that does not take it"));
+        return o;
+    }
     if (L.out_batch_channels && kind != 4 && kind != 9) {
         c.run(set_error(-1, "conv_block: a channel-slice output needs the Winograd kernel"));
         return o;
@@ -737,8 +748,19 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur.raw, c.s, cur.bound));
     float* spare_a = t2.raw;                        // free from here on
     float* spare_b = c.get<float>(g.numel());
+    // Channel-blocked activations between the 64-channel layers (round 5; conv2d_x3.hip: X3Args::in_cb8): level 1 = the
+    // tensor between the two convolutions of a residual block (produced and consumed by conv2d_x3 alone)
+    const int cb8_level = [&]() {
+        static const int level = []() {   // PDS_MATCHING_CB8=0: planar NCDHW everywhere (A/B, tests)
+            const char* e = debug_switch("PDS_MATCHING_CB8");
+            return e ? atoi(e) : 1;
+        }();
+        return (F == 64 && h % 16 == 0 && w % 16 == 0) ? level : 0;
+    }();
     for (int r = 1; r < P.residual_blocks; ++r) {
-        t1 = conv_block(c, cur.src(), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a);
+        ConvExtra blocked;
+        blocked.out_cb8 = cb8_level >= 1;
+        t1 = conv_block(c, cur.src(), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a, true, nullptr, nullptr, &blocked);
         t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1, spare_b);
         if (r + 1 < P.residual_blocks) {
             DT nxt;                                 // t1 is dead: x_{r+1} = norm(t2) + x_r goes there

@@ -100,6 +100,9 @@ struct Src {
     const float* bound = nullptr;
     int bound_n = 0;
     int bounded = 0;     // host-side only: a bound goes with the tensor (true in planning walks too, where bound is null)
+    // Channel-blocked layout [N][D][C / 8][H][W][8] instead of NCDHW (round 5): private to the fused inference chain of
+    // Matching, whose 64-channel tensors never leave the library; only the kernels of that chain accept it.
+    int cb8 = 0;
 };
 
 inline Src plain_src(const float* p) { return Src{p, nullptr, nullptr, 0, 0}; }
@@ -172,6 +175,7 @@ struct ConvLayer {
     // > 0: every d-plane has its own weight / bias set (weight + d * Cout*Cin*9, bias + d * Cout)
     int plane_weight_sets = 0;
     PackSink* sink = nullptr;  // nullptr: pack inline
+    int out_cb8 = 0;           // conv2d_x3 only: write the output channel-blocked (Src::cb8)
 };
 
 // direct VALU convolution, any channel count

@@ -111,6 +111,11 @@ struct X3Args {
     int planes;                               // N * D
     int nks;                                  // Cin / 16
     int epi_lds;                              // fp16 form: stores of interior tiles go through the LDS transposition
+    // Channel-blocked activations (round 5, fp16 form only): [N][D][C / 8][H][W][8] -- the eight channels of a group are
+    // the 32 contiguous bytes of a pixel, i.e. exactly one 16-byte LDS slot per split part, and a halo row of a group is
+    // ONE run of 34 x 32 bytes instead of eight 136-byte segments in eight channel planes.  Private to the fused
+    // Matching chain (l1_combine -> conv2d_x3 x 3 -> materialize_l0 -> conv2d_t8w), see matching_pipeline (api.hip).
+    int in_cb8, out_cb8;
     // fp16 form: the power-of-two operand scales (header comment).  ascale is computed by every workgroup from the
     // source's range certificate, 1 / ws was left behind the tile-queue counters by the weight packing.
     const float* __restrict__ bound;
@@ -120,6 +125,27 @@ struct X3Args {
 
 struct Tile {
     int n, d, tile, y0, x0;
+};
+
+// the sixteen channels of a K-step that a staging thread requests for its pixel: sixteen dword loads from sixteen channel
+// planes, or (channel-blocked input) four 16-byte loads from the two groups of eight
+template <bool CBI>
+struct X3In {
+    float v[16];
+    __device__ __forceinline__ float get(int c) const { return v[c]; }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = 0.f;
+    }
+};
+template <>
+struct X3In<true> {
+    f32x4 q[4];
+    __device__ __forceinline__ float get(int c) const { return q[c >> 2][c & 3]; }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 };
 
 // One lane draws the next tile: its home queue first, then the others (work stealing).  Virtual tile id =
@@ -306,7 +332,7 @@ struct MfmaLane {
 // One tile on an MFMA wave: all stages, then the epilogue.  The accumulators live and die inside this function, per
 // variant, so they never cross a control-flow merge (a phi of 128 registers costs copies and their live ranges).
 // Returns the id of the next tile (read at stage 1).
-template <int P, bool NORM, bool NARROW>
+template <int P, bool NORM, bool NARROW, bool CBO>
 __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds, const MfmaLane& L, const Tile& cur,
                                             int& upar, int& wpar) {
     using C = X3Cfg<P>;
@@ -442,17 +468,36 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
                         q2[nb][0] = __builtin_elementwise_fma(ta, ta, q2[nb][0]);
                         q2[nb][1] = __builtin_elementwise_fma(tb, tb, q2[nb][1]);
                     }
+#if defined(PDS_X3_EPI_DUMPONLY) || defined(PDS_X3_EPI_NOSTORE)   // timing ablations (wrong results)
+                if (acc[0][0][0] != 12345.f) continue;
+#endif
+                if constexpr (CBO) {
+                    // channel-blocked output: lane -> (pixel p of the M block, channel quad hq); store j writes channels
+                    // 8 j + 4 hq .. + 3 of that pixel, i.e. one instruction covers the 32 pixels x 32 bytes of group j:
+                    // 1 024 contiguous bytes (wide block) or two 512-byte runs (narrow block: two rows of 16)
+                    const int lane = (L.kgl << 5) | L.m32;
+                    const int p = lane >> 1, hq = lane & 1;
+                    const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (p >> 4) : mb);
+                    const int x = cur.x0 + (NARROW ? (p & 15) : p);
+                    float* po = A.out + (((size_t)(cur.n * A.D + cur.d) * 8) * L.plane + (size_t)y * A.W + x) * 8 + 4 * hq;
+                    const unsigned char* rdc = epi + (4 * hq) * C::EPI_ROW + p * 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const float*>(rdc + (8 * j + e) * C::EPI_ROW);
+                        *reinterpret_cast<f32x4*>(po + (size_t)j * L.plane * 8) = v;
+                    }
+                } else {
                 // pixel quad q of the M block: wide = one row of 32 columns; narrow = two rows of 16
                 const int y = cur.y0 + 4 * L.wave + (NARROW ? 2 * mb + (q >> 2) : mb);
                 const int x = cur.x0 + (NARROW ? 4 * (q & 3) : 4 * q);
                 float* po = obase + (size_t)cg * L.cstride + (size_t)y * A.W + x;
-#if defined(PDS_X3_EPI_DUMPONLY) || defined(PDS_X3_EPI_NOSTORE)   // timing ablations (wrong results)
-                if (acc[0][0][0] != 12345.f) continue;
-#endif
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     *reinterpret_cast<f32x4*>(po + (size_t)(8 * j) * L.cstride) =
                         *reinterpret_cast<const f32x4*>(rd + j * 8 * C::EPI_ROW);
+                }
             }
             done = true;
         }
@@ -487,7 +532,7 @@ __device__ __forceinline__ int x3_mfma_tile(const X3Args& A, unsigned char* lds,
     return nxt_id;
 }
 
-template <int P, bool NORM>
+template <int P, bool NORM, bool CBO>
 __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* lds, int wave, int lane, int cur_id) {
     MfmaLane L;
     L.wave = wave;
@@ -510,10 +555,10 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
         const Tile cur = decode_tile(A, cur_id);
         if (cur.x0 + 16 >= A.W) {   // the right half of the tile is outside the image (uniform)
             L.x_lane = x_narrow;
-            cur_id = x3_mfma_tile<P, NORM, true>(A, lds, L, cur, upar, wpar);
+            cur_id = x3_mfma_tile<P, NORM, true, CBO>(A, lds, L, cur, upar, wpar);
         } else {
             L.x_lane = x_full;
-            cur_id = x3_mfma_tile<P, NORM, false>(A, lds, L, cur, upar, wpar);
+            cur_id = x3_mfma_tile<P, NORM, false, CBO>(A, lds, L, cur, upar, wpar);
         }
         if (cur_id < 0) break;
     }
@@ -531,7 +576,7 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
 // two whole stages to land (global latency under load is ~2 us, about one stage; with a one-stage lag every stage
 // began by waiting for the loads issued at the end of the previous one).  The stage loop is unrolled by two so that
 // the set index is a compile-time constant; a stage body is one function that also does the end-of-tile bookkeeping.
-template <int P, bool NORM>
+template <int P, bool NORM, bool CBI>
 __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char* lds, int st, int cur_id) {
     using C = X3Cfg<P>;
     constexpr int W_ITERS = C::W_ITERS, W_STAGE = C::W_STAGE, IN_BUF = C::IN_BUF;
@@ -547,7 +592,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     const int home = blockIdx.x & 7;
     const int n_full = A.tiles_y * A.tiles_x_full;
 
-    float xin[2][16];         // [set][channel of the K-step]
+    X3In<CBI> xin[2];         // [set]: the channels of the K-step
     u32x4 win[2][W_ITERS];    // [set][this thread's pieces of a weight stage]
     float coef_s[2] = {1.f, 1.f}, coef_h[2] = {0.f, 0.f};   // [set]: the thread's channel of the NEXT tile's table
     const int wlast = W_STAGE / 16 - 1;
@@ -563,11 +608,27 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     // kSetLoads = loads every stage issues: 2 coefficients (NORM), 16 inputs, W_ITERS weight pieces; a wait for "at most
     // kSetLoads outstanding" therefore covers the whole older set (vector-memory results return in order; other
     // memory operations in between only make the wait stricter).
-    constexpr int kSetLoads = 16 + W_ITERS + (NORM ? 2 : 0);
-    auto request_inputs = [&](float (&x)[16], const Tile& tl, int ks, int third) {
-        const float* src = A.a.p + ((size_t)(tl.n * A.Cin + ks * 16) * A.D + tl.d) * plane;   // uniform
+    constexpr int kInLoads = CBI ? 4 : 16;
+    constexpr int kSetLoads = kInLoads + W_ITERS + (NORM ? 2 : 0);
+    auto request_inputs = [&](X3In<CBI>& x, const Tile& tl, int ks, int third) {
         const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
         const int yc = min(max(y, 0), A.H - 1), xc = min(max(xx, 0), A.W - 1);
+        if constexpr (CBI) {
+            // groups 2 ks and 2 ks + 1 of plane (n, d) of [N][D][C / 8][H][W][8]: the pixel's 32 bytes in each, two 16-byte
+            // loads per group -- the base walks in s[60:61] as below
+            const float* src = A.a.p + (((size_t)(tl.n * A.D + tl.d) * (A.Cin >> 3) + 2 * ks) * plane) * 8;   // uniform
+            const unsigned boff = (unsigned)(yc * A.W + xc) * 32u;
+            const unsigned long long base = reinterpret_cast<unsigned long long>(src);
+            const unsigned base_lo = (unsigned)base, base_hi = (unsigned)(base >> 32), step = (unsigned)(plane * 32);
+            asm volatile("s_mov_b32 s60, %5\n\ts_mov_b32 s61, %6\n\t"
+                         "global_load_dwordx4 %0, %4, s[60:61]\n\tglobal_load_dwordx4 %1, %4, s[60:61] offset:16\n\t"
+                         "s_add_u32 s60, s60, %7\n\ts_addc_u32 s61, s61, 0\n\t"
+                         "global_load_dwordx4 %2, %4, s[60:61]\n\tglobal_load_dwordx4 %3, %4, s[60:61] offset:16"
+                         : "=&v"(x.q[0]), "=&v"(x.q[1]), "=&v"(x.q[2]), "=&v"(x.q[3])
+                         : "v"(boff), "s"(base_lo), "s"(base_hi), "s"(step)
+                         : "memory", "s60", "s61", "scc");
+        } else {
+        const float* src = A.a.p + ((size_t)(tl.n * A.Cin + ks * 16) * A.D + tl.d) * plane;   // uniform
         const unsigned boff = (unsigned)(yc * A.W + xc) * 4u;   // (a channel plane is far below 4 GB)
         // One statement for the sixteen loads: the channel base walks in s[60:61] (scalar adds) and the lane offset is
         // one VGPR.  The base arrives through s_mov: an SGPR that the compiler has just re-loaded from a spill lane
@@ -579,29 +640,37 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
         asm volatile("s_mov_b32 s60, %17\n\ts_mov_b32 s61, %18\n\t" PDS_X3_LD(0) PDS_X3_LD(1) PDS_X3_LD(2) PDS_X3_LD(3)
                          PDS_X3_LD(4) PDS_X3_LD(5) PDS_X3_LD(6) PDS_X3_LD(7) PDS_X3_LD(8) PDS_X3_LD(9) PDS_X3_LD(10)
                              PDS_X3_LD(11) PDS_X3_LD(12) PDS_X3_LD(13) PDS_X3_LD(14) "global_load_dword %15, %16, s[60:61]"
-                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]),
-                       "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]),
-                       "=&v"(x[14]), "=&v"(x[15])
+                     : "=&v"(x.v[0]), "=&v"(x.v[1]), "=&v"(x.v[2]), "=&v"(x.v[3]), "=&v"(x.v[4]), "=&v"(x.v[5]), "=&v"(x.v[6]),
+                       "=&v"(x.v[7]), "=&v"(x.v[8]), "=&v"(x.v[9]), "=&v"(x.v[10]), "=&v"(x.v[11]), "=&v"(x.v[12]), "=&v"(x.v[13]),
+                       "=&v"(x.v[14]), "=&v"(x.v[15])
                      : "v"(boff), "s"(base_lo), "s"(base_hi), "s"(step)
                      : "memory", "s60", "s61", "scc");
 #undef PDS_X3_LD
+        }
     };
     // every value of a set passes through this statement before its first use: the wait cannot be scheduled after a
     // consumer, and no consumer before it
-    auto await_set = [&](float (&x)[16], u32x4 (&w)[W_ITERS], float& cs, float& ch) {
-        asm volatile("s_waitcnt vmcnt(%16)"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                       "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]),
-                       "+v"(x[15])
-                     : "n"(kSetLoads)
-                     : "memory");
+    auto await_set = [&](X3In<CBI>& x, u32x4 (&w)[W_ITERS], float& cs, float& ch) {
+        if constexpr (CBI) {
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]) : "n"(kSetLoads) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]),
+                           "+v"(x.v[7]), "+v"(x.v[8]), "+v"(x.v[9]), "+v"(x.v[10]), "+v"(x.v[11]), "+v"(x.v[12]), "+v"(x.v[13]),
+                           "+v"(x.v[14]), "+v"(x.v[15])
+                         : "n"(kSetLoads)
+                         : "memory");
+        }
 #pragma unroll
         for (int it = 0; it < W_ITERS; ++it) asm volatile("" : "+v"(w[it]) : : "memory");
         asm volatile("" : "+v"(cs), "+v"(ch) : : "memory");
     };
     f32x4 cs[4], ch[4];   // the sixteen (scale, shift) pairs of the K-step being written: read at its first third only
-    auto write_inputs = [&](const float (&x)[16], const Tile& tl, int ks, int third, unsigned char* buf,
+    auto write_inputs = [&](const X3In<CBI>& xs, const Tile& tl, int ks, int third, unsigned char* buf,
                             const float* coef) {
+        float x[16];   // (names for the set's registers: no copies survive)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = xs.get(c);
         // the producer's folded InstanceNorm of this (batch entry, plane): table of the tile in LDS, one address per
         // wave (broadcast reads), all sixteen channels up front; the three thirds of a K-step share them
         if (NORM && third == 0) {
@@ -760,21 +829,24 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     Tile nxt = cur, done = cur;
     int nxt_id = -1;
     int tpar = 0;             // coefficient table of the current tile
-    auto await_all = [&](float (&x)[16], u32x4 (&w)[W_ITERS], float& cs, float& ch) {
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                       "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]),
-                       "+v"(x[15])
-                     :
-                     : "memory");
+    auto await_all = [&](X3In<CBI>& x, u32x4 (&w)[W_ITERS], float& cs, float& ch) {
+        if constexpr (CBI) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]),
+                           "+v"(x.v[7]), "+v"(x.v[8]), "+v"(x.v[9]), "+v"(x.v[10]), "+v"(x.v[11]), "+v"(x.v[12]), "+v"(x.v[13]),
+                           "+v"(x.v[14]), "+v"(x.v[15])
+                         :
+                         : "memory");
+        }
 #pragma unroll
         for (int it = 0; it < W_ITERS; ++it) asm volatile("" : "+v"(w[it]) : : "memory");
         asm volatile("" : "+v"(cs), "+v"(ch) : : "memory");
     };
 #pragma unroll
     for (int set = 0; set < 2; ++set) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) xin[set][c] = 0.f;
+        xin[set].clear();
 #pragma unroll
         for (int it = 0; it < W_ITERS; ++it) win[set][it] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -865,7 +937,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
 
 }  // namespace
 
-template <int P, bool NORM>
+template <int P, bool NORM, bool CBI, bool CBO>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -890,8 +962,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A0) 
     __syncthreads();
     const int cur_id = __builtin_amdgcn_readfirstlane(next_slot[0]);
     if (cur_id >= 0) {
-        if (wave < 4) x3_mfma_waves<P, NORM>(A, lds, wave, tid & 63, cur_id);
-        else x3_staging_waves<P, NORM>(A, lds, tid - STAGERS, cur_id);
+        if (wave < 4) x3_mfma_waves<P, NORM, CBO>(A, lds, wave, tid & 63, cur_id);
+        else x3_staging_waves<P, NORM, CBI>(A, lds, tid - STAGERS, cur_id);
     }
     // A workgroup leaves only after it has found every queue empty, so the last one to leave may reset the counters
     // for the next launch on this workspace (no memset launch per layer; the packing launch zeroes them the first time).
@@ -938,23 +1010,33 @@ static bool x3_use_fp16(const ConvLayer& L) {
     return enabled && L.a.bounded;
 }
 
-template <int P>
+template <int P, bool CBI, bool CBO>
 static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t s) {
     using C = X3Cfg<P>;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, true, CBI, CBO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false, CBI, CBO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     }
     // (planes * tiles rides along as the "workgroups" of the probe record: it tells a 48-plane layer from a small one)
     const int probe = probe_before(P == 2 ? "conv2d_x3<fp16>" : "conv2d_x3<bf16>", s);
     if (L.a.scale)
-        hipLaunchKernelGGL((conv2d_x3_kernel<P, true>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
-    else hipLaunchKernelGGL((conv2d_x3_kernel<P, false>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
+        hipLaunchKernelGGL((conv2d_x3_kernel<P, true, CBI, CBO>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
+    else hipLaunchKernelGGL((conv2d_x3_kernel<P, false, CBI, CBO>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
     probe_after(probe, A.planes * A.tiles, s);
     return check_launch("conv2d_x3");
+}
+
+// channel-blocked tensors ([N][D][C / 8][H][W][8], common.hpp Src::cb8): the fp16 form, whole tiles only, 64 channels out
+bool conv2d_x3_cb8_ok(const ConvLayer& L, bool in_cb8, bool out_cb8) {
+    if (!in_cb8 && !out_cb8) return true;
+    if (!conv2d_x3_supported(L) || !L.a.bounded) return false;
+    if (L.in.h % TH != 0 || L.in.w % 16 != 0) return false;
+    if (out_cb8 && (L.out_batch_channels > 0 && L.out_batch_channels != 64)) return false;
+    if (in_cb8 && L.in.c % 8 != 0) return false;
+    return true;
 }
 
 int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
@@ -1014,7 +1096,16 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     }
     const long long all = (long long)A.planes * A.tiles;
     const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
-    return fp16 ? x3_launch<2>(L, A, workgroups, s) : x3_launch<3>(L, A, workgroups, s);
+    A.in_cb8 = L.a.cb8;
+    A.out_cb8 = L.out_cb8;
+    if (A.in_cb8 || A.out_cb8) {
+        if (!fp16 || !conv2d_x3_cb8_ok(L, A.in_cb8, A.out_cb8))
+            return set_error(-1, "conv2d_x3: channel-blocked tensors need the fp16 form and whole 16 x 16 tiles");
+        if (A.in_cb8 && A.out_cb8) return x3_launch<2, true, true>(L, A, workgroups, s);
+        if (A.in_cb8) return x3_launch<2, true, false>(L, A, workgroups, s);
+        return x3_launch<2, false, true>(L, A, workgroups, s);
+    }
+    return fp16 ? x3_launch<2, false, false>(L, A, workgroups, s) : x3_launch<3, false, false>(L, A, workgroups, s);
 }
 
 }  // namespace pds
