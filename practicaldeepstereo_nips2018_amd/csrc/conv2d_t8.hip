@@ -66,11 +66,10 @@ struct C2Args {
 
 // two-way fp16 split of four fp32 values (round to nearest): hi carries 11 bits, lo the next 11
 __device__ __forceinline__ void c2_split(const float (&v)[4], f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hi[i] = (_Float16)v[i];
-        lo[i] = (_Float16)(v[i] - (float)hi[i]);
-    }
+    pds_u32x2 h, l;   // (packed conversions, common.hpp: 3 instead of 5 instructions per value in the staging path)
+    split_quad_f16(v, h, l);
+    hi = __builtin_bit_cast(f16x4, h);
+    lo = __builtin_bit_cast(f16x4, l);
 }
 
 // power-of-two operand scales of a launch (header comment), wave-uniform; called by ALL threads before anything else

@@ -69,14 +69,10 @@ struct TXCfg {
 template <int P>
 __device__ __forceinline__ void tx_split(const float (&v)[4], u32x2 (&part)[P]) {
     if constexpr (P == 2) {
-        f16x4 hi, lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            hi[i] = (_Float16)v[i];
-            lo[i] = (_Float16)(v[i] - (float)hi[i]);
-        }
-        part[0] = __builtin_bit_cast(u32x2, hi);
-        part[1] = __builtin_bit_cast(u32x2, lo);
+        pds_u32x2 h, l;   // (packed conversions, common.hpp)
+        split_quad_f16(v, h, l);
+        part[0] = __builtin_bit_cast(u32x2, h);
+        part[1] = __builtin_bit_cast(u32x2, l);
     } else {
         // truncation split: every part is the top 16 bits of what is left, the remainder is exact
         unsigned short h[3][4];

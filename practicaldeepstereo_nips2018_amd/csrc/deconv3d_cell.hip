@@ -43,11 +43,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void cell_split(const float (&v)[4], f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hi[i] = (_Float16)v[i];
-        lo[i] = (_Float16)(v[i] - (float)hi[i]);
-    }
+    pds_u32x2 h, l;   // (packed conversions, common.hpp)
+    split_quad_f16(v, h, l);
+    hi = __builtin_bit_cast(f16x4, h);
+    lo = __builtin_bit_cast(f16x4, l);
 }
 
 struct CellArgs {

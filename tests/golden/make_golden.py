@@ -466,6 +466,67 @@ def g11_training_step():
     REPORT['g11_training_step'] = rep
 
 
+def g13_config5_gradients():
+    """BASELINE.json configs[4] at FULL size: ONE training step of the reference -- train-mode
+    PdsNetwork.default(191) on the 540x960 pair of the input recipe, SubpixelCrossEntropy against a seeded ground truth
+    with an unknown (inf) band, backward (pds_trainer.py:35-46, loss.py:30-78) -- in fp32 AND in fp64.  Stored per
+    parameter tensor: the gradient's norm and largest entry of both runs, the reference's own fp32-vs-fp64 distance, and a
+    strided sub-sample of at most 512 entries of both (a few hundred KB in all).  The weight gradients of the 64-channel
+    layers sum 1.6 M sign-cancelling terms per entry here -- the regime the small fixture G11 cannot reach."""
+    import copy
+    import gc
+    from practical_deep_stereo import loss as ref_loss
+    torch.manual_seed(0)
+    net = ref_network.PdsNetwork.default(191).train()
+    left, right = images(1, 540, 960)
+    g = torch.Generator().manual_seed(41)
+    gt = torch.rand(1, 540, 960, generator=g) * 190.0
+    gt[:, :17] = float('inf')
+    names = [n for n, _ in net.named_parameters()]
+
+    def sub(t):
+        flat = t.detach().flatten()
+        return flat[::max(1, -(-flat.numel() // 512))]
+
+    def run(network, dtype):
+        network.zero_grad()
+        cost = network(left.to(dtype), right.to(dtype))
+        value = ref_loss.SubpixelCrossEntropy()(cost, gt.to(dtype))
+        value.backward()
+        grads = {n: q.grad.detach().clone() for n, q in network.named_parameters()}
+        out = (float(value), grads, cost.detach()[:, ::8, ::36, ::64].contiguous().clone())
+        del cost, value
+        gc.collect()
+        return out
+    loss32, grads32, cost_sub32 = run(net, torch.float32)
+    net64 = copy.deepcopy(net).double()
+    net64.zero_grad()
+    loss64, grads64, cost_sub64 = run(net64, torch.float64)
+    del net64
+    gc.collect()
+
+    def rel(a, b):
+        return maxdiff(a, b) / (float(b.abs().max()) + 1e-300)
+    reference_rel = np.array([rel(grads32[n], grads64[n]) for n in names])
+    live = np.array([grads64[n].norm().item() > 1e-9 for n in names])
+    subs32 = [sub(grads32[n]).double() for n in names]
+    subs64 = [sub(grads64[n]) for n in names]
+    offsets = np.cumsum([0] + [t.numel() for t in subs64])
+    save('g13_config5_gradients', loss=np.array([loss32]), loss_fp64=np.array([loss64]), ground_truth_seed=np.array([41]),
+         grad_sub_offsets=offsets, grad_sub=torch.cat(subs32).float(), grad_sub_fp64=torch.cat(subs64),
+         grad_norms=np.array([grads32[n].double().norm().item() for n in names]),
+         grad_norms_fp64=np.array([grads64[n].norm().item() for n in names]),
+         grad_abs_max_fp64=np.array([grads64[n].abs().max().item() for n in names]),
+         grad_reference_vs_fp64_rel=reference_rel, live=live,
+         parameter_names=np.array(names), cost_sub=cost_sub32, cost_sub_fp64=cost_sub64,
+         weight_checksum=checksum(net.state_dict()))
+    REPORT['g13_config5_gradients'] = {
+        'loss_fp32': loss32, 'loss_fp64': loss64,
+        'param_grad_reference_fp32_vs_fp64_rel_max': float(reference_rel[live].max()),
+        'param_grad_reference_fp32_vs_fp64_rel_median': float(np.median(reference_rel[live])),
+        'tensors': len(names), 'tensors_with_nonzero_gradient': int(live.sum())}
+
+
 def injection_into_reference():
     """The reference-side half of the drop-in claim (BASELINE.json north_star: "network.py/pds_trainer.py drop them in
     unchanged"): the REFERENCE's own PdsNetwork (network.py:17-24) and PdsTrainer (pds_trainer.py:35-46, trainer.py:87-122)
@@ -587,6 +648,7 @@ if __name__ == '__main__':
     injection_into_reference()
     if '--skip-config2' not in sys.argv:
         g7_config2_statistics()
+        g13_config5_gradients()
     REPORT['torch'] = torch.__version__
     with open(os.path.join(HERE, 'pinning_report.json'), 'w') as f:
         json.dump(REPORT, f, indent=2, sort_keys=True)
