@@ -99,22 +99,32 @@ def _choose_gather_mode(device, group):
     global _GATHER_MODE, _GATHER_NOTE
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = _device_backend(group, device)
-    order = ['coalesced', 'separate', 'single']
-    batch, channels, d_local, h, w = 2, 3, 2, 3, 5
-    def shard(r):
-        base = torch.arange(batch * channels * d_local * h * w, dtype=torch.float32).view(batch, channels, d_local, h, w)
-        return base + 1000.0 * r
-    expect = torch.cat([shard(r) for r in range(world)], dim=2).to(device)
-    mine = shard(rank).to(device).contiguous()
+    # (the coalesced form is RCCL's ncclGroup; gloo offers the same method, but with CUDA tensors its result was wrong on
+    # real-size tensors although the tiny self-check passed -- tests/test_gpu_sharded.py -- so gloo keeps the separate calls)
+    order = ['coalesced', 'separate', 'single'] if backend == 'nccl' else ['separate', 'single']
+    # two sizes: a tiny one (layout errors show at once) and a realistic one -- 2.2 MB per rank, the per-channel blocks
+    # of config 2 at N = 8 are 0.8 MB -- because a form can pass on a few hundred bytes and fail on real transfers (gloo's
+    # coalesced method with CUDA tensors did, round 5)
+    def shard(r, shape):
+        n = 1
+        for v in shape:
+            n *= v
+        base = (torch.arange(n, dtype=torch.float32) % 8191.0).view(shape)
+        return base + 10000.0 * (r + 1)
+    cases = []
+    for shape in ((2, 3, 2, 3, 5), (1, 8, 2, 144, 240)):
+        expect = torch.cat([shard(r, shape) for r in range(world)], dim=2).to(device)
+        cases.append((shard(rank, shape).to(device).contiguous(), expect, (shape[0], shape[1], world * shape[2], shape[3], shape[4])))
     tried = []
     for mode in order:
         ok, why = True, ''
         try:
-            out = mine.new_full((batch, channels, world * d_local, h, w), float('nan'))
-            _GATHER_FORMS[mode](out, mine, group)
-            if out.is_cuda:
-                torch.cuda.synchronize(out.device)
-            ok = bool(torch.equal(out, expect))
+            for mine, expect, full_shape in cases:
+                out = mine.new_full(full_shape, float('nan'))
+                _GATHER_FORMS[mode](out, mine, group)
+                if out.is_cuda:
+                    torch.cuda.synchronize(out.device)
+                ok = ok and bool(torch.equal(out, expect))
             why = '' if ok else 'wrong result'
         except Exception as error:   # noqa: BLE001  (any failure of this form means: use the next one)
             ok, why = False, '%s: %s' % (type(error).__name__, str(error).split('\n')[0][:120])

@@ -248,26 +248,30 @@ def preflight_worker(rank, world, port, results):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         info = pdist.preflight_collectives(device='cpu')
-        ok = info['gather_mode'] in ('coalesced', 'separate', 'single') and info['backend'] == 'gloo'
+        ok = info['gather_mode'] in ('separate', 'single') and info['backend'] == 'gloo'
         ok = ok and info['all_reduce'] == 'ok' and info['gather_mode'] in pdist.gather_description()
         g = torch.Generator().manual_seed(21)
         full = torch.randn(2, 8, 4 * world, 3, 5, generator=g)
         mine = full[:, :, 4 * rank:4 * rank + 4].contiguous()
-        forms = ['separate', 'single'] + (['coalesced'] if info['gather_mode'] == 'coalesced' else [])
-        for mode in forms:   # (the coalesced form where this backend offers it: it is the public ProcessGroup method)
+        forms = ['separate', 'single', 'coalesced']   # (gloo offers the coalesced method for CPU tensors too: the layout is checked)
+        for mode in forms:
             out = torch.full_like(full, float('nan'))
             pdist._GATHER_FORMS[mode](out, mine, None)
             ok = ok and torch.equal(out, full)
-        # a failing 'coalesced' form must leave the process group usable: the chain moves on and later collectives work
+        # a failing 'coalesced' form must leave the process group usable (it is tried first on RCCL; here the order is
+        # forced): the chain moves on and later collectives work
         real_coalesced = pdist._GATHER_FORMS['coalesced']
+        real_backend = pdist._device_backend
         def broken_coalesced(out, local, group):
             raise RuntimeError('injected failure in the coalesced form')
         pdist._GATHER_FORMS['coalesced'] = broken_coalesced
+        pdist._device_backend = lambda group, device: 'nccl'
         try:
             pdist._GATHER_MODES.clear()
             mode = pdist._choose_gather_mode(torch.device('cpu'), None)
         finally:
             pdist._GATHER_FORMS['coalesced'] = real_coalesced
+            pdist._device_backend = real_backend
         ok = ok and mode == 'separate' and 'coalesced failed' in pdist.gather_description()
         ok = ok and torch.equal(pdist.gather_planes(mine), full)
         # (i) a form that raises on EVERY rank (an API error -- RCCL reports misuse as RuntimeError -- is the same

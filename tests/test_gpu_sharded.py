@@ -37,6 +37,12 @@ def worker(rank, world, port, results):
 
         hot_path = ShardedHotPath(net._matching, tail)
         ok, outputs = True, []
+        failed = []
+
+        def check(name, condition):
+            if not condition:
+                failed.append(name)
+            return bool(condition)
         with torch.no_grad():
             for i in range(4):
                 g = torch.Generator().manual_seed(100 + i)
@@ -44,12 +50,12 @@ def worker(rank, world, port, results):
                 right = torch.randn(1, 64, 32, 64, generator=g).to(dev)
                 shortcut = torch.randn(1, 8, 32, 64, generator=g).to(dev)
                 out = hot_path.submit(left, right, shortcut)
-                ok = ok and ((out is not None) == (i % world == rank))
+                ok = check('owner of pair %d' % i, (out is not None) == (i % world == rank)) and ok
                 outputs.append((out, left, right, shortcut))
             hot_path.drain()
             for out, left, right, shortcut in outputs:
                 if out is not None:
-                    ok = ok and torch.equal(out, tail(net._matching(left, right), shortcut))
+                    ok = check('side-stream tail equals unsharded', torch.equal(out, tail(net._matching(left, right), shortcut))) and ok
             # the same stream of pairs dealt to two HIP streams per rank (bench.py's N > 1 default)
             # ... with the ranks deliberately skewed (rank 1 submits late, in bursts): every all-gather is issued on the
             # object's ONE collective stream in submission order, so the skew can delay a pair but never mis-pair two
@@ -65,18 +71,19 @@ def worker(rank, world, port, results):
                 _, left, right, shortcut = outputs[i % 4]
                 dealt.append(lanes.submit(left, right, shortcut))
             lanes.drain()
-            ok = ok and lanes.gathers_issued == 12
+            ok = check('gathers issued %d' % lanes.gathers_issued, lanes.gathers_issued == 12) and ok
             for i, got in enumerate(dealt):
                 want = outputs[i % 4][0]
-                ok = ok and ((got is not None) == (i % world == rank))
+                ok = check('lane owner of pair %d' % i, (got is not None) == (i % world == rank)) and ok
                 if got is not None:
                     reference = want if want is not None else tail(net._matching(*outputs[i % 4][1:3]), outputs[i % 4][3])
-                    ok = ok and torch.equal(got, reference)
+                    ok = check('lane pair %d equals unsharded' % i, torch.equal(got, reference)) and ok
             # the plain sharded module (all-gather on every rank) as well
             _, left, right, _ = outputs[0]
-            ok = ok and torch.equal(ShardedMatching(net._matching)(left, right), net._matching(left, right))
+            ok = check('ShardedMatching equals unsharded', torch.equal(ShardedMatching(net._matching)(left, right), net._matching(left, right))) and ok
         torch.cuda.synchronize()
         results[rank] = bool(ok)
+        results['failed %d' % rank] = list(failed)
     finally:
         dist.destroy_process_group()
 
