@@ -755,7 +755,16 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
             const char* e = debug_switch("PDS_MATCHING_CB8");
             return e ? atoi(e) : 1;
         }();
-        return (F == 64 && h % 16 == 0 && w % 16 == 0) ? level : 0;
+        if (!(F == 64 && h % 16 == 0 && w % 16 == 0)) return 0;
+        ConvLayer probe;   // would conv2d_x3 serve these layers in its fp16 form (PDS_X3 / PDS_X3_FP16 may say no)?
+        probe.a = plain_src(nullptr);
+        probe.a.bounded = 1;
+        probe.b = no_src();
+        probe.in = g;
+        probe.out_g = g;
+        probe.kd = 1;
+        probe.stride = 1;
+        return conv2d_x3_cb8_ok(probe, true, true) ? level : 0;
     }();
     for (int r = 1; r < P.residual_blocks; ++r) {
         ConvExtra blocked;

@@ -598,6 +598,9 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 
     f32x4 acc[NBH];
     TilePos Pcur = tile_pos(0);
+#ifdef PDS_C2W_TIMING
+    long long tmw[5] = {0, 0, 0, 0, 0};
+#endif
     // one step: multiply chunk g, write chunk g + 1 (set (g + 1) & 1) to LDS and request chunk g + 3 into the same set
     auto step = [&](int g, auto set_c) {
         const int c = g % C2_CHUNKS;
@@ -613,7 +616,15 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 
         // ---- branch-free body ----------------------------------------------------------------------------------------
         const unsigned char* buf = ibuf + (g & 1) * buf_bytes + b_base;
+#ifdef PDS_C2W_TIMING   // (debug builds only: cycle stamps around the phases of a step; the scheduling barriers below are
+                        // disabled with it, so the phases run one after the other)
+        const long long tt0 = __builtin_readcyclecounter();
+#endif
         stash(ibuf + ((g + 1) & 1) * buf_bytes, set_c);
+#ifdef PDS_C2W_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long tt1 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int k = 0; k < C2W_ITEMS; ++k) {
             inside[k] = new_tile ? inside_n[k] : inside[k];
@@ -622,6 +633,9 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
         sbase = new_tile ? sbase_n : sbase;
         gidx = new_tile ? gidx_n : gidx;
         fetch(gf, set_c);
+#ifdef PDS_C2W_TIMING
+        const long long tt2 = __builtin_readcyclecounter();
+#endif
         const unsigned char* af = abuf + ((size_t)c * 3 * 2 * 64 + lane) * 8;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -639,6 +653,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, b_hi, acc[j], 0, 0, 0);
             }
         }
+#ifndef PDS_C2W_TIMING
 #pragma unroll
         for (int i = 0; i < 3 * NBH * 3; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -647,6 +662,10 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
         }
+#else
+        const long long tt3 = __builtin_readcyclecounter();
+        tmw[0] += tt1 - tt0; tmw[1] += tt2 - tt1; tmw[2] += tt3 - tt2;
+#endif
         if (c == C2_CHUNKS - 1) {
             // ---- epilogue of the tile: D row r = (channel 2q + (r >> 1), row parity r & 1) ------------------------------
             const int out_base = (int)((size_t)Pcur.nb * C2_COUT * cstride * sizeof(float));
@@ -665,12 +684,27 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                 }
             }
         }
+#ifdef PDS_C2W_TIMING
+        const long long tt4 = __builtin_readcyclecounter();
+#endif
         __syncthreads();
+#ifdef PDS_C2W_TIMING
+        tmw[3] += __builtin_readcyclecounter() - tt4;
+        tmw[4] += 1;
+#endif
     };
+#ifdef PDS_C2W_TIMING
+    const long long t_all = __builtin_readcyclecounter();
+#endif
     for (int g = 0; g < total_chunks; g += 2) {   // the two register sets alternate (16 chunks per tile)
         step(g, S1());
         step(g + 1, S0());
     }
+#ifdef PDS_C2W_TIMING
+    if (lane == 0 && (blockIdx.x % 61) == 0 && (wave == 0 || wave == 5))
+        printf("[t8w] wg %d wave %d: total %lld | stash(+wait) %lld fetch-issue %lld mfma %lld barrier %lld over %lld chunks (%d tiles)\n",
+               (int)blockIdx.x, wave, (long long)__builtin_readcyclecounter() - t_all, tmw[0], tmw[1], tmw[2], tmw[3], tmw[4], my_tiles);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

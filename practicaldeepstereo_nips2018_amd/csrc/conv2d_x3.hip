@@ -1032,7 +1032,7 @@ static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t 
 // channel-blocked tensors ([N][D][C / 8][H][W][8], common.hpp Src::cb8): the fp16 form, whole tiles only, 64 channels out
 bool conv2d_x3_cb8_ok(const ConvLayer& L, bool in_cb8, bool out_cb8) {
     if (!in_cb8 && !out_cb8) return true;
-    if (!conv2d_x3_supported(L) || !L.a.bounded) return false;
+    if (!conv2d_x3_supported(L) || !x3_use_fp16(L)) return false;   // (both honour their debug switches)
     if (L.in.h % TH != 0 || L.in.w % 16 != 0) return false;
     if (out_cb8 && (L.out_batch_channels > 0 && L.out_batch_channels != 64)) return false;
     if (in_cb8 && L.in.c % 8 != 0) return false;
