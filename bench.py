@@ -404,7 +404,9 @@ def train_record(device, steps=3, cpu=True):
     step of the CPU oracle (ONE step: forward + loss + backward, no optimizer) timed on the host beside it."""
     from practicaldeepstereo_nips2018_amd.training import DataParallelTrainer, synthetic_example
     torch.cuda.synchronize(device)
+    torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(device)
+    resident_before = torch.cuda.memory_allocated(device)   # the inference part's tensors and workspaces stay allocated
     trainer = DataParallelTrainer(MAX_DISPARITY, device)
     left, right, truth = synthetic_example(HEIGHT, WIDTH, MAX_DISPARITY, 1, device)
     losses = [trainer.step(left, right, truth)]                # warm-up: workspaces, weight re-layout
@@ -430,7 +432,9 @@ def train_record(device, steps=3, cpu=True):
               'steps': steps, 'steps_per_s': steps / elapsed, 'ms_per_step': elapsed / steps * 1e3,
               'forward_ms': (t1 - t0) * 1e3, 'loss_backward_ms': (t2 - t1) * 1e3,
               'first_loss': values[0], 'last_loss': values[-1],
-              'peak_memory_gb': torch.cuda.max_memory_allocated(device) / 2 ** 30}
+              'peak_memory_gb': (torch.cuda.max_memory_allocated(device) - resident_before) / 2 ** 30,
+              'peak_memory_note': 'PyTorch-allocated peak of the training step above what the inference part of this run '
+                                  'had left resident (%.1f GB)' % (resident_before / 2 ** 30)}
     if cpu:
         try:
             record['cpu_baseline'] = train_cpu_baseline(trainer.network, left, right, truth, values[0])
