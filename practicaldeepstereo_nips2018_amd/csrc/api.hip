@@ -315,6 +315,11 @@ struct ConvExtra {
     const float* weight_used = nullptr;
     int s2d_cin = 0;
     bool out_cb8 = false;   // conv2d_x3 only: write the output channel-blocked (the consumer must accept Src::cb8)
+    // conv2d_x3 only: input formed on the fly from the blocked layer-1 planes (ConvLayer::l1B)
+    const float* l1B = nullptr;
+    const float* l1H = nullptr;
+    unsigned l1_bstride = 0, l1_hstride = 0, l1_edge = 0;
+    int l1_P = 0, l1_d0 = 0;
     bool matching_extras() const { return l0A || side_out || plane_weight_sets > 0; }
 };
 
@@ -353,6 +358,13 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         L.side_out = extra->side_out;
         L.plane_weight_sets = extra->plane_weight_sets;
         L.out_cb8 = extra->out_cb8 ? 1 : 0;
+        L.l1B = extra->l1B;
+        L.l1H = extra->l1H;
+        L.l1_bstride = extra->l1_bstride;
+        L.l1_hstride = extra->l1_hstride;
+        L.l1_edge = extra->l1_edge;
+        L.l1_P = extra->l1_P;
+        L.l1_d0 = extra->l1_d0;
     }
     o.cb8 = L.out_cb8 != 0;
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
@@ -374,6 +386,10 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     if ((a.cb8 || b.cb8 || L.out_cb8) && !(kind == 8 && !L.out_cb8) &&
         !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
         c.run(set_error(-1, "conv_block: a channel-blocked tensor reached a kernel that does not take it"));
+        return o;
+    }
+    if (L.l1B && kind != 9) {
+        c.run(set_error(-1, "conv_block: the on-the-fly layer-1 source needs conv2d_x3"));
         return o;
     }
     if (L.out_batch_channels && kind != 4 && kind != 9) {
@@ -670,9 +686,33 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         conv_block(c, none, none, g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr, &l0);
         return;
     }
+    // Channel-blocked activations between the 64-channel layers (round 5; conv2d_x3.hip: X3Args::in_cb8): level 1 = the
+    // tensor between the two convolutions of a residual block (produced and consumed by conv2d_x3 alone); level 2 (opt-in,
+    // PDS_MATCHING_CB8=2): in addition the first 64 -> 64 launch forms its input t1 = LeakyReLU(B + shift_d(H)) while it stages it, from the
+    // channel-blocked layer-1 planes (misc.hip: l1_blocked_kernel) -- l1_combine only computes t1's statistics, the 425 MB
+    // round trip of t1 through HBM is gone.  Bit-identical; measured NEUTRAL (l1_combine 109 -> 63 us without its stores, + 20 us
+    // for the re-layout, + 11 us on the launch; 410 vs 408.5 pairs/s in a same-box A/B), so level 1 stays the default
+    const int cb8_level = [&]() {
+        static const int level = []() {   // PDS_MATCHING_CB8=0: planar NCDHW everywhere (A/B, tests)
+            const char* e = debug_switch("PDS_MATCHING_CB8");
+            return e ? atoi(e) : 1;
+        }();
+        if (!(F == 64 && h % 16 == 0 && w % 16 == 0)) return 0;
+        ConvLayer probe;   // would conv2d_x3 serve these layers in its fp16 form (PDS_X3 / PDS_X3_FP16 may say no)?
+        probe.a = plain_src(nullptr);
+        probe.a.bounded = 1;
+        probe.b = no_src();
+        probe.in = g;
+        probe.out_g = g;
+        probe.kd = 1;
+        probe.stride = 1;
+        return conv2d_x3_cb8_ok(probe, true, true) ? level : 0;
+    }();
     // Layer 1 factorised like layer 0 (misc.hip): B = conv1(A) + b1, H / Ha / Hb / H0 = conv1 of the G rows, as one
     // 5-plane launch with tap-masked weight sets; then LeakyReLU(B + shift_d(H)) + statistics in one streaming pass.
     DT t1;
+    ConvExtra fly;
+    bool on_the_fly = false;
     {
         DT y4;
         const float* corr = nullptr;
@@ -723,13 +763,31 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         t1.bound = c.get<float>(1);
         t1.bound_n = 1;
         t1.bounded = true;
+        if (columns && cb8_level >= 2) {
+            const int pad = d_begin + d_count;   // zero columns left of H: x - d + 2 + pad >= 0 for every plane of this call
+            fly.l1_bstride = (unsigned)(l1_blocked_b_floats(h, w) * sizeof(float));
+            fly.l1_hstride = (unsigned)(l1_blocked_h_floats(h, w, pad, d_count) * sizeof(float));
+            fly.l1_edge = (unsigned)(l1_blocked_edge_offset_floats(h, w, pad) * sizeof(float));
+            fly.l1_P = pad;
+            fly.l1_d0 = d_begin;
+            float* Bc = c.get<float>((size_t)batch * (F / 8) * l1_blocked_b_floats(h, w));
+            float* Hx = c.get<float>((size_t)batch * (F / 8) * l1_blocked_h_floats(h, w, pad, d_count));
+            fly.l1B = Bc;
+            fly.l1H = Hx;
+            on_the_fly = true;
+            if (!c.plan)
+                c.run(launch_l1_blocked(y4.raw, corr, corr0, Bc, Hx, batch, F, h, w, pad, d_begin, d_count, c.s));
+        }
         if (!c.plan) {
-            c.run(launch_l1_combine(y4.raw, corr, corr0, t1.raw, partials, batch, F, h, w, d_begin, d_count, c.s));
+            // (on the fly: statistics only -- t1 itself is never stored; its buffer is still the home of the first residual sum)
+            c.run(launch_l1_combine(y4.raw, corr, corr0, on_the_fly ? nullptr : t1.raw, partials, batch, F, h, w, d_begin,
+                                    d_count, c.s));
             c.run(launch_in_finalize(partials, groups, tiles, (double)h * w, P.blocks[0].gamma, P.blocks[0].beta, F,
                                      d_count, t1.scale, t1.shift, t1.mean, t1.rstd, c.s, t1.bound));
         }
     }
-    DT t2 = conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1);
+    DT t2 = on_the_fly ? conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &fly)
+                       : conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1);
     if (P.residual_blocks == 1) {
         conv_block(c, t2.src(), none, g, P.last, P.signature_features, 1, 1, 1, signatures, true, nullptr, nullptr,
                    &l0);
@@ -748,24 +806,6 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
         c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur.raw, c.s, cur.bound));
     float* spare_a = t2.raw;                        // free from here on
     float* spare_b = c.get<float>(g.numel());
-    // Channel-blocked activations between the 64-channel layers (round 5; conv2d_x3.hip: X3Args::in_cb8): level 1 = the
-    // tensor between the two convolutions of a residual block (produced and consumed by conv2d_x3 alone)
-    const int cb8_level = [&]() {
-        static const int level = []() {   // PDS_MATCHING_CB8=0: planar NCDHW everywhere (A/B, tests)
-            const char* e = debug_switch("PDS_MATCHING_CB8");
-            return e ? atoi(e) : 1;
-        }();
-        if (!(F == 64 && h % 16 == 0 && w % 16 == 0)) return 0;
-        ConvLayer probe;   // would conv2d_x3 serve these layers in its fp16 form (PDS_X3 / PDS_X3_FP16 may say no)?
-        probe.a = plain_src(nullptr);
-        probe.a.bounded = 1;
-        probe.b = no_src();
-        probe.in = g;
-        probe.out_g = g;
-        probe.kd = 1;
-        probe.stride = 1;
-        return conv2d_x3_cb8_ok(probe, true, true) ? level : 0;
-    }();
     for (int r = 1; r < P.residual_blocks; ++r) {
         ConvExtra blocked;
         blocked.out_cb8 = cb8_level >= 1;

@@ -176,6 +176,12 @@ struct ConvLayer {
     int plane_weight_sets = 0;
     PackSink* sink = nullptr;  // nullptr: pack inline
     int out_cb8 = 0;           // conv2d_x3 only: write the output channel-blocked (Src::cb8)
+    // conv2d_x3 only: the input is LeakyReLU(B + shift_d(H)) of the layer-1 factorisation, formed while it is staged from the
+    // channel-blocked planes of misc.hip: launch_l1_blocked (X3Args::l1B); `a` then carries only the deferred InstanceNorm
+    const float* l1B = nullptr;
+    const float* l1H = nullptr;
+    unsigned l1_bstride = 0, l1_hstride = 0, l1_edge = 0;
+    int l1_P = 0, l1_d0 = 0;
 };
 
 // direct VALU convolution, any channel count
@@ -300,6 +306,13 @@ int launch_l1_column_terms(const float* G, const float* G2, const float* wcol, f
                            int d_count, hipStream_t s);
 int launch_l1_weights2(const float* w1, const float* b1, float* w2, float* bias2, int cout, int channels,
                        hipStream_t s);
+// layer-1 planes B / H (y4 [n][C][2][h][w + 2]) + column corrections -> the channel-blocked form conv2d_x3 stages its first
+// launch from (ConvLayer::l1B): sizes in floats per (batch entry, channel group); pad = zero columns left of H
+__host__ __device__ size_t l1_blocked_b_floats(int h, int w);
+__host__ __device__ size_t l1_blocked_h_floats(int h, int w, int pad, int d_count);
+__host__ __device__ size_t l1_blocked_edge_offset_floats(int h, int w, int pad);
+int launch_l1_blocked(const float* y4, const float* corr, const float* corr0, float* Bc, float* Hx, int batch, int channels,
+                      int h, int w, int pad, int d_begin, int d_count, hipStream_t s);
 
 // small utility: zero-pad one column on the left ([.., w] -> [.., w+1]); split conv0 weights
 int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_t s);

@@ -116,6 +116,13 @@ struct X3Args {
     // ONE run of 34 x 32 bytes instead of eight 136-byte segments in eight channel planes.  Private to the fused
     // Matching chain (l1_combine -> conv2d_x3 x 3 -> materialize_l0 -> conv2d_t8w), see matching_pipeline (api.hip).
     int in_cb8, out_cb8;
+    // Input formed on the fly from the layer-1 planes of the fused Matching path (misc.hip: l1_blocked_kernel; replaces the
+    // 425 MB round trip through l1_combine's t1): B [n][C / 8]{[H][W + 2][8]} and H [n][C / 8]{[H][l1_P + W + 2][8] zero-padded on
+    // the left | edge columns [D][H][2][8]}; group strides and the edge block's offset in bytes; l1_d0: disparity of plane 0
+    const float* __restrict__ l1B;
+    const float* __restrict__ l1H;
+    unsigned l1_bstride, l1_hstride, l1_edge;
+    int l1_P, l1_d0;
     // fp16 form: the power-of-two operand scales (header comment).  ascale is computed by every workgroup from the
     // source's range certificate, 1 / ws was left behind the tile-queue counters by the weight packing.
     const float* __restrict__ bound;
@@ -129,7 +136,7 @@ struct Tile {
 
 // the sixteen channels of a K-step that a staging thread requests for its pixel: sixteen dword loads from sixteen channel
 // planes, or (channel-blocked input) four 16-byte loads from the two groups of eight
-template <bool CBI>
+template <int CBI>
 struct X3In {
     float v[16];
     __device__ __forceinline__ float get(int c) const { return v[c]; }
@@ -139,12 +146,29 @@ struct X3In {
     }
 };
 template <>
-struct X3In<true> {
+struct X3In<1> {
     f32x4 q[4];
     __device__ __forceinline__ float get(int c) const { return q[c >> 2][c & 3]; }
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+// layer-1 planes (round 5, X3Args::l1B): t1 = LeakyReLU(B[x] + H[x - d]) is formed while it is staged -- the B and the H
+// values of the pixel's sixteen channels, channel-blocked, eight 16-byte loads
+template <>
+struct X3In<2> {
+    f32x4 q[4], h[4];
+    __device__ __forceinline__ float get(int c) const {   // exactly l1_combine_kernel's arithmetic (misc.hip)
+        float v, m;
+        asm("v_add_f32 %0, %1, %2" : "=v"(v) : "v"(q[c >> 2][c & 3]), "v"(h[c >> 2][c & 3]));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(m) : "v"(v), "v"(kLeakySlope));
+        asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(m));   // == v > 0 ? v : slope * v for 0 < slope < 1
+        return v;
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = h[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 };
 
@@ -576,7 +600,7 @@ __device__ __forceinline__ void x3_mfma_waves(const X3Args& A, unsigned char* ld
 // two whole stages to land (global latency under load is ~2 us, about one stage; with a one-stage lag every stage
 // began by waiting for the loads issued at the end of the previous one).  The stage loop is unrolled by two so that
 // the set index is a compile-time constant; a stage body is one function that also does the end-of-tile bookkeeping.
-template <int P, bool NORM, bool CBI>
+template <int P, bool NORM, int CBI>
 __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char* lds, int st, int cur_id) {
     using C = X3Cfg<P>;
     constexpr int W_ITERS = C::W_ITERS, W_STAGE = C::W_STAGE, IN_BUF = C::IN_BUF;
@@ -608,12 +632,40 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     // kSetLoads = loads every stage issues: 2 coefficients (NORM), 16 inputs, W_ITERS weight pieces; a wait for "at most
     // kSetLoads outstanding" therefore covers the whole older set (vector-memory results return in order; other
     // memory operations in between only make the wait stricter).
-    constexpr int kInLoads = CBI ? 4 : 16;
+    constexpr int kInLoads = CBI == 2 ? 8 : (CBI == 1 ? 4 : 16);
     constexpr int kSetLoads = kInLoads + W_ITERS + (NORM ? 2 : 0);
     auto request_inputs = [&](X3In<CBI>& x, const Tile& tl, int ks, int third) {
         const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
         const int yc = min(max(y, 0), A.H - 1), xc = min(max(xx, 0), A.W - 1);
-        if constexpr (CBI) {
+        if constexpr (CBI == 2) {
+            // B at column x + 2 of its row; H[x - d] at column x - d + 2 + l1_P of the zero-padded row (0 for x - d < -2), or,
+            // where l1_combine adds a column correction (x = 0 at d = 0; x = w - 2, w - 1 at d >= 1), the edge entry that
+            // holds H + correction: a per-lane choice of the offset, the same eight loads for every lane
+            const int dd = A.l1_d0 + tl.d;
+            const bool edge = dd == 0 ? xc == 0 : xc >= A.W - 2;
+            const int slot = dd == 0 ? 0 : xc - (A.W - 2);
+            const unsigned boffB = (unsigned)(yc * (A.W + 2) + xc + 2) * 32u;
+            const unsigned boffH = edge ? A.l1_edge + (unsigned)((tl.d * A.H + yc) * 2 + slot) * 32u
+                                        : (unsigned)(yc * (A.l1_P + A.W + 2) + xc - dd + 2 + A.l1_P) * 32u;
+            const unsigned long long bb = reinterpret_cast<unsigned long long>(A.l1B) +
+                                          (unsigned long long)(tl.n * (A.Cin >> 3) + 2 * ks) * A.l1_bstride;   // uniform
+            const unsigned long long hb = reinterpret_cast<unsigned long long>(A.l1H) +
+                                          (unsigned long long)(tl.n * (A.Cin >> 3) + 2 * ks) * A.l1_hstride;
+            const unsigned b_lo = (unsigned)bb, b_hi = (unsigned)(bb >> 32), h_lo = (unsigned)hb, h_hi = (unsigned)(hb >> 32);
+            asm volatile("s_mov_b32 s60, %10\n\ts_mov_b32 s61, %11\n\t"
+                         "global_load_dwordx4 %0, %8, s[60:61]\n\tglobal_load_dwordx4 %1, %8, s[60:61] offset:16\n\t"
+                         "s_add_u32 s60, s60, %14\n\ts_addc_u32 s61, s61, 0\n\t"
+                         "global_load_dwordx4 %2, %8, s[60:61]\n\tglobal_load_dwordx4 %3, %8, s[60:61] offset:16\n\t"
+                         "s_mov_b32 s60, %12\n\ts_mov_b32 s61, %13\n\t"
+                         "global_load_dwordx4 %4, %9, s[60:61]\n\tglobal_load_dwordx4 %5, %9, s[60:61] offset:16\n\t"
+                         "s_add_u32 s60, s60, %15\n\ts_addc_u32 s61, s61, 0\n\t"
+                         "global_load_dwordx4 %6, %9, s[60:61]\n\tglobal_load_dwordx4 %7, %9, s[60:61] offset:16"
+                         : "=&v"(x.q[0]), "=&v"(x.q[1]), "=&v"(x.q[2]), "=&v"(x.q[3]), "=&v"(x.h[0]), "=&v"(x.h[1]),
+                           "=&v"(x.h[2]), "=&v"(x.h[3])
+                         : "v"(boffB), "v"(boffH), "s"(b_lo), "s"(b_hi), "s"(h_lo), "s"(h_hi), "s"(A.l1_bstride),
+                           "s"(A.l1_hstride)
+                         : "memory", "s60", "s61", "scc");
+        } else if constexpr (CBI == 1) {
             // groups 2 ks and 2 ks + 1 of plane (n, d) of [N][D][C / 8][H][W][8]: the pixel's 32 bytes in each, two 16-byte
             // loads per group -- the base walks in s[60:61] as below
             const float* src = A.a.p + (((size_t)(tl.n * A.D + tl.d) * (A.Cin >> 3) + 2 * ks) * plane) * 8;   // uniform
@@ -651,7 +703,12 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     // every value of a set passes through this statement before its first use: the wait cannot be scheduled after a
     // consumer, and no consumer before it
     auto await_set = [&](X3In<CBI>& x, u32x4 (&w)[W_ITERS], float& cs, float& ch) {
-        if constexpr (CBI) {
+        if constexpr (CBI == 2) {
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]), "+v"(x.h[0]), "+v"(x.h[1]), "+v"(x.h[2]), "+v"(x.h[3])
+                         : "n"(kSetLoads)
+                         : "memory");
+        } else if constexpr (CBI == 1) {
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]) : "n"(kSetLoads) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(%16)"
@@ -830,7 +887,12 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     int nxt_id = -1;
     int tpar = 0;             // coefficient table of the current tile
     auto await_all = [&](X3In<CBI>& x, u32x4 (&w)[W_ITERS], float& cs, float& ch) {
-        if constexpr (CBI) {
+        if constexpr (CBI == 2) {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]), "+v"(x.h[0]), "+v"(x.h[1]), "+v"(x.h[2]), "+v"(x.h[3])
+                         :
+                         : "memory");
+        } else if constexpr (CBI == 1) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]) : : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)"
@@ -937,7 +999,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
 
 }  // namespace
 
-template <int P, bool NORM, bool CBI, bool CBO>
+template <int P, bool NORM, int CBI, bool CBO>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -1010,7 +1072,7 @@ static bool x3_use_fp16(const ConvLayer& L) {
     return enabled && L.a.bounded;
 }
 
-template <int P, bool CBI, bool CBO>
+template <int P, int CBI, bool CBO>
 static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t s) {
     using C = X3Cfg<P>;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
@@ -1098,14 +1160,26 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     const int workgroups = (int)(all < cus[dev & 31] ? all : cus[dev & 31]);
     A.in_cb8 = L.a.cb8;
     A.out_cb8 = L.out_cb8;
+    A.l1B = L.l1B;
+    A.l1H = L.l1H;
+    A.l1_bstride = L.l1_bstride;
+    A.l1_hstride = L.l1_hstride;
+    A.l1_edge = L.l1_edge;
+    A.l1_P = L.l1_P;
+    A.l1_d0 = L.l1_d0;
+    if (L.l1B) {   // layer-1 planes formed on the fly (always behind the deferred InstanceNorm of t1)
+        if (!fp16 || !L.a.scale || A.in_cb8 || !conv2d_x3_cb8_ok(L, true, A.out_cb8 != 0))
+            return set_error(-1, "conv2d_x3: the layer-1 source needs the fp16 form, a deferred InstanceNorm and whole tiles");
+        return A.out_cb8 ? x3_launch<2, 2, true>(L, A, workgroups, s) : x3_launch<2, 2, false>(L, A, workgroups, s);
+    }
     if (A.in_cb8 || A.out_cb8) {
         if (!fp16 || !conv2d_x3_cb8_ok(L, A.in_cb8, A.out_cb8))
             return set_error(-1, "conv2d_x3: channel-blocked tensors need the fp16 form and whole 16 x 16 tiles");
-        if (A.in_cb8 && A.out_cb8) return x3_launch<2, true, true>(L, A, workgroups, s);
-        if (A.in_cb8) return x3_launch<2, true, false>(L, A, workgroups, s);
-        return x3_launch<2, false, true>(L, A, workgroups, s);
+        if (A.in_cb8 && A.out_cb8) return x3_launch<2, 1, true>(L, A, workgroups, s);
+        if (A.in_cb8) return x3_launch<2, 1, false>(L, A, workgroups, s);
+        return x3_launch<2, 0, true>(L, A, workgroups, s);
     }
-    return fp16 ? x3_launch<2, false, false>(L, A, workgroups, s) : x3_launch<3, false, false>(L, A, workgroups, s);
+    return fp16 ? x3_launch<2, 0, false>(L, A, workgroups, s) : x3_launch<3, 0, false>(L, A, workgroups, s);
 }
 
 }  // namespace pds

@@ -620,7 +620,9 @@ __device__ __forceinline__ float l1_row16_sum(float v) {
 
 // COLS: y4 holds only the planes B and H ([n][C][2][h][w+2]); the special columns arrive as corrections to H
 // (l1_column_terms_kernel: corr [nc][h][d_count][2], corr0 [nc][h]).
-template <bool COLS>
+// STORE = false: statistics only (round 5: conv2d_x3's first launch forms t1 on the fly from the blocked planes below; the
+// records must be the ones this kernel would have written beside t1, bit for bit)
+template <bool COLS, bool STORE = true>
 __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict__ y4, const float* __restrict__ corr,
                                                          const float* __restrict__ corr0, float* __restrict__ t1,
                                                          double* __restrict__ partials, int C, int h, int w,
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
             }
             r[k] = v;
         }
-        if (active) {
+        if (STORE && active) {
             float* o = t1 + ((size_t)nc * d_count + dl) * px + (size_t)y * w + xb;
             if (vec) {
                 // non-temporal: a write-only stream of 418 MB (125 -> 109 us; the consuming conv2d_x3 launch is unchanged)
@@ -732,6 +734,74 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
     }
 }
 
+// ---- the layer-1 planes, channel-blocked for conv2d_x3's staging (round 5) --------------------------------------------
+// per (batch entry, channel group of 8):
+//   Bc  [h][w + 2][8]                     Bc[y][x + 2] = B[c][y][x]                            (y4's own column convention)
+//   Hx  [h][pad + w + 2][8]               Hx[y][u + 2 + pad] = H[c][y][u] for u >= -2, zero to the left of it
+//       [d_count][h][2][8]  "edge"        what l1_combine_kernel adds a column correction to:
+//                                           plane d == 0:  entry 0 = H[0] + corr0                       (x = 0)
+//                                           plane d >= 1:  entry s = (u >= -2 ? H[u] : 0) + corr[s],  u = w - 2 + s - d
+__host__ __device__ size_t l1_blocked_b_floats(int h, int w) { return (size_t)h * (w + 2) * 8; }
+__host__ __device__ size_t l1_blocked_edge_offset_floats(int h, int w, int pad) { return (size_t)h * (pad + w + 2) * 8; }
+__host__ __device__ size_t l1_blocked_h_floats(int h, int w, int pad, int d_count) {
+    return l1_blocked_edge_offset_floats(h, w, pad) + (size_t)d_count * h * 2 * 8;
+}
+
+__global__ __launch_bounds__(256) void l1_blocked_kernel(const float* __restrict__ y4, const float* __restrict__ corr,
+                                                         const float* __restrict__ corr0, float* __restrict__ Bc,
+                                                         float* __restrict__ Hx, int C, int h, int w, int pad, int d_begin,
+                                                         int d_count) {
+    // grid: x = items of one (batch entry, channel group), y = batch entry * groups + group; one thread = one 32-byte slot
+    const int W2 = w + 2, HW = pad + w + 2;
+    const int nb = h * W2, nh = h * HW, ne = d_count * h * 2;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= nb + nh + ne) return;
+    const int ng = blockIdx.y, groups = C / 8, n = ng / groups, g = ng % groups;
+    const size_t plane = (size_t)h * W2;
+    const float* Bp = y4 + ((size_t)(n * C + g * 8) * 2) * plane;   // channel stride 2 planes
+    const float* Hp = Bp + plane;
+    float v[8];
+    float* dst;
+    if (item < nb) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = Bp[(size_t)c * 2 * plane + item];
+        dst = Bc + (size_t)ng * l1_blocked_b_floats(h, w) + (size_t)item * 8;
+    } else if (item < nb + nh) {
+        const int i = item - nb, y = i / HW, j = i % HW;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = j >= pad ? Hp[(size_t)c * 2 * plane + (size_t)y * W2 + (j - pad)] : 0.f;
+        dst = Hx + (size_t)ng * l1_blocked_h_floats(h, w, pad, d_count) + (size_t)i * 8;
+    } else {
+        const int i = item - nb - nh, slot = i & 1, y = (i >> 1) % h, dl = (i >> 1) / h, d = d_begin + dl;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const size_t nc = (size_t)n * C + g * 8 + c;
+            const float* hrow = Hp + (size_t)c * 2 * plane + (size_t)y * W2;
+            float t = 0.f;
+            if (d == 0) {
+                if (slot == 0) t = hrow[2] + corr0[nc * h + y];
+            } else {
+                const int u = w - 2 + slot - d;
+                t = (u >= -2 ? hrow[u + 2] : 0.f) + corr[((nc * h + y) * d_count + dl) * 2 + slot];
+            }
+            v[c] = t;
+        }
+        dst = Hx + (size_t)ng * l1_blocked_h_floats(h, w, pad, d_count) + l1_blocked_edge_offset_floats(h, w, pad) +
+              (size_t)i * 8;
+    }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<f32x4*>(dst)[0] = f32x4{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<f32x4*>(dst)[1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+int launch_l1_blocked(const float* y4, const float* corr, const float* corr0, float* Bc, float* Hx, int batch, int channels,
+                      int h, int w, int pad, int d_begin, int d_count, hipStream_t s) {
+    const int items = h * (w + 2) + h * (pad + w + 2) + d_count * h * 2;
+    hipLaunchKernelGGL(l1_blocked_kernel, dim3((items + 255) / 256, batch * (channels / 8)), dim3(256), 0, s, y4, corr, corr0,
+                       Bc, Hx, channels, h, w, pad, d_begin, d_count);
+    return check_launch("l1_blocked");
+}
+
 int launch_l1_stack_inputs(const float* y3, float* x4, int batch, int channels, int h, int w, hipStream_t s) {
     const size_t total = (size_t)batch * 2 * channels * kL1Planes * h * (w + 2);
     unsigned bx = (unsigned)((total + 255) / 256);
@@ -758,7 +828,10 @@ int launch_l1_combine(const float* y4, const float* corr, const float* corr0, fl
     for (int first = 0; first < d_count; first += kL1MaxPlanes) {
         const int n = d_count - first < kL1MaxPlanes ? d_count - first : kL1MaxPlanes;
         const dim3 grid(l1_combine_tiles(h, w), batch * channels);
-        if (corr)
+        if (corr && !t1)
+            hipLaunchKernelGGL((l1_combine_kernel<true, false>), grid, dim3(256), 0, s, y4, corr, corr0, t1, partials,
+                               channels, h, w, d_begin, first, n, d_count);
+        else if (corr)
             hipLaunchKernelGGL(l1_combine_kernel<true>, grid, dim3(256), 0, s, y4, corr, corr0, t1, partials, channels, h,
                                w, d_begin, first, n, d_count);
         else

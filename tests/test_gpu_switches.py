@@ -101,3 +101,13 @@ def test_switches_are_ignored_without_the_debug_gate(hip_library):
         assert out.returncode == 0, text[-2000:]
         launches = int([t for t in text.splitlines() if t.startswith('PROBE')][-1].split()[1])
         assert (launches > 0) == expect_x3, (gate, launches)
+
+
+def test_channel_blocked_levels_are_bit_identical(hip_library):
+    """PDS_MATCHING_CB8 = 0 (planar), 1 (default: blocked tensor inside a residual block), 2 (+ the first 64 -> 64 launch fed
+    from the blocked layer-1 planes): the same products in the same order, so the signatures are equal bit for bit at
+    config-2, config-1 (batch 2) and config-4 plane shapes (tools/cb8_check.py spawns one process per level)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'cb8_check.py'), '0', '1', '2'], cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode(errors='replace')
+    assert out.returncode == 0 and 'IDENTICAL' in text, text[-2000:]
