@@ -369,16 +369,14 @@ constexpr float kHalfTarget = 16384.f;   // scaled operands stay below 2^14 (fp1
 
 // ---- two-way fp16 split of fp32 values (the operands of the fp16-split MFMA kernels) ---------------------------------
 // hi = fp16(r), lo = fp16(r - hi), both round-to-nearest-even; a PAIR at a time with the packed conversion of gfx950
-// (conv2d_x3.hip, round 4): 6 instructions per pair instead of the 4 conversions + 2 subtractions + 2 packs of the scalar
+// (conv2d_x3.hip, round 4): 3 instructions per pair instead of the 4 conversions + 2 subtractions + 2 packs of the scalar
 // form, bit-identical results.  The packed words hold element 0 in their low half.
 __device__ __forceinline__ void split_pair_f16(float r0, float r1, unsigned& hi, unsigned& lo) {
-    float f0, f1, d0, d1;
+    // (the low parts straight from the mixed-precision fma: lo = f16(r - hi), hi read as the fp16 half it is; r - hi is exact in
+    // fp32, so the only rounding is the conversion -- 3 instructions per pair)
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(r0), "v"(r1));
-    asm("v_cvt_f32_f16 %0, %1" : "=v"(f0) : "v"(hi));
-    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(hi));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(r0), "v"(f0));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(r1), "v"(f1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(r0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(r1));
 }
 typedef unsigned pds_u32x2 __attribute__((ext_vector_type(2)));
 // four values -> the 8 bytes of hi parts and the 8 bytes of lo parts

@@ -754,14 +754,23 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
                 r0 = inimg ? r0 : 0.f;
                 r1 = inimg ? r1 : 0.f;
                 unsigned hi, lo;
-                float f0, f1;
                 asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(r0), "v"(r1));
+#ifdef PDS_X3_SPLIT_CVT   // (round-4 form: widen the halves again, subtract, convert the pair -- 5 instructions for the low parts)
+                float f0, f1;
                 asm("v_cvt_f32_f16 %0, %1" : "=v"(f0) : "v"(hi));
                 asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(hi));
                 float d0, d1;
                 asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(r0), "v"(f0));
                 asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(r1), "v"(f1));
                 asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+#else
+                // round 5: the low part straight from the mixed-precision fma -- lo = f16(r - hi) with hi read as the fp16
+                // half it is (r - hi is exact in fp32, so the one rounding is the conversion: bit-identical), 2 instructions.
+                // Same-box A/B against the five-instruction form and against a select-free copy of the loop for tiles whose
+                // halo lies inside the image: all three within noise (the launch does not care about staging VALU counts)
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(r0));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(r1));
+#endif
                 whi[pr >> 2][pr & 3] = hi;
                 wlo[pr >> 2][pr & 3] = lo;
             }
