@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dz, double* __restrict__ bias_partial,
                                                            float* __restrict__ dz_amax) {
     const int nc = blockIdx.z, d = blockIdx.y;
-    float seen = 0.f;
+    float seen = 0.f, poison = 0.f;
     const int c = nc % geom.c;
     const int grp = per_plane ? nc * geom.d + d : nc;
     const float mu = mean[grp], r = rstd[grp], a = gamma[c] * r, b1 = m1[grp], b2 = m2[grp];
@@ -133,11 +133,12 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
         dz[base + i] = v;
         sum += v;
         seen = fmaxf(seen, fabsf(v));
+        poison = fmaf(v, 0.f, poison);   // NaN / inf stick (fmaxf alone drops a NaN): ADVICE r4
     }
     __shared__ double red[4];
     __shared__ float redmax[4];
     const double ws = wave_sum((double)sum);
-    if (dz_amax) seen = wave_max(seen == seen ? seen : __builtin_inff());
+    if (dz_amax) seen = wave_max(poison == poison ? seen : __builtin_inff());
     if ((threadIdx.x & 63) == 0) {
         red[threadIdx.x >> 6] = ws;
         redmax[threadIdx.x >> 6] = seen;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kPlaneThreads) void in_bwd_plane_kernel(const float
     const double count = (double)geom.plane();
     const float mu = mean[grp], r = rstd[grp], a = gamma[c] * r;
     const float b1 = (float)(tot[0] / count), b2 = (float)(tot[1] / count);
-    float seen = 0.f;
+    float seen = 0.f, poison = 0.f;
     f32x4* o4 = reinterpret_cast<f32x4*>(dz + base);
 #pragma unroll
     for (int k = 0; k < kPlaneQuads; ++k) {
@@ -281,10 +282,13 @@ __global__ __launch_bounds__(kPlaneThreads) void in_bwd_plane_kernel(const float
         if (q < quads) {
             o4[q] = v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) seen = fmaxf(seen, fabsf(v[e]));
+            for (int e = 0; e < 4; ++e) {
+                seen = fmaxf(seen, fabsf(v[e]));
+                poison = fmaf(v[e], 0.f, poison);
+            }
         }
     }
-    if (dz_amax) seen = wave_max(seen == seen ? seen : __builtin_inff());
+    if (dz_amax) seen = wave_max(poison == poison ? seen : __builtin_inff());
     if (lane == 0) redmax[wave] = seen;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
                                                              int l0_rs, int d_begin, float* __restrict__ out,
                                                              float* __restrict__ amax) {
     __shared__ float red[16];
-    float seen = 0.f;
+    float seen = 0.f, poison = 0.f;
     // grid: x = tile over (y, x/4), y = d, z = n*C + c
     const int nc = blockIdx.z, d = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
@@ -554,7 +554,10 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
                 x0v += (x == g.w - 1 && disp >= 1) ? pG2[off] : pG[off];
             }
             r[k] = fmaf(sa, av[k], ha) + x0v;
-            if (x < g.w) seen = fmaxf(seen, fabsf(r[k]));
+            if (x < g.w) {
+                seen = fmaxf(seen, fabsf(r[k]));
+                poison = fmaf(r[k], 0.f, poison);   // NaN / inf stick (fmaxf alone drops a NaN): ADVICE r4
+            }
         }
         if (vec) {
             *reinterpret_cast<float4*>(po + i) = make_float4(r[0], r[1], r[2], r[3]);
@@ -564,7 +567,9 @@ __global__ __launch_bounds__(256) void materialize_l0_kernel(const Src a, const 
                 if (x0 + k < g.w) po[i + k] = r[k];
         }
     }
-    if (amax) block_amax_record(seen, amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
+    if (amax)
+        block_amax_record(poison == poison ? seen : __builtin_inff(),
+                          amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
 }
 
 // Plane-sweeping form of the above for rows that are a multiple of 4 wide: one thread owns four consecutive x of
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
                                                                    int l0_rs, int d_begin, float* __restrict__ out,
                                                                    float* __restrict__ amax) {
     __shared__ float red[16];
-    float seen = 0.f;
+    float seen = 0.f, poison = 0.f;
     const int nc = blockIdx.y;
     const int n = nc / g.c, c = nc % g.c;
     const size_t px = g.plane();
@@ -630,7 +635,10 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
             const float4 r = make_float4(fmaf(sa, t[j].x, ha) + (lv[0] + gw[0]), fmaf(sa, t[j].y, ha) + (lv[1] + gw[1]),
                                          fmaf(sa, t[j].z, ha) + (lv[2] + gw[2]), fmaf(sa, t[j].w, ha) + (lv[3] + g3));
             if (active) *reinterpret_cast<float4*>(po + (size_t)d * px) = r;
-            seen = fmaxf(fmaxf(seen, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            if (active) {   // (shadow threads of the last workgroup repeat the last quad: not part of the record)
+                seen = fmaxf(fmaxf(seen, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+                poison = fmaf(r.x + r.y + r.z + r.w, 0.f, poison);   // a NaN / inf anywhere makes the record +inf
+            }
             // slide the window to disparity disp + 1
             const float from_left = __builtin_bit_cast(
                 float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw[3]), 0x138, 0xf, 0xf, true));
@@ -644,8 +652,7 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
             }
         }
     }
-    // (fmaxf drops NaNs: a NaN anywhere in the sum also shows in the statistics of the layers behind it)
-    if (amax) block_amax_record(seen, amax + (size_t)blockIdx.y * gridDim.x + blockIdx.x, red);
+    if (amax) block_amax_record(poison == poison ? seen : __builtin_inff(), amax + (size_t)blockIdx.y * gridDim.x + blockIdx.x, red);
 }
 
 static dim3 materialize_l0_grid(const Geom& g) {

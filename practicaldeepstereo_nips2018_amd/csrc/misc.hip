@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void l0_combine_kernel(const float* __restrict
                                                          float* __restrict__ x0, int C, int h, int w,
                                                          int d_begin, int d_count, float* __restrict__ amax) {
     __shared__ float red[16];
-    float seen = 0.f;   // largest |x0| of this thread: the range certificate of the plain result (Src::bound)
+    float seen = 0.f, poison = 0.f;   // largest |x0| of this thread: the range certificate of the plain result (Src::bound)
     // grid: x = row tile, y = local disparity, z = b*C + c
     const int bc = blockIdx.z, dl = blockIdx.y;
     const int d = d_begin + dl;
@@ -80,10 +80,11 @@ __global__ __launch_bounds__(256) void l0_combine_kernel(const float* __restrict
                 t += (x == w - 1 && d >= 1 && u >= -1) ? g2[(size_t)y * (w + 1) + (u + 1)] : gv;
                 v[e] = t;
                 seen = fmaxf(seen, fabsf(t));
+                poison = fmaf(t, 0.f, poison);   // NaN / inf stick (fmaxf alone drops a NaN)
             }
             *reinterpret_cast<f32x4*>(dst + (size_t)y * w + xb) = v;
         }
-        if (amax) block_amax_record(seen, amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
+        if (amax) block_amax_record(poison == poison ? seen : __builtin_inff(), amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
         return;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < px; i += (size_t)gridDim.x * 256) {
@@ -96,8 +97,9 @@ __global__ __launch_bounds__(256) void l0_combine_kernel(const float* __restrict
         }
         dst[i] = v;
         seen = fmaxf(seen, fabsf(v));
+        poison = fmaf(v, 0.f, poison);
     }
-    if (amax) block_amax_record(seen, amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
+    if (amax) block_amax_record(poison == poison ? seen : __builtin_inff(), amax + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
 }
 
 // one workgroup per (batch entry, channel, plane): the amax records (one per workgroup) stay a few thousand
