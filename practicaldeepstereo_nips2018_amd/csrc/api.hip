@@ -1091,6 +1091,15 @@ static void backward_walk(Ctx& c, const Tape& T, const GradMap& M, std::vector<f
         // consume acc.  The residual blocks have exactly this shape (ro = the block's last convolution, acc = its input):
         // a 425 MB copy per residual sum / two-source layer of Matching.
         auto route_pair = [&](int a, int b, const float* grad_in, const Geom& in_g, bool mine) {
+            // `mine` also requires that no OTHER tape tensor still owns this buffer as its gradient with its producer yet to
+            // be processed (an earlier share, `dhat[b] = dhat[a]` below): taking the buffer over and accumulating into it
+            // would corrupt that tensor's gradient.  The Matching / Regularization / Embedding tapes never form that shape;
+            // the check turns the topological assumption into a rule -- such a buffer is copied, not adopted (run
+            // walks only: planning walks carry marker pointers.  A tape that did trigger it would need more arena than planned
+            // and fail loudly with the overflow error).
+            if (mine && grad_in && !c.plan)
+                for (size_t id = 0; id < T.tensors.size(); ++id)
+                    if ((int)id != L.out && dhat[id] == grad_in && producer[id] >= 0 && producer[id] < li) mine = false;
             auto fresh = [&](int id) {
                 return mine && id >= 0 && T.tensors[id].needs_grad && !T.tensors[id].bcast_d && !dhat[id] && !written[id];
             };
