@@ -15,7 +15,7 @@ for a, b in (('bench_line.json', 'bench_line.json'), ('kernels_seq.txt', 'kernel
              ('train_step_kernels.txt', 'train_step_kernels.txt')):
     shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
 blocks = re.split(r'\n(?=\S)', open(os.path.join(dst, tag + '_pmc_all_kernels.txt')).read())
-block = [b for b in blocks if 'conv2d_x3_kernel<2, true, false, false>' in b.split('\n')[0] and '131072' in b.split('\n')[0]][0]
+block = [b for b in blocks if 'conv2d_x3_kernel<2, true, 0, false>' in b.split('\n')[0] and '131072' in b.split('\n')[0]][0]
 values = {m.group(1): float(m.group(2)) for m in re.finditer(r'^\s+(\w+)\s+([\d.e+]+)\s*$', block, re.M)}
 path = os.path.join(dst, tag + '_conv64_pmc.json')
 if not os.path.exists(path):   # the fixed fields (correction rule, algorithmic bytes) carry over from the last round
