@@ -236,6 +236,29 @@ def test_fused_regularization_estimator_matches_unfused(dev):
     assert helpers.disparity_report(fused, unfused)['mae'] <= TOL_DISPARITY_MAE
 
 
+@pytest.mark.parametrize('half_support_window,step', [(2, 2), (4, 2), (6, 2), (8, 2)])
+def test_fused_estimator_support_windows(dev, half_support_window, step):
+    """The fused upsample + sub-pixel MAP kernel has one instantiation per window half-width T = window // step in
+    {1, 2, 4} (different register rings and unroll factors; T = 3 runs on the T = 4 build): every one against the
+    stand-alone estimator on the cost volume of the same sweep, and against the oracle (estimator.py:45-91)."""
+    g = helpers.golden('g3_regularization')
+    reg = helpers.seeded(pds.Regularization).to(dev)
+    est = pds.SubpixelMap(half_support_window, step)
+    gen = torch.Generator().manual_seed(77)
+    signatures = torch.randn(2, 8, 16, 32, 48, generator=gen).to(dev)
+    shortcut = torch.randn(2, 8, 32, 48, generator=gen).to(dev)
+    with torch.no_grad():
+        cost = reg(signatures, shortcut)
+        unfused = est(cost)
+        fused = reg.forward_with_estimator(signatures, shortcut, est)
+    assert fused.shape == unfused.shape == (2, 128, 192)
+    rep = helpers.disparity_report(fused, unfused)
+    assert rep['mae_noflip'] <= 1e-4 and round(rep['flips'] * fused.numel()) <= 2, rep
+    ref = oracle.subpixel_map(cost.cpu(), half_support_window, step)
+    rep = helpers.disparity_report(fused, ref)
+    assert rep['mae_noflip'] <= 1e-4 and round(rep['flips'] * fused.numel()) <= 2, rep
+
+
 # ------------------------------------------------------------------------------- whole hot path
 def hot_path_inputs(maximum_disparity, batch, height, width):
     """SURVEY.md 8c recipe: seed-0 default network, seed-1 images, descriptors computed once on CPU."""
