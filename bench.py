@@ -331,7 +331,7 @@ def cpu_baseline(net, ld, rd, shortcut, gpu_disparity, gpu_signatures=None, gpu_
     return base, parity
 
 
-ALL_CORES_TIMEOUT_S = 75.0
+ALL_CORES_TIMEOUT_S = 45.0
 
 
 def cpu_all_cores(params, ld, rd, shortcut, usable):
