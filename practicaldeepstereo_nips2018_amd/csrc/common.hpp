@@ -124,6 +124,7 @@ struct PackJob {
     int cout = 0, cin = 0, mblocks = 0, kc = 4, taps = 9;
     int mode = 0;                // 0 conv, 1 transposed k4 s2, 2 transposed k(3,4,4) s(1,2,2), 3 conv 3x3 -> F(2,3) along x, 4 conv 3x3 -> F(2x2,3x3) per-lane order,
                                  // 5 transposed k4 s2 in the dense cell form (8 taps)
+                                 // 6 / 7 conv2d_x3 (bf16 x 3 / fp16 x 2 split), 8 / 9 conv3d_ks X form (fp16 x 2 split of modes 0 / 5)
     int total = 0;               // floats in dst
 };
 int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s);

@@ -24,6 +24,15 @@
 //               share the epilogue: bias, LeakyReLU(0.1), store, per-channel statistics -> one record per workgroup.
 //   MODE 2      ConvTranspose3d(k4, s2, p1) in the dense "cell" form of deconv3d_cell.hip: cell c maps its 2x2x2 input
 //               corners to the 2x2x2 outputs 2c + 1 + p through 8 "taps"; virtual channel v = class * Cout + oc.
+//
+// Round 5, template flag X: the same kernel on v_mfma_f32_16x16x16_f16 with split fp32 operands (as conv2d_x3.hip /
+// deconv3d_cell.hip).  PMC of the 32 -> 32 level-2 layer: its four waves per SIMD keep the fp32 matrix pipe busy for 27 600 of
+// their 33 000 cycles (216 MFMAs x 32 cycles each) -- the larger of these layers are fp32-pipe-bound for ~40 % of their time.
+// K = 16 = four input channels x the four x-taps of a kernel row (dx = 0..2 and a zero): one MFMA x three partial products
+// per (dz, dy) covers what three fp32 MFMAs did; in the cell form K = four channels x the (yi, xi) corners, one MFMA per zi.
+// The wave-private LDS region holds [group of 4 channels][part][position][4 x fp16] (the bytes of the fp32 tile), a B
+// fragment is one 8-byte slot (k group = lane >> 4 selects the x-tap / corner).  Operand scales: powers of two from max|w|
+// (pack.hip: pack_wscale_kernel) and from the sources' range certificates (Src::bound); a source without one keeps fp32.
 #include <atomic>
 
 #include "common.hpp"
@@ -33,6 +42,7 @@ namespace pds {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ks_f16x4 __attribute__((ext_vector_type(4)));
 
 struct KsArgs {
     Src a, b;
@@ -46,6 +56,8 @@ struct KsArgs {
     int tiles_x, tiles_y, tiles;
     int mblocks;                     // blocks of 16 (virtual) channels
     int cs;                          // LDS floats per input channel (bank-padded)
+    // X form: the 16-dword tail behind the packed weights (dwords 12, 13: ws, 1 / ws)
+    const float* __restrict__ wtail;
 };
 
 // MODE 0: conv 3x3x3 stride 1; 1: conv 3x3x3 stride 2; 2: transposed conv k4 s2 p1 (cell form)
@@ -73,10 +85,11 @@ __device__ __forceinline__ float ks_row16_sum(float v) {
 }  // namespace
 
 // NKS: groups of four input channels per wave (Cin = 4 NKS KSPLIT)
-template <int MODE, int TZ, int TY, int NB, int MBW, int KSPLIT, int NKS>
+template <int MODE, int TZ, int TY, int NB, int MBW, int KSPLIT, int NKS, bool X = false>
 __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) {
     using G = KsGeom<MODE, TZ, TY, NB>;
     constexpr int S = G::S, R = G::R, NACC = MBW * R * NB;
+    constexpr int TG = MODE == 2 ? 2 : 9;          // X form: MFMA K-steps per group of four channels ((dz, dy) / zi)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -103,8 +116,22 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
 
     // ---- every A fragment of this wave: requested now, consumed after the staging ------------------------------------
     const size_t tap_stride = (size_t)A.mblocks * 64;                       // floats between consecutive taps
-    float af[NKS][G::TAPS][MBW];
-    {
+    float af[X ? 1 : NKS][X ? 1 : G::TAPS][X ? 1 : MBW];
+    pds_u32x2 afx[X ? NKS : 1][X ? TG : 1][X ? MBW : 1][2];                  // X: [group][K-step][block][part], 8 bytes per lane
+    if constexpr (X) {
+        // packed [ic / 4][K-step][block][part][64 lanes][2 dwords] (pack.hip modes 8 / 9)
+        const pds_u32x2* wl = reinterpret_cast<const pds_u32x2*>(A.wpk) +
+                              (((size_t)(c_first >> 2) * TG) * A.mblocks + mb0) * 2 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        afx[ks][t][m][p] = wl[((((size_t)ks * TG + t) * A.mblocks + m) * 2 + p) * 64];
+    } else {
         const float* wl = A.wpk + ((size_t)(c_first >> 2) * G::TAPS) * tap_stride + (size_t)mb0 * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
@@ -112,6 +139,23 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
             for (int t = 0; t < G::TAPS; ++t)
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) af[ks][t][m] = wl[((size_t)ks * G::TAPS + t) * tap_stride + m * 64];
+    }
+    // X: power-of-two operand scales -- as from the sources' range certificates (few records: every wave reduces them
+    // itself, no barrier), 1 / ws from the packed weights' tail
+    float ascale = 1.f, unscale = 1.f;
+    if constexpr (X) {
+        float bm = 0.f, bm2 = 0.f;
+        for (int i = lane; i < A.a.bound_n; i += 64) {
+            const float v = fabsf(A.a.bound[i]);
+            bm = fmaxf(bm, v == v ? v : __builtin_inff());
+        }
+        if (two)
+            for (int i = lane; i < A.b.bound_n; i += 64) {
+                const float v = fabsf(A.b.bound[i]);
+                bm2 = fmaxf(bm2, v == v ? v : __builtin_inff());
+            }
+        ascale = pow2_scale(wave_max(bm) + wave_max(bm2), kHalfTarget);
+        unscale = A.wtail[13] * (1.f / ascale);
     }
 
     // ---- stage this wave's channels: private LDS region [cq][CS] ---------------------------------------------------
@@ -153,6 +197,38 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
                     vb[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, ob, 0, 0));
                 }
             }
+        if constexpr (X) {
+            // [group of 4 channels][part][position][4 x fp16]: the same bytes as the fp32 tile of those channels
+            unsigned char* minex = reinterpret_cast<unsigned char*>(mine);
+            // (coefficients pre-multiplied by the operand scale, in vector registers: measured 36 -> 30 us on the
+            // 32 -> 32 layer against scalar coefficients + one multiply per element)
+            float s1[cq], h1[cq], s2[cq], h2[cq];
+#pragma unroll
+            for (int c = 0; c < cq; ++c) {
+                s1[c] = (sa ? sa[c] : 1.f) * ascale;
+                h1[c] = (sa ? ha[c] : 0.f) * ascale;
+                s2[c] = (sb ? sb[c] : 1.f) * ascale;
+                h2[c] = (sb ? hb[c] : 0.f) * ascale;
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int i = 0; i < PER_CH; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = 4 * ks + k;
+                        float t = fmaf(s1[c], va[c][i], h1[c]);
+                        if (two) t += fmaf(s2[c], vb[c][i], h2[c]);
+                        v[k] = in_[i] ? t : 0.f;
+                    }
+                    pds_u32x2 hi, lo;
+                    split_quad_f16(v, hi, lo);
+                    unsigned char* slot = minex + ((size_t)ks * 2 * G::NPOS + lo_[i]) * 8;
+                    *reinterpret_cast<pds_u32x2*>(slot) = hi;
+                    *reinterpret_cast<pds_u32x2*>(slot + (size_t)G::NPOS * 8) = lo;
+                }
+        } else {
 #pragma unroll
         for (int c = 0; c < cq; ++c) {
             const float s1 = sa ? sa[c] : 1.f, h1 = sa ? ha[c] : 0.f;     // wave-uniform: scalar loads
@@ -164,6 +240,7 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
                 mine[c * A.cs + lo_[i]] = in_[i] ? v : 0.f;
             }
         }
+        }
     }
 
     // ---- K loop: this wave's NKS groups of four channels, all taps ------------------------------------------------------
@@ -174,7 +251,38 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < NB; ++j) acc[m][r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (X) {
+        // B fragment: the 8-byte slot of position (column n = lane & 15 [+ the x-tap / corner of k group lane >> 4])
+        // cell: (yi, xi) = (q >> 1, q & 1); conv: dx = q, and the zero fourth group re-reads dx = 0 (finite data: a slot
+        // past the row could hold the bits of an fp16 infinity, and inf x 0 is not 0)
+        const int kg_off = MODE == 2 ? ((q >> 1) * G::XT + (q & 1)) : (q == 3 ? 0 : q);
+        const unsigned char* bl = reinterpret_cast<const unsigned char*>(mine) + (size_t)(n16 * S + kg_off) * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const int dz = MODE == 2 ? t : t / 3, dy = MODE == 2 ? 0 : t % 3;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int rz = r / TY, ry = r % TY;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const unsigned char* bp =
+                            bl + ((size_t)ks * 2 * G::NPOS + ((rz * S + dz) * G::YT + ry * S + dy) * G::XT + j * 16 * S) * 8;
+                        const ks_f16x4 b_hi = *reinterpret_cast<const ks_f16x4*>(bp);
+                        const ks_f16x4 b_lo = *reinterpret_cast<const ks_f16x4*>(bp + (size_t)G::NPOS * 8);
+#pragma unroll
+                        for (int m = 0; m < MBW; ++m) {
+                            const ks_f16x4 a_hi = __builtin_bit_cast(ks_f16x4, afx[ks][t][m][0]);
+                            const ks_f16x4 a_lo = __builtin_bit_cast(ks_f16x4, afx[ks][t][m][1]);
+                            acc[m][r][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, b_lo, acc[m][r][j], 0, 0, 0);
+                            acc[m][r][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_lo, b_hi, acc[m][r][j], 0, 0, 0);
+                            acc[m][r][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, b_hi, acc[m][r][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+    } else {
         const float* bl = mine + q * A.cs + n16 * S;   // B fragment: channel k = lane >> 4, column n = lane & 15
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
@@ -240,7 +348,8 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
                         ox = 2 * (ox - 1) + 1 + (cls & 1);
                     }
                     ok = ok && (unsigned)oz < (unsigned)A.Do && (unsigned)oy < (unsigned)A.Ho && (unsigned)ox < (unsigned)A.Wo;
-                    float val = t[e] + ((ok && A.bias) ? A.bias[oc] : 0.f);
+                    float val = X ? fmaf(t[e], unscale, (ok && A.bias) ? A.bias[oc] : 0.f)
+                                  : t[e] + ((ok && A.bias) ? A.bias[oc] : 0.f);
                     if (A.lrelu) val = fmaxf(val, val * kLeakySlope);
                     const unsigned off = ok ? (unsigned)(((size_t)oc * A.Do + oz) * plane_o + (size_t)oy * A.Wo + ox) * 4u : ~0u;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), ro, off, 0, 0);
@@ -314,7 +423,7 @@ KsPlan ks_plan(int cin, int columns) {
     return p;
 }
 
-template <int MODE, int NB, int KSPLIT, int NKS, int MBW_ = 0>
+template <int MODE, int NB, int KSPLIT, int NKS, int MBW_ = 0, bool X = false>
 int launch_ks(KsArgs A, int batch, hipStream_t s) {
     // two channel blocks per workgroup (every B operand feeds two MFMAs), except where 16 waves x 108 weight registers
     // would not fit (the 128-channel convolutions take one) and for 16 output channels
@@ -329,30 +438,58 @@ int launch_ks(KsArgs A, int batch, hipStream_t s) {
     if (lds_bytes > 160 * 1024) return set_error(-1, "conv3d_ks: tile does not fit in LDS (%zu bytes)", lds_bytes);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS, X>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
     dim3 grid(A.tiles, A.mblocks / MBW, batch);
-    hipLaunchKernelGGL((conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS>), grid, dim3(64 * KSPLIT), lds_bytes, s, A);
+    hipLaunchKernelGGL((conv3d_ks_kernel<MODE, 1, 1, NB, MBW, KSPLIT, NKS, X>), grid, dim3(64 * KSPLIT), lds_bytes, s, A);
     return check_launch("conv3d_ks");
 }
 
-template <int MODE, int NB>
+// which configurations take the X form: measured per configuration on the hot path's layers (us per launch, fp32 -> X):
+//   3x3x3 s1, 4 channels per wave   34.9 -> 30.0 (32 -> 32 at 12x36x60)       taken
+//   3x3x3 s1, 8 channels per wave   20.4 -> 22.1, 16.2 -> 24.1                 not taken (144+ weight registers: spills)
+//   3x3x3 s2                        27.1 -> 33.1, 17.1 -> 17.8, 15.6 -> 15.2   not taken
+//   k4 s2 transposed (cell form)    49.1 -> 41.6, 33.7 -> 29.3, 31.3 -> 30.8   taken
+constexpr bool ks_split_config(int mode, int nks) { return mode == 2 || (mode == 0 && nks == 1); }
+
+template <int MODE, int NB, bool X>
 int dispatch_split(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s) {
-    if (p.ksplit == 4 && p.nks == 1 && A.mblocks == 1 && MODE == 0) return launch_ks<0, NB, 4, 1, 1>(A, batch, s);
-    if (p.ksplit == 4 && p.nks == 1) return launch_ks<MODE, NB, 4, 1>(A, batch, s);
-    if (p.ksplit == 8 && p.nks == 1) return launch_ks<MODE, NB, 8, 1>(A, batch, s);
-    if (p.ksplit == 8 && p.nks == 2) return launch_ks<MODE, NB, 8, 2>(A, batch, s);
-    if (p.ksplit == 16 && p.nks == 2) return launch_ks<MODE, NB, 16, 2>(A, batch, s);
+    if constexpr (!X || ks_split_config(MODE, 1)) {
+        if (p.ksplit == 4 && p.nks == 1 && A.mblocks == 1 && MODE == 0) return launch_ks<0, NB, 4, 1, 1, X>(A, batch, s);
+        if (p.ksplit == 4 && p.nks == 1) return launch_ks<MODE, NB, 4, 1, 0, X>(A, batch, s);
+        if (p.ksplit == 8 && p.nks == 1) return launch_ks<MODE, NB, 8, 1, 0, X>(A, batch, s);
+    }
+    if constexpr (!X || ks_split_config(MODE, 2)) {
+        if (p.ksplit == 8 && p.nks == 2) return launch_ks<MODE, NB, 8, 2, 0, X>(A, batch, s);
+        if (p.ksplit == 16 && p.nks == 2) return launch_ks<MODE, NB, 16, 2, 0, X>(A, batch, s);
+    }
     return set_error(-1, "conv3d_ks: no configuration for %d x %d channels per wave", p.ksplit, p.nks);
 }
 
 template <int MODE>
-int dispatch_ks(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s) {
-    if (p.nb == 1) return dispatch_split<MODE, 1>(p, A, batch, s);
-    if (p.nb == 2) return dispatch_split<MODE, 2>(p, A, batch, s);
-    return dispatch_split<MODE, 4>(p, A, batch, s);
+int dispatch_ks(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s, bool x) {
+    if (x) {
+        if (p.nb == 1) return dispatch_split<MODE, 1, true>(p, A, batch, s);
+        if (p.nb == 2) return dispatch_split<MODE, 2, true>(p, A, batch, s);
+        return dispatch_split<MODE, 4, true>(p, A, batch, s);
+    }
+    if (p.nb == 1) return dispatch_split<MODE, 1, false>(p, A, batch, s);
+    if (p.nb == 2) return dispatch_split<MODE, 2, false>(p, A, batch, s);
+    return dispatch_split<MODE, 4, false>(p, A, batch, s);
 }
+
+// X form (split fp16 operands on v_mfma_f32_16x16x16_f16) when every source carries a range certificate
+bool ks_use_split(const Src& a, const Src& b, int mode, const KsPlan& p) {
+    if (!ks_split_config(mode, p.nks)) return false;
+    static const bool enabled = []() {  // PDS_CONV3D_KSX=0: every launch on the fp32 matrix pipe (A/B, debugging)
+        const char* e = debug_switch("PDS_CONV3D_KSX");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && a.bounded && (b.p == nullptr || b.bounded);
+}
+
+size_t ks_split_dwords(int cin, int mblocks, int ksteps) { return (size_t)(cin / 4) * ksteps * mblocks * 2 * 64 * 2; }
 
 size_t ks_lds_bytes(int mode, const KsPlan& p, int cin) {
     const int sx = mode == 1 ? 2 : 1, ext = mode == 2 ? 2 : 3;
@@ -390,7 +527,12 @@ int conv3d_ks_tiles(const Geom& o) {
     return ((o.w + 16 * nb - 1) / (16 * nb)) * o.h * o.d;
 }
 
-size_t conv3d_ks_packed_floats(int cin, int vchannels, int taps) { return (size_t)(cin / 4) * taps * vchannels * 4; }
+// (the larger of the two forms + the 16-dword tail of the split form: the choice follows the sources' certificates)
+size_t conv3d_ks_packed_floats(int cin, int vchannels, int taps) {
+    const size_t plain = (size_t)(cin / 4) * taps * vchannels * 4;
+    const size_t split = ks_split_dwords(cin, vchannels / 16, taps == 27 ? 9 : 2) + 16;
+    return plain > split ? plain : split;
+}
 
 int launch_conv3d_ks(const ConvLayer& L, hipStream_t s) {
     if (!L.packed) return set_error(-1, "conv3d_ks: packed weights missing");
@@ -416,6 +558,9 @@ int launch_conv3d_ks(const ConvLayer& L, hipStream_t s) {
     A.tiles_x = (A.Wo + 16 * p.nb - 1) / (16 * p.nb);
     A.tiles_y = A.Ho;
     A.tiles = conv3d_ks_tiles(L.out_g);
+    const bool x = ks_use_split(L.a, L.b, mode, p);
+    const size_t split_total = ks_split_dwords(A.Cin, A.mblocks, 9) + 16;
+    A.wtail = L.packed + split_total - 16;
     {
         const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
         if (phase != kPackDone) {
@@ -427,13 +572,13 @@ int launch_conv3d_ks(const ConvLayer& L, hipStream_t s) {
             j.mblocks = A.mblocks;
             j.kc = 4;
             j.taps = 27;
-            j.mode = 0;
-            j.total = (int)conv3d_ks_packed_floats(A.Cin, A.Cout, 27);
+            j.mode = x ? 8 : 0;
+            j.total = x ? (int)split_total : (int)((size_t)(A.Cin / 4) * 27 * A.Cout * 4);
             if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
             if (int rc = launch_multi_pack(&j, 1, s)) return rc;
         }
     }
-    return mode == 1 ? dispatch_ks<1>(p, A, L.in.n, s) : dispatch_ks<0>(p, A, L.in.n, s);
+    return mode == 1 ? dispatch_ks<1>(p, A, L.in.n, s, x) : dispatch_ks<0>(p, A, L.in.n, s, x);
 }
 
 bool deconv3d_ks_supported(const DeconvLayer& L) {
@@ -473,6 +618,9 @@ int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s) {
     A.tiles_x = (A.Wi + 1 + 16 * p.nb - 1) / (16 * p.nb);
     A.tiles_y = A.Hi + 1;
     A.tiles = deconv3d_ks_tiles(L.in, A.Cout);
+    const bool x = ks_use_split(L.a, no_src(), 2, p);
+    const size_t split_total = ks_split_dwords(A.Cin, A.mblocks, 2) + 16;
+    A.wtail = L.packed + split_total - 16;
     {
         const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
         if (phase != kPackDone) {
@@ -484,13 +632,13 @@ int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s) {
             j.mblocks = A.mblocks;
             j.kc = 4;
             j.taps = 8;
-            j.mode = 5;
-            j.total = (int)conv3d_ks_packed_floats(A.Cin, 8 * A.Cout, 8);
+            j.mode = x ? 9 : 5;
+            j.total = x ? (int)split_total : (int)((size_t)(A.Cin / 4) * 8 * 8 * A.Cout * 4);
             if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
             if (int rc = launch_multi_pack(&j, 1, s)) return rc;
         }
     }
-    return dispatch_ks<2>(p, A, L.in.n, s);
+    return dispatch_ks<2>(p, A, L.in.n, s, x);
 }
 
 }  // namespace pds

@@ -67,11 +67,47 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     const PackJob J = T.j[blockIdx.y];
     const int ks_n = J.kc / 4;
     // mode 7: the weight scale of the job, left in the tail by pack_wscale_kernel (launched ahead of this kernel)
-    const float wscale = J.mode == 7 ? J.dst[J.total - 16 + 12] : 1.f;
+    const float wscale = J.mode >= 7 ? J.dst[J.total - 16 + 12] : 1.f;
     const int ncls = J.mode == 1 ? 8 : (J.mode == 2 ? 4 : 1);  // modes 0 and 3: plain convolutions
     const int kdn = J.mode == 1 ? 4 : 3;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < J.total; e += gridDim.x * 256) {
         int r = e;
+        if (J.mode == 8 || J.mode == 9) {
+            // conv3d_ks.hip, X form: two-way fp16 split of ws * w in the A-fragment order of v_mfma_f32_16x16x16_f16,
+            // [ic / 4][K-step][block][part][64 lanes][2 dwords]; lane = (k group q) * 16 + row, k = 4 q + channel.
+            //   mode 8 (3x3x3 convolution): K-step = (dz, dy), k group = dx (the fourth group is zero)
+            //   mode 9 (k4 s2 transposed convolution, cell form of mode 5): K-step = zi, k group = (yi, xi)
+            if (e >= J.total - 16) continue;   // (the tail: ws, 1 / ws from pack_wscale_kernel)
+            const int i2 = r % 2;
+            r /= 2;
+            const int ln = r % 64;
+            r /= 64;
+            const int part = r % 2;
+            r /= 2;
+            const int mb = r % J.mblocks;
+            r /= J.mblocks;
+            const int tsteps = J.mode == 8 ? 9 : 2;
+            const int t = r % tsteps;
+            const int g = r / tsteps;
+            const int v = mb * 16 + (ln & 15), q = ln >> 4;
+            unsigned h2[2] = {0u, 0u};
+            for (int k = 0; k < 2; ++k) {
+                const int c = 4 * g + 2 * i2 + k;
+                if (c >= J.cin) continue;
+                float val = 0.f;
+                if (J.mode == 8) {
+                    if (v < J.cout && q < 3) val = J.src[((size_t)v * J.cin + c) * 27 + t * 3 + q];
+                } else if (v < 8 * J.cout) {
+                    const int cls = v / J.cout, oc = v % J.cout;
+                    const int kz = 2 + ((cls >> 2) & 1) - 2 * t, ky = 2 + ((cls >> 1) & 1) - 2 * (q >> 1),
+                              kx = 2 + (cls & 1) - 2 * (q & 1);
+                    val = J.src[(((size_t)c * J.cout + oc) * 4 + kz) * 16 + ky * 4 + kx];
+                }
+                h2[k] = fp16_split_part(val * wscale, part);
+            }
+            reinterpret_cast<unsigned*>(J.dst)[e] = h2[0] | (h2[1] << 16);
+            continue;
+        }
         if (J.mode == 6 || J.mode == 7) {
             if (e >= J.total - 16) {   // the tile-queue counters of conv2d_x3 sit behind its weights: zeroed with them
                 if (J.mode == 6 || e < J.total - 16 + 12) reinterpret_cast<unsigned*>(J.dst)[e] = 0u;   // (12, 13: ws, 1 / ws)
@@ -160,13 +196,13 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable T) {
     }
 }
 
-// ws and 1 / ws of every mode-7 job of the table (one workgroup per job; the others leave at once)
+// ws and 1 / ws of every fp16-split job (modes 7, 8, 9) of the table (one workgroup per job; the others leave at once)
 __global__ __launch_bounds__(1024) void pack_wscale_kernel(const PackTable T) {
     const PackJob J = T.j[blockIdx.x];
-    if (J.mode != 7) return;
+    if (J.mode < 7) return;
     __shared__ float red[16];
     float m = 0.f;
-    const int nw = J.cout * J.cin * 9;
+    const int nw = J.cout * J.cin * (J.mode == 7 ? 9 : (J.mode == 8 ? 27 : 64));
     // (a tensor from PyTorch's allocator is 16-byte aligned; the tail covers counts that are not a multiple of 4)
     const float4* src4 = reinterpret_cast<const float4*>(J.src);
     const bool vec = (reinterpret_cast<uintptr_t>(J.src) & 15) == 0;
@@ -199,7 +235,7 @@ int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s) {
         if (bx > 128) bx = 128;
         if (bx < 1) bx = 1;
         bool any_fp16 = false;
-        for (int i = 0; i < n; ++i) any_fp16 |= T.j[i].mode == 7;
+        for (int i = 0; i < n; ++i) any_fp16 |= T.j[i].mode >= 7;
         if (any_fp16) {
             hipLaunchKernelGGL(pack_wscale_kernel, dim3(n), dim3(1024), 0, s, T);
             if (int rc = check_launch("pack_wscale")) return rc;
