@@ -230,16 +230,16 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
                 }
         } else {
 #pragma unroll
-        for (int c = 0; c < cq; ++c) {
-            const float s1 = sa ? sa[c] : 1.f, h1 = sa ? ha[c] : 0.f;     // wave-uniform: scalar loads
-            const float s2 = sb ? sb[c] : 1.f, h2 = sb ? hb[c] : 0.f;
+            for (int c = 0; c < cq; ++c) {
+                const float s1 = sa ? sa[c] : 1.f, h1 = sa ? ha[c] : 0.f;     // wave-uniform: scalar loads
+                const float s2 = sb ? sb[c] : 1.f, h2 = sb ? hb[c] : 0.f;
 #pragma unroll
-            for (int i = 0; i < PER_CH; ++i) {
-                float v = fmaf(s1, va[c][i], h1);
-                if (two) v += fmaf(s2, vb[c][i], h2);
-                mine[c * A.cs + lo_[i]] = in_[i] ? v : 0.f;
+                for (int i = 0; i < PER_CH; ++i) {
+                    float v = fmaf(s1, va[c][i], h1);
+                    if (two) v += fmaf(s2, vb[c][i], h2);
+                    mine[c * A.cs + lo_[i]] = in_[i] ? v : 0.f;
+                }
             }
-        }
         }
     }
 
