@@ -464,13 +464,19 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
     const int total_chunks = my_tiles * C2_CHUNKS;
 
     // staging role of this thread: items tid + 512 k = (halo row, aligned quad of four columns), all four channels
-    int item_row[C2W_ITEMS], item_col[C2W_ITEMS], lo_off[C2W_ITEMS];
+    int item_row[C2W_ITEMS], item_col[C2W_ITEMS], lo_off[C2W_ITEMS], lo_step[C2W_ITEMS];
+    bool item_ok[C2W_ITEMS];
 #pragma unroll
     for (int k = 0; k < C2W_ITEMS; ++k) {
-        const int it = min(tid + C2W_THREADS * k, C2W_YT * QW - 1);    // (surplus threads re-stage the last item)
+        // surplus threads (600 items for 1 024 slots at W = 240): their loads go out of range (zero, no memory access)
+        // and the zeros land on slots 0 and 1 of halo row 0 (unused, left zero column) -- re-staging the last item kept
+        // 41 % of the loads in flight redundant
+        item_ok[k] = tid + C2W_THREADS * k < C2W_YT * QW;
+        const int it = min(tid + C2W_THREADS * k, C2W_YT * QW - 1);
         item_row[k] = it / QW;
         item_col[k] = 4 * (it % QW);
-        lo_off[k] = (item_row[k] * RSW + 2 + item_col[k]) * 8;
+        lo_off[k] = item_ok[k] ? (item_row[k] * RSW + 2 + item_col[k]) * 8 : 0;
+        lo_step[k] = item_ok[k] ? 16 : 0;
     }
 
     struct TilePos {
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 #pragma unroll
         for (int k = 0; k < C2W_ITEMS; ++k) {
             const int y = P.y0 + item_row[k] - 1;
-            const bool ok = (unsigned)y < (unsigned)A.H;
+            const bool ok = (unsigned)y < (unsigned)A.H && item_ok[k];
             in[k] = ok ? 1.f : 0.f;
             off[k] = ok ? (unsigned)((size_t)y * A.W + item_col[k]) * 4u : ~0u;
         }
@@ -564,8 +570,8 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                         lo2[4 * e + i] = lo[i];
                     }
                 }
-                *reinterpret_cast<f16x8*>(buf + lo_off[k] + pp * 16) = hi2;
-                *reinterpret_cast<f16x8*>(buf + part_bytes + lo_off[k] + pp * 16) = lo2;
+                *reinterpret_cast<f16x8*>(buf + lo_off[k] + pp * lo_step[k]) = hi2;
+                *reinterpret_cast<f16x8*>(buf + part_bytes + lo_off[k] + pp * lo_step[k]) = lo2;
             }
     };
 
