@@ -2,6 +2,7 @@
 the planar one: the same products in the same order, so the signatures must be identical bit for bit.
 
     python tools/cb8_check.py            (spawns one process per level: the switch is read once per process)
+    python tools/cb8_check.py 0 1 2 1,PDS_X3_QUADS=0     (a level may carry further debug switches)
 """
 import hashlib
 import os
@@ -29,8 +30,11 @@ for (maxd, b, h, w) in ((191, 1, 144, 240), (63, 2, 32, 64), (255, 1, 96, 320)):
 
 def main():
     results = {}
-    for level in sys.argv[1:] or ['0', '1']:
+    for spec in sys.argv[1:] or ['0', '1']:
+        level, *extra = spec.split(',')
         env = dict(os.environ, PDS_DEBUG_SWITCHES='1', PDS_MATCHING_CB8=level)
+        env.update(kv.split('=', 1) for kv in extra)
+        level = spec
         out = subprocess.run([sys.executable, '-c', CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         text = out.stdout.decode(errors='replace')
         lines = [t for t in text.splitlines() if t.startswith('HASH')]
