@@ -163,7 +163,7 @@ def test_network_training_step(dev):
         for p in net.parameters():
             p -= 1e-3 * p.grad
     loss2 = torch.nn.functional.cross_entropy(net(left, right), target)
-    assert float(loss2) < float(loss)
+    assert float(loss2.detach()) < float(loss.detach())
 
 
 def test_subpixel_cross_entropy_known_answer(dev):
