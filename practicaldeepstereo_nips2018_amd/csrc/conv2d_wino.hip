@@ -31,17 +31,21 @@ namespace pds {
 
 namespace {
 
-constexpr int TH = 4, TWX = 64, NT = TWX / 2, NBT = NT / 16, KC = 4, MB = 4;
+constexpr int TWX = 64, NT = TWX / 2, NBT = NT / 16, KC = 4, MB = 4;
 constexpr int PS = NT;                    // floats between the 4 positions of one row
 constexpr int RSV = 4 * PS;               // row stride
-constexpr int CS = (TH + 2) * RSV + 16;   // channel stride, == 16 (mod 32): the two k-halves of a 32-lane group
-                                          // read disjoint banks
-constexpr int IN_CHUNK = KC * CS;
 constexpr int W_CHUNK = 12 * MB * 64;     // 12 (dy, p) products x 4 channel blocks x 64 lanes
-constexpr int BUF = IN_CHUNK + W_CHUNK;
-constexpr int ITEMS = KC * (TH + 2) * NT;  // (channel, row, tile) items per chunk: 768
-static_assert(ITEMS % 64 == 0 && ((TH + 2) * NT) % 64 == 0, "a wave stages whole rows of one channel");
-static_assert(CS % 32 == 16, "bank layout");
+// TH rows per tile = row-waves per workgroup: 4, or 6 for launches of a few hundred tiles (round 5, launch_conv2d_wino)
+template <int TH>
+struct WinoGeom {
+    static constexpr int CS = (TH + 2) * RSV + 16;   // channel stride, == 16 (mod 32): the two k-halves of a 32-lane group
+                                                     // read disjoint banks
+    static constexpr int IN_CHUNK = KC * CS;
+    static constexpr int BUF = IN_CHUNK + W_CHUNK;
+    static constexpr int ITEMS = KC * (TH + 2) * NT;  // (channel, row, tile) items per chunk: 768 / 1 024
+    static_assert(ITEMS % 64 == 0 && ((TH + 2) * NT) % 64 == 0, "a wave stages whole rows of one channel");
+    static_assert(CS % 32 == 16, "bank layout");
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -99,9 +103,12 @@ __device__ __forceinline__ float wave_shift_down(float v) {
 // NORM: the source carries a deferred InstanceNorm (scale / shift per channel or per (channel, plane)).
 // HALVES: 1 = 4 waves, wave r owns row r and all 64 output channels (128 accumulator registers, 2 waves/SIMD);
 //         2 = 8 waves, wave (r, half) owns row r and 32 output channels (64 accumulator registers, 4 waves/SIMD).
-template <bool NORM, int HALVES>
-__global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(const WinoArgs A) {
-    constexpr int THREADS = 256 * HALVES;
+template <bool NORM, int HALVES, int TH = 4>
+__global__ __launch_bounds__(64 * TH * HALVES, TH == 4 ? 2 * HALVES : (TH * HALVES) / 4)
+void conv2d_wino_kernel(const WinoArgs A) {
+    using WG = WinoGeom<TH>;
+    constexpr int CS = WG::CS, IN_CHUNK = WG::IN_CHUNK, BUF = WG::BUF, ITEMS = WG::ITEMS;
+    constexpr int THREADS = 64 * TH * HALVES;
     constexpr int MBW = MB / HALVES;                              // channel blocks per wave
     constexpr int IPT = (ITEMS + THREADS - 1) / THREADS;          // 3 or 2 (the last one only on waves 0-3)
     constexpr int W_ITERS = (W_CHUNK / 4 + THREADS - 1) / THREADS;
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_id & 3, half = wave_id >> 2;
+    const int wave = wave_id % TH, half = wave_id / TH;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, so
     // the launch index is re-mapped to make every XCD work on whole planes: neighbouring tiles (shared halo rows)
     // and the plane's statistics stay in one L2.  Needs D % 8 == 0; otherwise the identity mapping.
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
     const bool rowok = y < A.H;
     const int jx = lane & 15, q = lane >> 4;
     const bool pairs = (A.W & 1) == 0;  // rows start 8-byte aligned
-    float* red = lds;  // [4 rows][64 channels][2]
+    float* red = lds;  // [TH rows][64 channels][2]
 #pragma unroll
     for (int m = 0; m < MBW; ++m) {
 #pragma unroll
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256 * HALVES, 2 * HALVES) void conv2d_wino_kernel(c
             const int oc = tid >> 1, k = tid & 1;
             double v = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < 4; ++wv) v += (double)red[((wv * MB * 16) + oc) * 2 + k];
+            for (int wv = 0; wv < TH; ++wv) v += (double)red[((wv * MB * 16) + oc) * 2 + k];
             A.partials[((((size_t)n * A.Cout + oc) * A.D + d) * A.tiles + tile) * 2 + k] = v;
         }
     }
@@ -355,9 +362,27 @@ int conv2d_wino16_tiles(int h, int w);
 bool conv2d_wino16_preferred(int h, int w);
 int launch_conv2d_wino16(const ConvLayer& L, size_t w_set_stride, int bias_set_stride, hipStream_t s);
 
+// Rows per tile.  A workgroup of the 4-row form keeps the fp32 matrix pipe of its CU busy for ~22 us per 64 input channels,
+// and two of them on one CU share that pipe: the 2-plane launches of Matching's front end (288 workgroups on 256 CUs) took
+// 66 us because 32 CUs held two.  With 6-row tiles the same launch is 192 workgroups of 1.5 x the work, one per CU.  The
+// rule compares (rounds of workgroups over the CUs) x (rows per tile); large launches keep the 4-row form.
+static int wino_rows(const Geom& o) {
+    static const bool enabled = []() {  // PDS_WINO_ROWS6=0: 4-row tiles everywhere (A/B)
+        const char* e = debug_switch("PDS_WINO_ROWS6");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return 4;
+    const long long planes = (long long)o.n * o.d, tx = (o.w + TWX - 1) / TWX;
+    const long long w4 = planes * tx * ((o.h + 3) / 4), w6 = planes * tx * ((o.h + 5) / 6);
+    const long long cus = 256;
+    const long long t4 = ((w4 + cus - 1) / cus) * 4, t6 = ((w6 + cus - 1) / cus) * 6;
+    return t6 < t4 ? 6 : 4;
+}
+
 int conv2d_wino_tiles(const Geom& o) {
     if (conv2d_wino16_preferred(o.h, o.w)) return conv2d_wino16_tiles(o.h, o.w);
-    return ((o.h + TH - 1) / TH) * ((o.w + TWX - 1) / TWX);
+    const int th = wino_rows(o);
+    return ((o.h + th - 1) / th) * ((o.w + TWX - 1) / TWX);
 }
 
 size_t conv2d_wino_packed_floats(int cin, int cout) { return (size_t)(cin / KC) * W_CHUNK; }
@@ -406,7 +431,6 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
     A.tiles = conv2d_wino_tiles(L.out_g);
     A.w_set_stride = L.plane_weight_sets > 0 ? (size_t)total : 0;
     A.bias_set_stride = L.plane_weight_sets > 0 ? L.out_g.c : 0;
-    const size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     if (DeviceOnce once{attr_done}) {
         const int bytes = (int)(160 * 1024);
@@ -414,8 +438,19 @@ int launch_conv2d_wino(const ConvLayer& L, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<true, 2, 6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wino_kernel<false, 2, 6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
     const dim3 grid(A.tiles, A.D, A.N);
+    if (wino_rows(L.out_g) == 6) {
+        const size_t lds_bytes = (size_t)2 * WinoGeom<6>::BUF * sizeof(float);
+        if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2, 6>), grid, dim3(768), lds_bytes, s, A);
+        else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2, 6>), grid, dim3(768), lds_bytes, s, A);
+        return check_launch("conv2d_wino");
+    }
+    const size_t lds_bytes = (size_t)2 * WinoGeom<4>::BUF * sizeof(float);
     if (L.a.scale) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2>), grid, dim3(512), lds_bytes, s, A);
     else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2>), grid, dim3(512), lds_bytes, s, A);
     return check_launch("conv2d_wino");
