@@ -578,6 +578,8 @@ int launch_conv3d_ks(const ConvLayer& L, hipStream_t s) {
             if (int rc = launch_multi_pack(&j, 1, s)) return rc;
         }
     }
+    if (x && (!L.a.bound || L.a.bound_n <= 0 || (L.b.p && (!L.b.bound || L.b.bound_n <= 0))))
+        return set_error(-1, "conv3d_ks: split form without a range bound");
     return mode == 1 ? dispatch_ks<1>(p, A, L.in.n, s, x) : dispatch_ks<0>(p, A, L.in.n, s, x);
 }
 
@@ -638,6 +640,7 @@ int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s) {
             if (int rc = launch_multi_pack(&j, 1, s)) return rc;
         }
     }
+    if (x && (!L.a.bound || L.a.bound_n <= 0)) return set_error(-1, "deconv3d_ks: split form without a range bound");
     return dispatch_ks<2>(p, A, L.in.n, s, x);
 }
 
