@@ -105,8 +105,17 @@ def conv64_hbm_traffic():
 # algorithmic flop, priced against the dense fp16 MFMA peak (== the bf16 one).  PDS_X3_FP16=0 selects the range-safe
 # bf16 form (three parts, six products), PDS_X3=0 the exact-fp32 Winograd kernel of round 2 (2/3 of the flops on the
 # fp32 MFMA pipe).
-X3 = os.environ.get('PDS_X3', '1')[:1] != '0'
-X3_PRODUCTS = 3.0 if os.environ.get('PDS_X3_FP16', '1')[:1] != '0' else 6.0
+# (the library honours its kernel-selection variables only with PDS_DEBUG_SWITCHES=1, csrc/common.hpp: debug_switch;
+# without the gate the default kernels run whatever PDS_X3 says, and this script prices them as such)
+SWITCHES_ARMED = os.environ.get('PDS_DEBUG_SWITCHES', '')[:1] == '1'
+
+
+def debug_switch(name, default='1'):
+    return os.environ.get(name, default) if SWITCHES_ARMED else default
+
+
+X3 = debug_switch('PDS_X3')[:1] != '0'
+X3_PRODUCTS = 3.0 if debug_switch('PDS_X3_FP16')[:1] != '0' else 6.0
 CONV64_EXECUTED_GFLOP = CONV64_GFLOP * X3_PRODUCTS if X3 else CONV64_GFLOP * (2.0 / 3.0)
 CONV64_EXECUTED_PEAK = BF16_MFMA_PEAK_TFLOPS if X3 else FP32_MFMA_PEAK_TFLOPS
 # algorithmic work of the whole hot path per pair at configs[1]
@@ -489,10 +498,9 @@ def train_main(args, world, rank, device, collectives=None):
     elapsed = time.perf_counter() - t0
     in_sync = True
     if world > 1:
-        t = torch.tensor(windows, device=device, dtype=torch.float64)   # MAX over ranks of every region, then the median
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)   # one timed region: MAX over ranks
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        windows = [float(v) for v in t.tolist()]
-        elapsed = sorted(windows)[len(windows) // 2]
+        elapsed = float(t.item())
         in_sync = trainer.replicas_in_sync()
     # forward / backward split of one more (untimed) step on rank 0's pair
     torch.cuda.synchronize(device)

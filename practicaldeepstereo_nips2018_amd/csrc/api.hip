@@ -383,8 +383,8 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
     if (kind == 9) L.packed = c.get<float>(conv2d_x3_packed_floats(in.c));
-    if ((a.cb8 || b.cb8 || L.out_cb8) && !(kind == 8 && !L.out_cb8) &&
-        !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
+    // (conv2d_t8 / conv2d_t8w read planar tensors only: nothing but conv2d_x3 takes or writes the blocked layout)
+    if ((a.cb8 || b.cb8 || L.out_cb8) && !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
         c.run(set_error(-1, "conv_block: a channel-blocked tensor reached a kernel that does not take it"));
         return o;
     }

@@ -469,8 +469,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 #pragma unroll
     for (int k = 0; k < C2W_ITEMS; ++k) {
         // surplus threads (600 items for 1 024 slots at W = 240): their loads go out of range (zero, no memory access)
-        // and the zeros land on slots 0 and 1 of halo row 0 (unused, left zero column) -- re-staging the last item kept
-        // 41 % of the loads in flight redundant
+        // and their LDS stores are predicated off -- re-staging the last item kept 41 % of the loads in flight redundant
         item_ok[k] = tid + C2W_THREADS * k < C2W_YT * QW;
         const int it = min(tid + C2W_THREADS * k, C2W_YT * QW - 1);
         item_row[k] = it / QW;
@@ -570,8 +569,12 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                         lo2[4 * e + i] = lo[i];
                     }
                 }
-                *reinterpret_cast<f16x8*>(buf + lo_off[k] + pp * lo_step[k]) = hi2;
-                *reinterpret_cast<f16x8*>(buf + part_bytes + lo_off[k] + pp * lo_step[k]) = lo2;
+                // (surplus threads store nothing: their zero loads times a non-finite InstanceNorm coefficient would put a
+                // NaN on the left zero column of halo row 0, which real tiles read as x = -1 padding -- ADVICE r5)
+                if (item_ok[k]) {
+                    *reinterpret_cast<f16x8*>(buf + lo_off[k] + pp * lo_step[k]) = hi2;
+                    *reinterpret_cast<f16x8*>(buf + part_bytes + lo_off[k] + pp * lo_step[k]) = lo2;
+                }
             }
     };
 

@@ -92,50 +92,101 @@ def _all_ranks_agree(ok, device, group):
     return bool(flag.item() == 1.0)
 
 
+def _preflight_shapes(world, on_gpu):
+    """Per-rank shard shapes the pre-flight gathers: a tiny one (layout errors show at once), then the EXACT shards of
+    BASELINE configs[2] ([1, 8, 48 / N, 144, 240]: per-channel blocks of 3.3 / 1.7 / 0.8 MB at N = 2 / 4 / 8) and of
+    configs[3] ([4, 8, 64 / N, 96, 320]; batch 1 on a CPU group, where only the block size matters and gloo is slow) --
+    a form can pass on a few hundred bytes and fail on real transfers (gloo's coalesced method with CUDA tensors did)."""
+    shapes = [(2, 3, 2, 3, 5)]
+    if 48 % world == 0:
+        shapes.append((1, 8, 48 // world, 144, 240))
+    if 64 % world == 0:
+        shapes.append((4 if on_gpu else 1, 8, 64 // world, 96, 320))
+    return shapes
+
+
 def _choose_gather_mode(device, group):
-    """Tries the forms in order of preference on a tiny tensor and takes the first one that runs AND reproduces the
-    locally computed expectation on every rank.  An exception (of any type: RCCL reports API misuse as RuntimeError)
-    or a wrong result on ANY rank moves all ranks on together, so the ranks never disagree about the form."""
+    """Tries the forms in order of preference and takes the first one that runs AND reproduces the locally computed
+    expectation on every rank, on every shape of `_preflight_shapes`.  An exception (of any type: RCCL reports API
+    misuse as RuntimeError) or a wrong result on ANY rank moves all ranks on together: the agreement all-reduce runs
+    after EVERY case, so a rank that fails a case locally and the ranks that did not still issue the same sequence of
+    collectives (with one agreement per form a one-sided failure on the first case left the others inside
+    the second case's gather).  PDS_FORCE_GATHER=coalesced|separate|single skips the search (recorded in the note)."""
     global _GATHER_MODE, _GATHER_NOTE
+    import os
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = _device_backend(group, device)
-    # (the coalesced form is RCCL's ncclGroup; gloo offers the same method, but with CUDA tensors its result was wrong on
-    # real-size tensors although the tiny self-check passed -- tests/test_gpu_sharded.py -- so gloo keeps the separate calls)
-    order = ['coalesced', 'separate', 'single'] if backend == 'nccl' else ['separate', 'single']
-    # two sizes: a tiny one (layout errors show at once) and a realistic one -- 2.2 MB per rank, the per-channel blocks
-    # of config 2 at N = 8 are 0.8 MB -- because a form can pass on a few hundred bytes and fail on real transfers (gloo's
-    # coalesced method with CUDA tensors did, round 5)
+    forced = os.environ.get('PDS_FORCE_GATHER', '').strip().lower()
+    if forced:
+        if forced not in _GATHER_FORMS:
+            raise RuntimeError('PDS_FORCE_GATHER=%s: not one of %s' % (forced, ', '.join(sorted(_GATHER_FORMS))))
+        order = [forced]
+    else:
+        # (the coalesced form is RCCL's ncclGroup; gloo offers the same method, but with CUDA tensors its result was wrong
+        # on real-size tensors although the tiny self-check passed -- tests/test_gpu_sharded.py -- so gloo keeps the
+        # separate calls)
+        order = ['coalesced', 'separate', 'single'] if backend == 'nccl' else ['separate', 'single']
+
     def shard(r, shape):
         n = 1
         for v in shape:
             n *= v
         base = (torch.arange(n, dtype=torch.float32) % 8191.0).view(shape)
         return base + 10000.0 * (r + 1)
-    cases = []
-    for shape in ((2, 3, 2, 3, 5), (1, 8, 2, 144, 240)):
-        expect = torch.cat([shard(r, shape) for r in range(world)], dim=2).to(device)
-        cases.append((shard(rank, shape).to(device).contiguous(), expect, (shape[0], shape[1], world * shape[2], shape[3], shape[4])))
+    shapes = _preflight_shapes(world, torch.device(device).type == 'cuda')
     tried = []
     for mode in order:
-        ok, why = True, ''
-        try:
-            for mine, expect, full_shape in cases:
-                out = mine.new_full(full_shape, float('nan'))
+        agreed, why = True, ''
+        for shape in shapes:
+            ok = True
+            try:
+                mine = shard(rank, shape).to(device).contiguous()
+                expect = torch.cat([shard(r, shape) for r in range(world)], dim=2).to(device)
+                out = mine.new_full((shape[0], shape[1], world * shape[2], shape[3], shape[4]), float('nan'))
                 _GATHER_FORMS[mode](out, mine, group)
                 if out.is_cuda:
                     torch.cuda.synchronize(out.device)
-                ok = ok and bool(torch.equal(out, expect))
-            why = '' if ok else 'wrong result'
-        except Exception as error:   # noqa: BLE001  (any failure of this form means: use the next one)
-            ok, why = False, '%s: %s' % (type(error).__name__, str(error).split('\n')[0][:120])
-        agreed = _all_ranks_agree(ok, device, group)
+                ok = bool(torch.equal(out, expect))
+                why = '' if ok else 'wrong result at shard %s' % (list(shape),)
+                del mine, expect, out
+            except Exception as error:   # noqa: BLE001  (any failure of this form means: use the next one)
+                ok, why = False, '%s at shard %s: %s' % (type(error).__name__, list(shape), str(error).split('\n')[0][:120])
+            agreed = _all_ranks_agree(ok, device, group)   # after EVERY case: the same collective sequence on every rank
+            if not agreed:
+                break
         tried.append('%s %s' % (mode, 'ok' if agreed else ('failed (%s)' % (why or 'on another rank'))))
         if agreed:
             _GATHER_MODE = mode
-            _GATHER_NOTE = 'backend %s; %s' % (backend, ', '.join(tried))
+            _GATHER_NOTE = 'backend %s; %s%s; shards checked %s' % (
+                backend, 'PDS_FORCE_GATHER; ' if forced else '', ', '.join(tried), [list(v) for v in shapes])
             _GATHER_MODES[(group, torch.device(device).type)] = mode
             return mode
     raise RuntimeError('no form of the all-gather works on this process group: %s' % ', '.join(tried))
+
+
+def _communicator_facts(group, device):
+    """What the communication library ITSELF says about the communicator behind this group (RCCL only): ncclCommCount /
+    ncclCommUserRank / ncclCommCuDevice through the handle torch exposes -- so the bench line can confirm that RCCL, not
+    just torch.distributed, saw N ranks (the first multi-GPU run of this code is the driver's)."""
+    import ctypes
+    import glob
+    import os
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    backend = pg._get_backend(torch.device(device))
+    handle = int(backend._comm_ptr())
+    if not handle:
+        return {'nranks_seen': None, 'note': 'communicator not created yet'}
+    found = glob.glob(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so*'))
+    lib = ctypes.CDLL(found[0] if found else 'librccl.so')
+    facts = {}
+    for key, name in (('nranks_seen', 'ncclCommCount'), ('user_rank', 'ncclCommUserRank'), ('device', 'ncclCommCuDevice')):
+        value = ctypes.c_int(-1)
+        fn = getattr(lib, name)
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        fn.restype = ctypes.c_int
+        rc = fn(ctypes.c_void_p(handle), ctypes.byref(value))
+        facts[key] = int(value.value) if rc == 0 else 'error %d' % rc
+    return facts
 
 
 def preflight_collectives(group=None, device=None):
@@ -164,8 +215,20 @@ def preflight_collectives(group=None, device=None):
             info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
         except Exception as error:   # noqa: BLE001
             info['rccl_version'] = 'unknown (%s)' % type(error).__name__
+        try:   # RCCL's own view of the communicator (ncclCommCount): every rank's count, MIN / MAX over the ranks
+            facts = _communicator_facts(group, device)
+            seen = facts.get('nranks_seen')
+            t = torch.tensor([float(seen) if isinstance(seen, int) else -1.0], device=device, dtype=torch.float64)
+            lo, hi = t.clone(), t.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            facts['nranks_seen_min_over_ranks'] = int(lo.item())
+            facts['nranks_seen_max_over_ranks'] = int(hi.item())
+            info.update(facts)
+        except Exception as error:   # noqa: BLE001  (diagnostics only: never take the run down)
+            info['nranks_seen'] = 'unknown (%s: %s)' % (type(error).__name__, str(error)[:80])
     import os
-    info['knobs'] = {k: os.environ[k] for k in sorted(os.environ) if k.startswith(('NCCL_', 'RCCL_'))}
+    info['knobs'] = {k: os.environ[k] for k in sorted(os.environ) if k.startswith(('NCCL_', 'RCCL_', 'PDS_FORCE_'))}
     return info
 
 
@@ -372,6 +435,9 @@ class ShardedHotPath(object):
         """all-gather of this rank's planes on the dedicated collective stream:
         lane --(event: planes produced)--> gather stream: all-gather --(event: gathered)--> lane."""
         self.gathers_issued += 1
+        # (the raw gather is not differentiable: this schedule is the inference path -- ADVICE r5)
+        assert not (torch.is_grad_enabled() and local_planes.requires_grad), \
+            'ShardedHotPath with streams > 1 is inference-only: call it under torch.no_grad()'
         if not local_planes.is_cuda:
             return _gather_planes_raw(local_planes, self._group)
         device = local_planes.device

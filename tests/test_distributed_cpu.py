@@ -296,6 +296,42 @@ def preflight_worker(rank, world, port, results):
             ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
         ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
         ok = ok and torch.equal(pdist.gather_planes(mine), full)
+        # (iii) ADVICE r5: a form that raises on ONE rank on the FIRST case only, and (iv) a form that is right on the tiny
+        # case and wrong on the real-size shards (gloo's coalesced method with CUDA tensors did this): the agreement runs
+        # after every case, so no rank is left inside a collective the others skipped, and all move on together
+        for kind in ('rank 0 raises on the first case', 'wrong at real size'):
+            calls = [0]
+            def broken(out, local, group, kind=kind, calls=calls):
+                calls[0] += 1
+                real(out, local, group)
+                # (after the collective: a rank that raises BEFORE entering a collective its peers are already in cannot be
+                # rescued by any protocol; an error surfacing after it -- an asynchronous RCCL error, a failed check -- can)
+                if kind.startswith('rank 0') and rank == 0 and calls[0] == 1:
+                    raise RuntimeError('injected one-sided failure')
+                if kind.startswith('wrong') and local.numel() > 10000 and rank == 1:
+                    out.view(-1)[7] += 1.0
+            pdist._GATHER_FORMS['separate'] = broken
+            try:
+                pdist._GATHER_MODES.clear()
+                mode = pdist._choose_gather_mode(torch.device('cpu'), None)
+            finally:
+                pdist._GATHER_FORMS['separate'] = real
+            ok = ok and mode == 'single' and 'separate failed' in pdist.gather_description()
+            ok = ok and torch.equal(pdist.gather_planes(mine), full)
+        # the exact shards of configs[2] / configs[3] are among the checked shapes
+        shapes = pdist._preflight_shapes(world, False)
+        ok = ok and (1, 8, 48 // world, 144, 240) in shapes and (1, 8, 64 // world, 96, 320) in shapes
+        ok = ok and pdist._preflight_shapes(8, True)[1:] == [(1, 8, 6, 144, 240), (4, 8, 8, 96, 320)]
+        # PDS_FORCE_GATHER: no search, recorded in the description and in the pre-flight's knobs
+        os.environ['PDS_FORCE_GATHER'] = 'single'
+        try:
+            pdist._GATHER_MODES.clear()
+            info = pdist.preflight_collectives(device=torch.device('cpu'))
+        finally:
+            del os.environ['PDS_FORCE_GATHER']
+        ok = ok and info['gather_mode'] == 'single' and 'PDS_FORCE_GATHER' in pdist.gather_description()
+        ok = ok and info['knobs'].get('PDS_FORCE_GATHER') == 'single'
+        ok = ok and torch.equal(pdist.gather_planes(mine), full)
         results[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
