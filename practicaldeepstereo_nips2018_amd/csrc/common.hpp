@@ -36,6 +36,7 @@ int check_launch(const char* what);
 int probe_before(const char* name, hipStream_t s);
 void probe_after(int slot, int workgroups, hipStream_t s);
 long long nonfinite_statistics(int reset);   // conv_direct.hip: the host-mapped counter behind pds_nonfinite_statistics
+unsigned* nonfinite_counter(hipStream_t s);  // its device-visible address (nullptr: unavailable, e.g. while capturing)
 
 // Per-function attributes (hipFuncSetAttribute) and per-device launch data are set up once per DEVICE of the process:
 //     static std::atomic<unsigned> done{0};          // one bit per device
@@ -204,6 +205,33 @@ struct DeconvLayer {
 };
 int launch_deconv_direct(const DeconvLayer& L, hipStream_t s);
 int deconv_direct_tiles(const Geom& out_g);
+
+// ---- the persistent chain of K-split hourglass layers (conv3d_ks.hip) ------------------------------------------------
+// A module walk hands consecutive conv3d_ks / deconv3d_ks layers to a chain instead of launching them; the chain runs
+// them -- and the InstanceNorm fold behind each -- as ONE launch when the next other launch is due.
+struct KsChainFold {          // what launch_in_finalize would be given behind a stand-alone launch of the layer
+    const float* gamma;
+    const float* beta;
+    float* scale;
+    float* shift;
+    float* mean;
+    float* rstd;
+    float* bound;
+    int groups, per_group, channels;
+    double count;
+};
+struct KsChain {
+    int count = 0;
+    struct alignas(8) Slot {
+        unsigned char bytes[384];
+    } storage[12];            // opaque phases (conv3d_ks.hip: KsPhase)
+};
+constexpr int kKsChainSyncWords = 64;   // unsigned words of device memory the chain kernel synchronises through
+bool conv3d_ks_chain_enabled();
+// `taken` = the layer went into the chain (otherwise: launch it the usual way, after flushing the chain)
+int conv3d_ks_chain_add(KsChain& chain, const ConvLayer& L, const KsChainFold& fold, bool* taken);
+int deconv3d_ks_chain_add(KsChain& chain, const DeconvLayer& L, const KsChainFold& fold, bool* taken);
+int conv3d_ks_chain_launch(KsChain& chain, unsigned* sync_words, hipStream_t s);
 
 // partial sums -> (scale, shift).  groups = N*C*(per_plane ? D : 1); each group reduces
 // `per_group` consecutive partial records of (sum, sumsq); count = elements per group.
@@ -433,6 +461,57 @@ __device__ __forceinline__ void block_amax_record(float m, float* __restrict__ r
         for (int k = 0; k < waves; ++k) r = fmaxf(r, red[k]);
         *rec = r;
     }
+}
+
+// ---- InstanceNorm fold: partial records -> (scale, shift) of ONE group, by ONE wave (every lane calls it) --------------
+// The single definition behind in_finalize_kernel (conv_direct.hip) and the in-launch fold of the persistent chain kernel
+// (conv3d_ks.hip): lane l sums the records l, l + 64, ... in order, one shuffle reduction, lane 0 finishes -- the same
+// order wherever it runs, so both paths give the same bits.  Biased variance, eps 1e-5 (torch.nn.InstanceNorm defaults,
+// network_blocks.py:58,72,85).  g: group index; c = (g / inner) % channels its channel.
+__device__ __forceinline__ void in_finalize_group(const double* __restrict__ partials, int g, int per_group, double count,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  int channels, int inner, float* __restrict__ scale,
+                                                  float* __restrict__ shift, float* __restrict__ mean_out,
+                                                  float* __restrict__ rstd_out, unsigned* __restrict__ nonfinite, int lane) {
+    const double2* p = reinterpret_cast<const double2*>(partials) + (size_t)g * per_group;
+    double s = 0.0, q = 0.0;
+#pragma unroll 4
+    for (int i = lane; i < per_group; i += 64) {
+        const double2 r = p[i];
+        s += r.x;
+        q += r.y;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        // a NaN / inf reached this layer (or it overflowed): counted in host-mapped memory, pds_nonfinite_statistics()
+        if (nonfinite && !(fabs(mean) < 1.7e308 && fabs(var) < 1.7e308)) atomicAdd_system(nonfinite, 1u);
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + kInEps);
+        const int c = (g / inner) % channels;
+        const double sc = (gamma ? (double)gamma[c] : 1.0) * rstd;  // no affine: embedding.py:32
+        scale[g] = (float)sc;
+        shift[g] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
+        if (mean_out) {  // kept for the backward pass
+            mean_out[g] = (float)mean;
+            rstd_out[g] = (float)rstd;
+        }
+    }
+}
+// Range certificate of the normalised tensor (Src::bound): a group of `count` values with unit (biased) variance has no
+// z-score beyond sqrt(count - 1), so |gamma| sqrt(count) + |beta| bounds every value.  One wave, every lane calls it.
+__device__ __forceinline__ void in_finalize_bound(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  int channels, double count, float* __restrict__ bound_out, int lane) {
+    float m = 0.f;
+    const float root = sqrtf((float)count);
+    for (int c = lane; c < channels; c += 64) {
+        const float v = fabsf(gamma ? gamma[c] : 1.f) * root + fabsf(beta ? beta[c] : 0.f);
+        m = fmaxf(m, v == v ? v : __builtin_inff());
+    }
+    m = wave_max(m);
+    if (lane == 0) *bound_out = m;
 }
 
 }  // namespace pds

@@ -84,19 +84,53 @@ __device__ __forceinline__ float ks_row16_sum(float v) {
 
 }  // namespace
 
+// ---- how an item of work is ordered against its producers ---------------------------------------------------------
+// Stand-alone launch: the kernel boundary orders everything, scalar loads of the folded InstanceNorm are fine.
+struct KsAlone {
+    __device__ __forceinline__ void before_staging() const {}
+    __device__ __forceinline__ float coef(const float* p) const { return *p; }
+};
+// Inside the persistent chain kernel (below): the sources were written by other workgroups of the SAME launch.  One lane
+// polls the producer phase's `ready` word (relaxed, agent scope), ONE agent-scope acquire drops this CU's stale L1 lines,
+// the barrier publishes that to the other waves, then plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).  The
+// folded coefficients must not travel through the scalar cache, which no fence of this kernel invalidates.
+struct KsInLaunch {
+    const unsigned* ready;     // nullptr: the phase has no in-launch producer
+    unsigned* nonfinite;       // host-mapped error counter (pds_nonfinite_statistics): a poll that times out counts here
+    __device__ __forceinline__ void before_staging() const {
+        if (!ready) return;    // (kernel argument: uniform)
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > 400000000ll) {   // 4 s of the 100 MHz clock: never hang the GPU, report instead
+                    if (nonfinite) atomicAdd_system(nonfinite, 1u << 20);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ float coef(const float* p) const {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// One item of work: output tile `tile` (one row of 16 NB columns), channel blocks [mb0, mb0 + MBW), batch entry nb, by
+// the KSPLIT waves of a (sub-)group: `wave` / `tid` count inside the group, `lds` is the group's own region.  Every wave
+// of the WORKGROUP must call it (the barriers are workgroup-wide); a group without an item passes active = false: it
+// recomputes the item it was handed and stores nothing.
 // NKS: groups of four input channels per wave (Cin = 4 NKS KSPLIT)
-template <int MODE, int TZ, int TY, int NB, int MBW, int KSPLIT, int NKS, bool X = false>
-__global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) {
+template <int MODE, int TZ, int TY, int NB, int MBW, int KSPLIT, int NKS, bool X, class Sync>
+__device__ __forceinline__ void ks_item(const KsArgs& A, const int tile, const int mb0, const int nb, float* lds,
+                                        const int wave, const int tid, const bool active, const Sync& sync) {
     using G = KsGeom<MODE, TZ, TY, NB>;
     constexpr int S = G::S, R = G::R, NACC = MBW * R * NB;
     constexpr int TG = MODE == 2 ? 2 : 9;          // X form: MFMA K-steps per group of four channels ((dz, dy) / zi)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, mb0 = blockIdx.y * MBW, nb = blockIdx.z;
     const int tx = tile % A.tiles_x, ty = (tile / A.tiles_x) % A.tiles_y, tz = tile / (A.tiles_x * A.tiles_y);
     // output (conv) / cell (deconv) origin of the tile and the input coordinate of halo position (0, 0, 0)
     const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16 * NB;
@@ -140,6 +174,8 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) af[ks][t][m] = wl[((size_t)ks * G::TAPS + t) * tap_stride + m * 64];
     }
+    // (in-launch producers: the weights above are already on their way while this waits)
+    sync.before_staging();
     // X: power-of-two operand scales -- as from the sources' range certificates (few records: every wave reduces them
     // itself, no barrier), 1 / ws from the packed weights' tail
     float ascale = 1.f, unscale = 1.f;
@@ -205,10 +241,10 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
             float s1[cq], h1[cq], s2[cq], h2[cq];
 #pragma unroll
             for (int c = 0; c < cq; ++c) {
-                s1[c] = (sa ? sa[c] : 1.f) * ascale;
-                h1[c] = (sa ? ha[c] : 0.f) * ascale;
-                s2[c] = (sb ? sb[c] : 1.f) * ascale;
-                h2[c] = (sb ? hb[c] : 0.f) * ascale;
+                s1[c] = (sa ? sync.coef(sa + c) : 1.f) * ascale;
+                h1[c] = (sa ? sync.coef(ha + c) : 0.f) * ascale;
+                s2[c] = (sb ? sync.coef(sb + c) : 1.f) * ascale;
+                h2[c] = (sb ? sync.coef(hb + c) : 0.f) * ascale;
             }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
@@ -231,8 +267,8 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
         } else {
 #pragma unroll
             for (int c = 0; c < cq; ++c) {
-                const float s1 = sa ? sa[c] : 1.f, h1 = sa ? ha[c] : 0.f;     // wave-uniform: scalar loads
-                const float s2 = sb ? sb[c] : 1.f, h2 = sb ? hb[c] : 0.f;
+                const float s1 = sa ? sync.coef(sa + c) : 1.f, h1 = sa ? sync.coef(ha + c) : 0.f;   // (stand-alone: scalar loads)
+                const float s2 = sb ? sync.coef(sb + c) : 1.f, h2 = sb ? sync.coef(hb + c) : 0.f;
 #pragma unroll
                 for (int i = 0; i < PER_CH; ++i) {
                     float v = fmaf(s1, va[c][i], h1);
@@ -339,7 +375,7 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
                 for (int e = 0; e < 4; ++e) {
                     const int v = (mb0 + m) * 16 + 4 * q + e;      // (virtual) output channel
                     int oc = v, oz = z0 + rz, oy = y0 + ry, ox = x0 + 16 * j + n16;
-                    bool ok = v < (MODE == 2 ? 8 * A.Cout : A.Cout);
+                    bool ok = active && v < (MODE == 2 ? 8 * A.Cout : A.Cout);
                     if (MODE == 2) {
                         const int cls = v / A.Cout;
                         oc = v - cls * A.Cout;
@@ -378,7 +414,7 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
             const int c16 = tid >> 1, k = tid & 1;
             const int v = mb0 * 16 + c16;
             const int vmax = MODE == 2 ? 8 * A.Cout : A.Cout;
-            if (v < vmax) {
+            if (v < vmax && active) {
                 double sum = 0.0;
 #pragma unroll
                 for (int w = 0; w < KSPLIT; ++w) sum += (double)sred[((w * MBW * 16) + c16) * 2 + k];
@@ -393,7 +429,168 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
     }
 }
 
+// ---- stand-alone launch: one item per workgroup -------------------------------------------------------------------------
+template <int MODE, int TZ, int TY, int NB, int MBW, int KSPLIT, int NKS, bool X = false>
+__global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ks_item<MODE, TZ, TY, NB, MBW, KSPLIT, NKS, X>(A, blockIdx.x, blockIdx.y * MBW, blockIdx.z, lds, wave, threadIdx.x, true,
+                                                   KsAlone{});
+}
+
 // ---------------------------------------------------------------------------------------------------------------
+// The persistent CHAIN kernel (round 6): a run of consecutive K-split layers of the hourglass -- at 960x540, D = 192 the
+// eleven layers of levels 1-3 (regularization.py:22-26, 48-52: contraction 1-3, expansion 0-1 and the transposed
+// convolution of expansion 2) -- as ONE launch instead of eleven launches + eleven in_finalize launches.
+//
+//   work list   every phase (layer) is a list of tickets; a ticket is 8 / KSPLIT items (4-wave configurations run two
+//               items side by side in the 8-wave workgroup).  Workgroups draw tickets from ONE atomic counter, in order.
+//   ordering    a ticket of phase p waits for `ready[p - 1]` (set when every ticket of phase p - 1 is done AND its
+//               InstanceNorm has been folded).  Tickets are drawn in order and depend on earlier tickets only, so the
+//               scheme cannot deadlock however few workgroups are resident (another stream's kernel may hold the CUs, a
+//               second chain kernel may run beside this one): the lowest unfinished ticket is always held by a running
+//               workgroup whose dependencies are complete.  No grid barrier, no co-residency requirement.
+//   visibility  producers: plain stores -> every wave drains its stores -> barrier -> lane 0: agent-scope release fence,
+//               drained (asm), relaxed agent-scope fetch_add on done[p].  The workgroup that draws the last count folds the
+//               InstanceNorm (the same wave-per-group order as in_finalize_kernel: identical bits), releases again and
+//               stores ready[p].  Consumers: one lane polls ready[p] relaxed, ONE agent acquire, barrier, plain loads;
+//               folded coefficients by agent-scope loads (never through the scalar cache).
+//               (MI355X_MICROARCH.md, "inter-workgroup visibility"; cdna_hip_programming.md Guideline 16.)
+//   state       the counters are zeroed by a hipMemsetAsync node ahead of every launch.
+constexpr int kKsChainMax = 11;            // (11 phases x 336 bytes + header: the kernel arguments stay under 4 KB)
+constexpr int kKsChainThreads = 512;
+constexpr int kKsSyncWords = kKsChainSyncWords;   // [0] head, [16 + p] done, [32 + p] ready, [48 + p] time stamps (debug)
+
+struct KsPhase {
+    KsArgs A;
+    int cfg;                  // instantiation (ks_cfg_id)
+    int ksplit;               // waves per item
+    int mgroups;              // channel-block groups per tile (mblocks / MBW)
+    int mbw;
+    int items, tickets;       // items = tiles * mgroups * batch; tickets = ceil(items / (8 / ksplit))
+    int lds_stride;           // floats between the LDS regions of the sub-groups of a workgroup
+    // InstanceNorm fold of this phase's output (what launch_in_finalize does behind a stand-alone launch)
+    const float* gamma;
+    const float* beta;
+    float* scale;
+    float* shift;
+    float* mean;
+    float* rstd;
+    float* bound;
+    int groups, per_group, channels;
+    double count;
+};
+
+struct KsChainArgs {
+    int n;
+    int first[kKsChainMax + 1];   // first ticket of every phase; first[n] = total
+    unsigned* sync;
+    unsigned* nonfinite;
+    KsPhase ph[kKsChainMax];
+};
+
+// configurations of the chain kernel: id = ((mode * 3 + nbi) * 4 + cini), nbi = log2(NB), cini = log2(Cin / 16)
+#define PDS_KS_CHAIN_CONFIGS(F)                                                                                     \
+    F(0, 1, 1, 4, 1, true, 16) F(0, 2, 1, 4, 1, true, 16) F(0, 4, 1, 4, 1, true, 16)                                 \
+    F(0, 1, 2, 8, 1, true, 32) F(0, 2, 2, 8, 1, true, 32) F(0, 4, 2, 8, 1, true, 32)                                 \
+    F(0, 1, 2, 8, 2, false, 64) F(0, 2, 2, 8, 2, false, 64) F(0, 4, 2, 8, 2, false, 64)                              \
+    F(0, 1, 1, 8, 4, false, 128)                                                                                      \
+    F(1, 1, 2, 4, 1, false, 16) F(1, 2, 2, 4, 1, false, 16) F(1, 4, 2, 4, 1, false, 16)                              \
+    F(1, 1, 2, 8, 1, false, 32) F(1, 2, 2, 8, 1, false, 32) F(1, 4, 2, 8, 1, false, 32)                              \
+    F(1, 1, 2, 8, 2, false, 64) F(1, 2, 2, 8, 2, false, 64) F(1, 4, 2, 8, 2, false, 64)                              \
+    F(2, 1, 2, 4, 1, true, 16) F(2, 2, 2, 4, 1, true, 16) F(2, 4, 2, 4, 1, true, 16)                                 \
+    F(2, 1, 2, 8, 1, true, 32) F(2, 2, 2, 8, 1, true, 32) F(2, 4, 2, 8, 1, true, 32)                                 \
+    F(2, 1, 2, 8, 2, true, 64) F(2, 2, 2, 8, 2, true, 64) F(2, 4, 2, 8, 2, true, 64)                                 \
+    F(2, 1, 2, 8, 4, true, 128) F(2, 2, 2, 8, 4, true, 128) F(2, 4, 2, 8, 4, true, 128)
+
+__host__ __device__ constexpr int ks_cfg_id(int mode, int nb, int cin) {
+    return (mode * 3 + (nb == 1 ? 0 : nb == 2 ? 1 : 2)) * 4 + (cin == 16 ? 0 : cin == 32 ? 1 : cin == 64 ? 2 : 3);
+}
+
+// one out-of-line function per configuration: compiled once each (the thirty bodies inlined into one kernel took the
+// compiler five minutes and the register allocator 5 KB of scratch per lane)
+template <int MODE, int NB, int MBW, int KSPLIT, int NKS, bool X>
+__device__ __attribute__((noinline)) void ks_chain_item(const KsArgs* A, int tile, int mb0, int nb, float* region, int gwave,
+                                                        int gtid, bool active, const unsigned* ready, unsigned* nonfinite) {
+    ks_item<MODE, 1, 1, NB, MBW, KSPLIT, NKS, X>(*A, tile, mb0, nb, region, gwave, gtid, active, KsInLaunch{ready, nonfinite});
+}
+
+__global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const KsChainArgs C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (all LDS in the one dynamic array: the control words live behind the item regions)
+    int* ctl = reinterpret_cast<int*>(lds + (160 * 1024 - 64) / sizeof(float));
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned* head = C.sync;
+    unsigned* done = C.sync + 16;
+    unsigned* ready = C.sync + 32;
+    const int total = C.first[C.n];
+    for (;;) {
+        if (tid == 0) ctl[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(ctl[0]);
+        __syncthreads();   // (ctl[0] is rewritten by the next draw / the last-arriver flag below)
+        if (ticket >= total) break;
+        int p = 0;
+        while (ticket >= C.first[p + 1]) ++p;
+        const KsPhase& P = C.ph[p];
+        const int per_wg = 8 / P.ksplit;                       // items side by side in this workgroup
+        const int sub = wave / P.ksplit;
+        int item = (ticket - C.first[p]) * per_wg + sub;
+        const bool active = item < P.items;
+        item = min(item, P.items - 1);
+        const int tile = item % P.A.tiles, mg = (item / P.A.tiles) % P.mgroups, nb = item / (P.A.tiles * P.mgroups);
+        float* region = lds + (size_t)sub * P.lds_stride;
+        const int gwave = wave - sub * P.ksplit, gtid = tid - sub * P.ksplit * 64;
+        const unsigned* wait_for = p > 0 ? ready + (p - 1) : nullptr;
+        switch (P.cfg) {
+#define PDS_KS_CASE(MODE, NB, MBW, KSPLIT, NKS, X, CIN)                                                              \
+    case ks_cfg_id(MODE, NB, CIN):                                                                                   \
+        ks_chain_item<MODE, NB, MBW, KSPLIT, NKS, X>(&P.A, tile, mg * MBW, nb, region, gwave, gtid, active, wait_for, \
+                                                     C.nonfinite);                                                   \
+        break;
+            PDS_KS_CHAIN_CONFIGS(PDS_KS_CASE)
+#undef PDS_KS_CASE
+            default: break;
+        }
+        // ---- publish this ticket; the workgroup that completes the phase folds its InstanceNorm --------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restated where the compiler cannot drop it: Guideline 16 pitfall 12)
+            const unsigned old = __hip_atomic_fetch_add(done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old + 1u == (unsigned)P.tickets;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ctl[0] = last;
+        }
+        __syncthreads();
+        const int last = __builtin_amdgcn_readfirstlane(ctl[0]);
+        __syncthreads();
+        if (last) {
+            if (P.scale) {
+                const int lane = tid & 63;
+                for (int g = wave; g < P.groups; g += kKsChainThreads / 64)
+                    in_finalize_group(P.A.partials, g, P.per_group, P.count, P.gamma, P.beta, P.channels, 1, P.scale,
+                                      P.shift, P.mean, P.rstd, C.nonfinite, lane);
+                if (wave == 0 && P.bound) in_finalize_bound(P.gamma, P.beta, P.channels, P.count, P.bound, lane);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                C.sync[48 + p] = (unsigned)wall_clock64();     // (debug: phase completion stamps, 100 MHz)
+                __hip_atomic_store(ready + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int conv3d_ks_tiles(const Geom& o);
+int deconv3d_ks_tiles(const Geom& in, int cout);
+
 namespace {
 
 bool ks_enabled() {
@@ -410,7 +607,9 @@ struct KsPlan {
     int nks;      // groups of four input channels per wave
 };
 
-// tiles are single rows of 16 / 32 / 64 columns; the waves of a workgroup take 4 (Cin <= 32) or 8 input channels each
+// tiles are single rows of 16 / 32 / 64 columns; the waves of a workgroup take 4 (Cin <= 32), 8 (Cin = 64) or 16
+// (Cin = 128) input channels each -- never more than 8 waves, the size of the chain kernel's workgroups (round 6: the
+// 128-channel layers ran 16 waves x 8 channels; both forms of a layer must use ONE plan to give the same bits)
 // 16-column blocks per tile: the ONE rule behind the plan, the tile counts and the record counts (32-wide tiles for rows
 // of more than 32 columns measured neutral: 30.1 / 42.0 / 24.6 us against 29.8 / 44.2 / 23.8)
 int ks_nb(int columns) { return columns <= 16 ? 1 : (columns <= 32 ? 2 : 4); }
@@ -418,16 +617,21 @@ int ks_nb(int columns) { return columns <= 16 ? 1 : (columns <= 32 ? 2 : 4); }
 KsPlan ks_plan(int cin, int columns) {
     KsPlan p;
     p.nb = ks_nb(columns);
-    p.nks = cin >= 64 ? 2 : 1;
+    p.nks = cin >= 128 ? 4 : (cin >= 64 ? 2 : 1);
     p.ksplit = cin / (4 * p.nks);
     return p;
 }
 
-template <int MODE, int NB, int KSPLIT, int NKS, int MBW_ = 0, bool X = false>
+// channel blocks per item: two (every B operand feeds two MFMAs), except where the weight registers of a wave would not
+// fit (the 128-channel convolutions: 4 x 27 fragments per block) and for 16 output channels
+int ks_mbw(int mode, const KsPlan& p, int mblocks) {
+    if (mode != 2 && p.nks == 4) return 1;
+    if (mode == 0 && mblocks == 1) return 1;
+    return 2;
+}
+
+template <int MODE, int NB, int KSPLIT, int NKS, int MBW, bool X>
 int launch_ks(KsArgs A, int batch, hipStream_t s) {
-    // two channel blocks per workgroup (every B operand feeds two MFMAs), except where 16 waves x 108 weight registers
-    // would not fit (the 128-channel convolutions take one) and for 16 output channels
-    constexpr int MBW = MBW_ ? MBW_ : ((KSPLIT == 16 && MODE != 2) ? 1 : 2);
     using G = KsGeom<MODE, 1, 1, NB>;
     A.cs = G::CS;
     constexpr int NACC = MBW * NB;
@@ -454,29 +658,33 @@ int launch_ks(KsArgs A, int batch, hipStream_t s) {
 constexpr bool ks_split_config(int mode, int nks) { return mode == 2 || (mode == 0 && nks == 1); }
 
 template <int MODE, int NB, bool X>
-int dispatch_split(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s) {
+int dispatch_split(const KsPlan& p, const KsArgs& A, int batch, int mbw, hipStream_t s) {
     if constexpr (!X || ks_split_config(MODE, 1)) {
-        if (p.ksplit == 4 && p.nks == 1 && A.mblocks == 1 && MODE == 0) return launch_ks<0, NB, 4, 1, 1, X>(A, batch, s);
-        if (p.ksplit == 4 && p.nks == 1) return launch_ks<MODE, NB, 4, 1, 0, X>(A, batch, s);
-        if (p.ksplit == 8 && p.nks == 1) return launch_ks<MODE, NB, 8, 1, 0, X>(A, batch, s);
+        if (p.ksplit == 4 && p.nks == 1 && mbw == 1 && MODE == 0) return launch_ks<0, NB, 4, 1, 1, X>(A, batch, s);
+        if (p.ksplit == 4 && p.nks == 1 && mbw == 2) return launch_ks<MODE, NB, 4, 1, 2, X>(A, batch, s);
+        if (p.ksplit == 8 && p.nks == 1 && mbw == 2) return launch_ks<MODE, NB, 8, 1, 2, X>(A, batch, s);
     }
     if constexpr (!X || ks_split_config(MODE, 2)) {
-        if (p.ksplit == 8 && p.nks == 2) return launch_ks<MODE, NB, 8, 2, 0, X>(A, batch, s);
-        if (p.ksplit == 16 && p.nks == 2) return launch_ks<MODE, NB, 16, 2, 0, X>(A, batch, s);
+        if (p.ksplit == 8 && p.nks == 2 && mbw == 2) return launch_ks<MODE, NB, 8, 2, 2, X>(A, batch, s);
+        if constexpr (MODE == 2) {
+            if (p.ksplit == 8 && p.nks == 4 && mbw == 2) return launch_ks<2, NB, 8, 4, 2, X>(A, batch, s);
+        } else if constexpr (MODE == 0 && NB == 1 && !X) {
+            if (p.ksplit == 8 && p.nks == 4 && mbw == 1) return launch_ks<0, 1, 8, 4, 1, false>(A, batch, s);
+        }
     }
-    return set_error(-1, "conv3d_ks: no configuration for %d x %d channels per wave", p.ksplit, p.nks);
+    return set_error(-1, "conv3d_ks: no configuration for %d x %d channels per wave (mode %d)", p.ksplit, p.nks, MODE);
 }
 
 template <int MODE>
-int dispatch_ks(const KsPlan& p, const KsArgs& A, int batch, hipStream_t s, bool x) {
+int dispatch_ks(const KsPlan& p, const KsArgs& A, int batch, int mbw, hipStream_t s, bool x) {
     if (x) {
-        if (p.nb == 1) return dispatch_split<MODE, 1, true>(p, A, batch, s);
-        if (p.nb == 2) return dispatch_split<MODE, 2, true>(p, A, batch, s);
-        return dispatch_split<MODE, 4, true>(p, A, batch, s);
+        if (p.nb == 1) return dispatch_split<MODE, 1, true>(p, A, batch, mbw, s);
+        if (p.nb == 2) return dispatch_split<MODE, 2, true>(p, A, batch, mbw, s);
+        return dispatch_split<MODE, 4, true>(p, A, batch, mbw, s);
     }
-    if (p.nb == 1) return dispatch_split<MODE, 1, false>(p, A, batch, s);
-    if (p.nb == 2) return dispatch_split<MODE, 2, false>(p, A, batch, s);
-    return dispatch_split<MODE, 4, false>(p, A, batch, s);
+    if (p.nb == 1) return dispatch_split<MODE, 1, false>(p, A, batch, mbw, s);
+    if (p.nb == 2) return dispatch_split<MODE, 2, false>(p, A, batch, mbw, s);
+    return dispatch_split<MODE, 4, false>(p, A, batch, mbw, s);
 }
 
 // X form (split fp16 operands on v_mfma_f32_16x16x16_f16) when every source carries a range certificate
@@ -491,19 +699,148 @@ bool ks_use_split(const Src& a, const Src& b, int mode, const KsPlan& p) {
 
 size_t ks_split_dwords(int cin, int mblocks, int ksteps) { return (size_t)(cin / 4) * ksteps * mblocks * 2 * 64 * 2; }
 
-size_t ks_lds_bytes(int mode, const KsPlan& p, int cin) {
+int ks_cs(int mode, int nb) {
     const int sx = mode == 1 ? 2 : 1, ext = mode == 2 ? 2 : 3;
-    const int npos = ext * ext * ((16 * p.nb - 1) * sx + ext);
-    const int cs = sx == 1 ? ((npos + 15) / 32 * 32 + 16) : (npos | 1);
-    return (size_t)cin * cs * sizeof(float);
+    const int npos = ext * ext * ((16 * nb - 1) * sx + ext);
+    return sx == 1 ? ((npos + 15) / 32 * 32 + 16) : (npos | 1);
 }
+
+size_t ks_lds_bytes(int mode, const KsPlan& p, int cin) { return (size_t)cin * ks_cs(mode, p.nb) * sizeof(float); }
 
 bool ks_shape_ok(int mode, int cin, int vchannels, int columns, size_t in_elems, size_t out_elems, int batch) {
     if (cin != 16 && cin != 32 && cin != 64 && cin != 128) return false;
     if (vchannels % 32 != 0 && !(vchannels == 16 && mode == 0)) return false;   // two channel blocks per workgroup
     if (in_elems >= ((size_t)1 << 30) || out_elems >= ((size_t)1 << 30)) return false;   // 32-bit byte offsets
     if (batch > 65535) return false;
-    return ks_lds_bytes(mode, ks_plan(cin, columns), cin) <= 160 * 1024;
+    const KsPlan p = ks_plan(cin, columns);
+    if (p.nks == 4 && mode == 1) return false;            // (128 -> 256 stride 2: no configuration; conv3d_mfma.hip)
+    if (p.nks == 4 && mode == 0 && p.nb != 1) return false;
+    return ks_lds_bytes(mode, p, cin) <= 160 * 1024;
+}
+
+// the launch description of a layer: arguments, plan, pack job
+struct KsLaunch {
+    KsArgs A;
+    KsPlan plan;
+    int mode = 0, mbw = 2, batch = 1;
+    bool x = false;
+    PackJob job;
+};
+
+int ks_describe_conv(const ConvLayer& L, KsLaunch& K) {
+    if (!L.packed) return set_error(-1, "conv3d_ks: packed weights missing");
+    K.mode = L.stride == 2 ? 1 : 0;
+    KsArgs& A = K.A;
+    A.a = L.a;
+    A.b = L.b;
+    A.wpk = L.packed;
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.Cin = L.in.c;
+    A.Di = L.in.d;
+    A.Hi = L.in.h;
+    A.Wi = L.in.w;
+    A.Cout = L.out_g.c;
+    A.Do = L.out_g.d;
+    A.Ho = L.out_g.h;
+    A.Wo = L.out_g.w;
+    A.lrelu = L.lrelu;
+    A.mblocks = A.Cout / 16;
+    K.plan = ks_plan(A.Cin, A.Wo);
+    K.mbw = ks_mbw(K.mode, K.plan, A.mblocks);
+    K.batch = L.in.n;
+    A.tiles_x = (A.Wo + 16 * K.plan.nb - 1) / (16 * K.plan.nb);
+    A.tiles_y = A.Ho;
+    A.tiles = conv3d_ks_tiles(L.out_g);
+    A.cs = ks_cs(K.mode, K.plan.nb);
+    K.x = ks_use_split(L.a, L.b, K.mode, K.plan);
+    const size_t split_total = ks_split_dwords(A.Cin, A.mblocks, 9) + 16;
+    A.wtail = L.packed + split_total - 16;
+    PackJob& j = K.job;
+    j.src = L.weight;
+    j.dst = L.packed;
+    j.cout = A.Cout;
+    j.cin = A.Cin;
+    j.mblocks = A.mblocks;
+    j.kc = 4;
+    j.taps = 27;
+    j.mode = K.x ? 8 : 0;
+    j.total = K.x ? (int)split_total : (int)((size_t)(A.Cin / 4) * 27 * A.Cout * 4);
+    if (K.x && (!L.a.bounded || (L.b.p && !L.b.bounded)))
+        return set_error(-1, "conv3d_ks: split form without a range bound");
+    return 0;
+}
+
+int ks_describe_deconv(const DeconvLayer& L, KsLaunch& K) {
+    if (!L.packed) return set_error(-1, "deconv3d_ks: packed weights missing");
+    K.mode = 2;
+    KsArgs& A = K.A;
+    A.a = L.a;
+    A.b = no_src();
+    A.wpk = L.packed;
+    A.bias = L.bias;
+    A.out = L.out;
+    A.partials = L.partials;
+    A.Cin = L.in.c;
+    A.Di = L.in.d;
+    A.Hi = L.in.h;
+    A.Wi = L.in.w;
+    A.Cout = L.out_g.c;
+    A.Do = L.out_g.d;
+    A.Ho = L.out_g.h;
+    A.Wo = L.out_g.w;
+    A.lrelu = L.lrelu;
+    A.mblocks = 8 * A.Cout / 16;
+    K.plan = ks_plan(A.Cin, A.Wi + 1);
+    K.mbw = ks_mbw(2, K.plan, A.mblocks);
+    K.batch = L.in.n;
+    A.tiles_x = (A.Wi + 1 + 16 * K.plan.nb - 1) / (16 * K.plan.nb);
+    A.tiles_y = A.Hi + 1;
+    A.tiles = deconv3d_ks_tiles(L.in, A.Cout);
+    A.cs = ks_cs(2, K.plan.nb);
+    K.x = ks_use_split(L.a, no_src(), 2, K.plan);
+    const size_t split_total = ks_split_dwords(A.Cin, A.mblocks, 2) + 16;
+    A.wtail = L.packed + split_total - 16;
+    PackJob& j = K.job;
+    j.src = L.weight;
+    j.dst = L.packed;
+    j.cout = A.Cout;
+    j.cin = A.Cin;
+    j.mblocks = A.mblocks;
+    j.kc = 4;
+    j.taps = 8;
+    j.mode = K.x ? 9 : 5;
+    j.total = K.x ? (int)split_total : (int)((size_t)(A.Cin / 4) * 8 * 8 * A.Cout * 4);
+    if (K.x && !L.a.bounded) return set_error(-1, "deconv3d_ks: split form without a range bound");
+    return 0;
+}
+
+// pack (per the layer's phase) and, unless only collecting, launch stand-alone
+int ks_pack_and_launch(const KsLaunch& K, PackSink* sink, hipStream_t s) {
+    const PackPhase phase = sink ? sink->phase : kPackInline;
+    if (phase != kPackDone) {
+        if (phase == kPackCollect) return sink->push(K.job) ? 0 : set_error(-1, "pack job table full");
+        if (int rc = launch_multi_pack(&K.job, 1, s)) return rc;
+    }
+    const Src& a = K.A.a;
+    const Src& b = K.A.b;
+    if (K.x && (!a.bound || a.bound_n <= 0 || (b.p && (!b.bound || b.bound_n <= 0))))
+        return set_error(-1, "conv3d_ks: split form without a range bound");
+    return K.mode == 2 ? dispatch_ks<2>(K.plan, K.A, K.batch, K.mbw, s, K.x)
+                       : K.mode == 1 ? dispatch_ks<1>(K.plan, K.A, K.batch, K.mbw, s, K.x)
+                                     : dispatch_ks<0>(K.plan, K.A, K.batch, K.mbw, s, K.x);
+}
+
+// is (mode, nb, cin, mbw, ksplit, nks, x) one of the chain kernel's instantiations?
+bool ks_chain_has(const KsLaunch& K) {
+    const int cin = K.A.Cin;
+#define PDS_KS_HAS(MODE, NB, MBW, KSPLIT, NKS, X, CIN)                                                               \
+    if (K.mode == MODE && K.plan.nb == NB && cin == CIN)                                                             \
+        return K.mbw == MBW && K.plan.ksplit == KSPLIT && K.plan.nks == NKS && K.x == X;
+    PDS_KS_CHAIN_CONFIGS(PDS_KS_HAS)
+#undef PDS_KS_HAS
+    return false;
 }
 
 }  // namespace
@@ -535,52 +872,9 @@ size_t conv3d_ks_packed_floats(int cin, int vchannels, int taps) {
 }
 
 int launch_conv3d_ks(const ConvLayer& L, hipStream_t s) {
-    if (!L.packed) return set_error(-1, "conv3d_ks: packed weights missing");
-    const int mode = L.stride == 2 ? 1 : 0;
-    KsArgs A;
-    A.a = L.a;
-    A.b = L.b;
-    A.wpk = L.packed;
-    A.bias = L.bias;
-    A.out = L.out;
-    A.partials = L.partials;
-    A.Cin = L.in.c;
-    A.Di = L.in.d;
-    A.Hi = L.in.h;
-    A.Wi = L.in.w;
-    A.Cout = L.out_g.c;
-    A.Do = L.out_g.d;
-    A.Ho = L.out_g.h;
-    A.Wo = L.out_g.w;
-    A.lrelu = L.lrelu;
-    A.mblocks = A.Cout / 16;
-    const KsPlan p = ks_plan(A.Cin, A.Wo);
-    A.tiles_x = (A.Wo + 16 * p.nb - 1) / (16 * p.nb);
-    A.tiles_y = A.Ho;
-    A.tiles = conv3d_ks_tiles(L.out_g);
-    const bool x = ks_use_split(L.a, L.b, mode, p);
-    const size_t split_total = ks_split_dwords(A.Cin, A.mblocks, 9) + 16;
-    A.wtail = L.packed + split_total - 16;
-    {
-        const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
-        if (phase != kPackDone) {
-            PackJob j;
-            j.src = L.weight;
-            j.dst = L.packed;
-            j.cout = A.Cout;
-            j.cin = A.Cin;
-            j.mblocks = A.mblocks;
-            j.kc = 4;
-            j.taps = 27;
-            j.mode = x ? 8 : 0;
-            j.total = x ? (int)split_total : (int)((size_t)(A.Cin / 4) * 27 * A.Cout * 4);
-            if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
-            if (int rc = launch_multi_pack(&j, 1, s)) return rc;
-        }
-    }
-    if (x && (!L.a.bound || L.a.bound_n <= 0 || (L.b.p && (!L.b.bound || L.b.bound_n <= 0))))
-        return set_error(-1, "conv3d_ks: split form without a range bound");
-    return mode == 1 ? dispatch_ks<1>(p, A, L.in.n, s, x) : dispatch_ks<0>(p, A, L.in.n, s, x);
+    KsLaunch K;
+    if (int rc = ks_describe_conv(L, K)) return rc;
+    return ks_pack_and_launch(K, L.sink, s);
 }
 
 bool deconv3d_ks_supported(const DeconvLayer& L) {
@@ -598,50 +892,111 @@ int deconv3d_ks_tiles(const Geom& in, int cout) {
 }
 
 int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s) {
-    if (!L.packed) return set_error(-1, "deconv3d_ks: packed weights missing");
-    KsArgs A;
-    A.a = L.a;
-    A.b = no_src();
-    A.wpk = L.packed;
-    A.bias = L.bias;
-    A.out = L.out;
-    A.partials = L.partials;
-    A.Cin = L.in.c;
-    A.Di = L.in.d;
-    A.Hi = L.in.h;
-    A.Wi = L.in.w;
-    A.Cout = L.out_g.c;
-    A.Do = L.out_g.d;
-    A.Ho = L.out_g.h;
-    A.Wo = L.out_g.w;
-    A.lrelu = L.lrelu;
-    A.mblocks = 8 * A.Cout / 16;
-    const KsPlan p = ks_plan(A.Cin, A.Wi + 1);
-    A.tiles_x = (A.Wi + 1 + 16 * p.nb - 1) / (16 * p.nb);
-    A.tiles_y = A.Hi + 1;
-    A.tiles = deconv3d_ks_tiles(L.in, A.Cout);
-    const bool x = ks_use_split(L.a, no_src(), 2, p);
-    const size_t split_total = ks_split_dwords(A.Cin, A.mblocks, 2) + 16;
-    A.wtail = L.packed + split_total - 16;
-    {
-        const PackPhase phase = L.sink ? L.sink->phase : kPackInline;
-        if (phase != kPackDone) {
-            PackJob j;
-            j.src = L.weight;
-            j.dst = L.packed;
-            j.cout = A.Cout;
-            j.cin = A.Cin;
-            j.mblocks = A.mblocks;
-            j.kc = 4;
-            j.taps = 8;
-            j.mode = x ? 9 : 5;
-            j.total = x ? (int)split_total : (int)((size_t)(A.Cin / 4) * 8 * 8 * A.Cout * 4);
-            if (phase == kPackCollect) return L.sink->push(j) ? 0 : set_error(-1, "pack job table full");
-            if (int rc = launch_multi_pack(&j, 1, s)) return rc;
-        }
+    KsLaunch K;
+    if (int rc = ks_describe_deconv(L, K)) return rc;
+    return ks_pack_and_launch(K, L.sink, s);
+}
+
+// ---- the chain (common.hpp: KsChain) ---------------------------------------------------------------------------------
+namespace {
+int ks_chain_append(KsChain& chain, const KsLaunch& K, const KsChainFold& fold) {
+    if (chain.count >= kKsChainMax) return set_error(-1, "conv3d_ks chain: more than %d layers", kKsChainMax);
+    static_assert(sizeof(KsPhase) <= sizeof(chain.storage[0]), "KsChain::storage too small for a phase");
+    KsPhase& P = *reinterpret_cast<KsPhase*>(&chain.storage[chain.count]);
+    P.A = K.A;
+    P.cfg = ks_cfg_id(K.mode, K.plan.nb, K.A.Cin);
+    P.ksplit = K.plan.ksplit;
+    P.mbw = K.mbw;
+    P.mgroups = K.A.mblocks / K.mbw;
+    P.items = K.A.tiles * P.mgroups * K.batch;
+    const int per_wg = 8 / P.ksplit;
+    P.tickets = (P.items + per_wg - 1) / per_wg;
+    const size_t staging = (size_t)K.A.Cin * K.A.cs;
+    const size_t reduce = (size_t)P.ksplit * (K.mbw * K.plan.nb) * 64 * 4;
+    size_t region = staging > reduce ? staging : reduce;
+    if (region < 1024) region = 1024;
+    region = (region + 63) & ~(size_t)63;
+    if (region * per_wg * sizeof(float) > 160 * 1024 - 64)
+        return set_error(-1, "conv3d_ks chain: %d items of %zu bytes do not fit in LDS", per_wg, region * sizeof(float));
+    P.lds_stride = (int)region;
+    P.gamma = fold.gamma;
+    P.beta = fold.beta;
+    P.scale = fold.scale;
+    P.shift = fold.shift;
+    P.mean = fold.mean;
+    P.rstd = fold.rstd;
+    P.bound = fold.bound;
+    P.groups = fold.groups;
+    P.per_group = fold.per_group;
+    P.channels = fold.channels;
+    P.count = fold.count;
+    ++chain.count;
+    return 0;
+}
+}  // namespace
+
+bool conv3d_ks_chain_enabled() {
+    static const bool on = []() {  // PDS_CONV3D_KS_CHAIN=0: one launch + in_finalize per layer (A/B, the bit-exactness reference)
+        const char* e = debug_switch("PDS_CONV3D_KS_CHAIN");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+int conv3d_ks_chain_add(KsChain& chain, const ConvLayer& L, const KsChainFold& fold, bool* taken) {
+    *taken = false;
+    KsLaunch K;
+    if (int rc = ks_describe_conv(L, K)) return rc;
+    if (!ks_chain_has(K) || chain.count >= kKsChainMax) return 0;
+    if (K.x && (!L.a.bound || L.a.bound_n <= 0 || (L.b.p && (!L.b.bound || L.b.bound_n <= 0)))) return 0;
+    if (int rc = ks_chain_append(chain, K, fold)) return rc;
+    *taken = true;
+    return 0;
+}
+
+int deconv3d_ks_chain_add(KsChain& chain, const DeconvLayer& L, const KsChainFold& fold, bool* taken) {
+    *taken = false;
+    KsLaunch K;
+    if (int rc = ks_describe_deconv(L, K)) return rc;
+    if (!ks_chain_has(K) || chain.count >= kKsChainMax) return 0;
+    if (K.x && (!L.a.bound || L.a.bound_n <= 0)) return 0;
+    if (int rc = ks_chain_append(chain, K, fold)) return rc;
+    *taken = true;
+    return 0;
+}
+
+int conv3d_ks_chain_launch(KsChain& chain, unsigned* sync_words, hipStream_t s) {
+    if (chain.count == 0) return 0;
+    if (!sync_words) return set_error(-1, "conv3d_ks chain: no synchronisation words");
+    KsChainArgs C;
+    C.n = chain.count;
+    int t = 0;
+    for (int p = 0; p < chain.count; ++p) {
+        C.ph[p] = *reinterpret_cast<const KsPhase*>(&chain.storage[p]);
+        C.first[p] = t;
+        t += C.ph[p].tickets;
     }
-    if (x && (!L.a.bound || L.a.bound_n <= 0)) return set_error(-1, "deconv3d_ks: split form without a range bound");
-    return dispatch_ks<2>(p, A, L.in.n, s, x);
+    for (int p = chain.count; p <= kKsChainMax; ++p) C.first[p] = t;
+    C.sync = sync_words;
+    C.nonfinite = nonfinite_counter(s);
+    chain.count = 0;
+    static std::atomic<unsigned> attr_done{0};   // one bit per device
+    static int cu_count = 256;
+    if (DeviceOnce once{attr_done}) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_ks_chain_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cu_count = n;
+    }
+    if (hipMemsetAsync(sync_words, 0, kKsSyncWords * sizeof(unsigned), s) != hipSuccess)
+        return set_error(-1, "conv3d_ks chain: hipMemsetAsync failed");
+    const int grid = t < cu_count ? t : cu_count;    // one 8-wave workgroup per CU (256 registers per lane, 160 KB of LDS)
+    const int probe = probe_before("conv3d_ks_chain", s);
+    hipLaunchKernelGGL(conv3d_ks_chain_kernel, dim3(grid), dim3(kKsChainThreads), 160 * 1024, s, C);
+    probe_after(probe, grid, s);
+    return check_launch("conv3d_ks_chain");
 }
 
 }  // namespace pds

@@ -389,50 +389,16 @@ __global__ __launch_bounds__(64) void in_finalize_kernel(const double* __restric
                                                          float* __restrict__ rstd_out, float* __restrict__ bound_out,
                                                          unsigned* __restrict__ nonfinite) {
     const int g = blockIdx.x;
-    // Range certificate of the normalised tensor (common.hpp, Src::bound): a group of `count` values with unit
-    // (biased) variance has no z-score beyond sqrt(count - 1), so |gamma| sqrt(count) + |beta| bounds every value.
-    if (bound_out && g == 0) {
-        float m = 0.f;
-        const float root = sqrtf((float)count);
-        for (int c = threadIdx.x; c < channels; c += 64) {
-            const float v = fabsf(gamma ? gamma[c] : 1.f) * root + fabsf(beta ? beta[c] : 0.f);
-            m = fmaxf(m, v == v ? v : __builtin_inff());
-        }
-        m = wave_max(m);
-        if (threadIdx.x == 0) *bound_out = m;
-    }
-    const double2* p = reinterpret_cast<const double2*>(partials) + (size_t)g * per_group;
-    double s = 0.0, q = 0.0;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < per_group; i += 64) {
-        const double2 r = p[i];
-        s += r.x;
-        q += r.y;
-    }
-    s = wave_sum(s);
-    q = wave_sum(q);
-    if (threadIdx.x == 0) {
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        // a NaN / inf reached this layer (or it overflowed): counted in host-mapped memory, pds_nonfinite_statistics()
-        if (nonfinite && !(fabs(mean) < 1.7e308 && fabs(var) < 1.7e308)) atomicAdd_system(nonfinite, 1u);
-        if (var < 0.0) var = 0.0;
-        const double rstd = 1.0 / sqrt(var + kInEps);
-        const int c = (g / inner) % channels;
-        const double sc = (gamma ? (double)gamma[c] : 1.0) * rstd;  // no affine: embedding.py:32
-        scale[g] = (float)sc;
-        shift[g] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
-        if (mean_out) {  // kept for the backward pass
-            mean_out[g] = (float)mean;
-            rstd_out[g] = (float)rstd;
-        }
-    }
+    if (bound_out && g == 0) in_finalize_bound(gamma, beta, channels, count, bound_out, threadIdx.x);
+    in_finalize_group(partials, g, per_group, count, gamma, beta, channels, inner, scale, shift, mean_out, rstd_out,
+                      nonfinite, threadIdx.x);
 }
 
 // ---- the non-finite statistics counter (include/pds_hip.h, ABI v5): one word of host-mapped memory ----------------
 namespace {
 std::atomic<unsigned*> g_nonfinite{nullptr};
 std::atomic<int> g_nonfinite_state{0};   // 0 not tried, 1 ready, -1 unavailable
+}  // namespace
 unsigned* nonfinite_counter(hipStream_t s) {
     const int st = g_nonfinite_state.load(std::memory_order_acquire);
     if (st == 1) return g_nonfinite.load(std::memory_order_relaxed);
@@ -458,7 +424,6 @@ unsigned* nonfinite_counter(hipStream_t s) {
     g_nonfinite_state.store(1, std::memory_order_release);
     return p;
 }
-}  // namespace
 
 long long nonfinite_statistics(int reset) {
     if (g_nonfinite_state.load(std::memory_order_acquire) != 1)
