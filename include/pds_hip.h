@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDS_ABI_VERSION 5
+#define PDS_ABI_VERSION 6
 
 typedef void* pds_stream_t; /* hipStream_t */
 
@@ -59,6 +59,13 @@ long long pds_nonfinite_statistics(int reset);
  * launches serialise them. */
 int pds_probe_begin(const char* kernel, int capacity);
 int pds_probe_end(float* ms, int* workgroups, int capacity);
+
+/* ABI v6.  Measurement only: the inner levels of the Regularization hourglass (regularization.py:22-26, 48-52: the
+ * layers the K-split kernel serves) run as ONE persistent launch whose workgroups walk the layer list (conv3d_ks.hip:
+ * conv3d_ks_chain_kernel).  Synchronises the device and writes, for every layer of the LAST such launch of this
+ * process, the time at which it was complete (InstanceNorm folded) in ticks of the 100 MHz device clock since the
+ * first ticket of the launch was drawn; returns the number of layers (0: no such launch yet) or a negative error code. */
+int pds_debug_chain_stamps(unsigned* ticks, int capacity);
 
 /* ------------------------------------------------------------------------------------
  * Layer parameters in the reference's own (PyTorch) layouts.

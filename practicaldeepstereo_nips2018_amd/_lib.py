@@ -151,6 +151,7 @@ SIGNATURES = {
     'pds_nonfinite_statistics': (ctypes.c_longlong, [_I]),
     'pds_probe_begin': (_I, [ctypes.c_char_p, _I]),
     'pds_probe_end': (_I, [_VP, _VP, _I]),
+    'pds_debug_chain_stamps': (_I, [_VP, _I]),
     'pds_subpixel_map_fwd': (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_shift_concat_fwd': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     'pds_matching_workspace_bytes': (_SZ, [ctypes.POINTER(MatchingParams), _I, _I, _I, _I]),
@@ -214,7 +215,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 5   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
+ABI_VERSION = 6   # include/pds_hip.h PDS_ABI_VERSION: the argument lists in SIGNATURES are those of this version
 
 
 def load():

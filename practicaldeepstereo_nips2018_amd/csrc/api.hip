@@ -89,6 +89,7 @@ bool conv3d_ks_supported(const ConvLayer& L);
 int conv3d_ks_tiles(const Geom& out_g);
 size_t conv3d_ks_packed_floats(int cin, int vchannels, int taps);
 int launch_deconv3d_ks(const DeconvLayer& L, hipStream_t s);
+int ks_chain_debug_stamps(unsigned* out, int capacity);           // (measurement aid: pds_debug_chain_stamps)
 bool deconv3d_ks_supported(const DeconvLayer& L);
 int deconv3d_ks_tiles(const Geom& in_g, int cout);
 int launch_deconv3d_cell(const DeconvLayer& L, hipStream_t s);    // deconv3d_cell.hip (dense cell form, k4 s2)
@@ -156,6 +157,13 @@ struct Ctx {
     PackSink* sink = nullptr;
     Tape* tape = nullptr;   // non-null: record layers for the backward pass (and keep every layer tape-friendly)
     size_t limit = ~(size_t)0;  // bytes behind `base`: carving past it is an error, never a wild write
+    // Regularization only (round 6): consecutive K-split layers are collected here and run as ONE persistent launch
+    // (conv3d_ks.hip: conv3d_ks_chain_kernel) when the next other launch is due -- flush_chain()
+    KsChain* chain = nullptr;
+    unsigned* chain_sync = nullptr;
+    void flush_chain() {
+        if (chain && chain->count > 0) run(conv3d_ks_chain_launch(*chain, chain_sync, s));
+    }
 
     template <class T>
     T* get(size_t count) {
@@ -432,13 +440,22 @@ static DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const P
         o.bound_n = 1;
         o.bounded = true;
         if (!c.plan) {
-            c.run(launch());
             const int per_group = volume_records ? tiles : tiles * (per_plane ? 1 : o.g.d);
             const double count = (double)o.g.h * o.g.w * (per_plane ? 1 : o.g.d);
-            c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
-                                     per_plane ? o.g.d : 1, o.scale, o.shift, o.mean, o.rstd, c.s, o.bound));
+            bool chained = false;
+            if (c.chain && kind == 7 && !per_plane) {
+                const KsChainFold fold{P.gamma, P.beta, o.scale, o.shift, o.mean, o.rstd, o.bound, groups, per_group, o.g.c, count};
+                c.run(conv3d_ks_chain_add(*c.chain, L, fold, &chained));
+            }
+            if (!chained) {
+                c.flush_chain();
+                c.run(launch());
+                c.run(launch_in_finalize(L.partials, groups, per_group, count, P.gamma, P.beta, o.g.c,
+                                         per_plane ? o.g.d : 1, o.scale, o.shift, o.mean, o.rstd, c.s, o.bound));
+            }
         }
     } else if (!c.plan) {
+        c.flush_chain();
         c.run(launch());
     }
     tape_layer(c, 0, kd, stride, a, b, in, o, &P, norm);
@@ -501,11 +518,21 @@ static DT deconv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const
         o.bound_n = 1;
         o.bounded = true;
         if (!c.plan) {
-            c.run(launch());
-            c.run(launch_in_finalize(L.partials, groups, per_group, (double)o.g.volume(), P.gamma, P.beta,
-                                     o.g.c, 1, o.scale, o.shift, o.mean, o.rstd, c.s, o.bound));
+            bool chained = false;
+            if (c.chain && ks) {
+                const KsChainFold fold{P.gamma, P.beta, o.scale, o.shift, o.mean, o.rstd, o.bound, groups, per_group, o.g.c,
+                                       (double)o.g.volume()};
+                c.run(deconv3d_ks_chain_add(*c.chain, L, fold, &chained));
+            }
+            if (!chained) {
+                c.flush_chain();
+                c.run(launch());
+                c.run(launch_in_finalize(L.partials, groups, per_group, (double)o.g.volume(), P.gamma, P.beta,
+                                         o.g.c, 1, o.scale, o.shift, o.mean, o.rstd, c.s, o.bound));
+            }
         }
     } else if (!c.plan) {
+        c.flush_chain();
         c.run(launch());
     }
     tape_layer(c, 1, kd, kd == 4 ? 2 : 1, a, b, in, o, &P, norm);
@@ -839,6 +866,10 @@ static DT regularization_trunk(Ctx& c, const PdsRegularizationParams& P, const f
     // tape ids: 0 = signatures, 1 = left shortcut ([batch, F, h, w] broadcast along D, regularization.py:115)
     const Src ms_src = external_src(c, ms, g0);
     Src shortcut = external_src(c, left, g0, 1);
+    // the K-split layers of the inner levels go through a chain: one persistent launch per run of consecutive ones
+    KsChain chain;
+    c.chain_sync = c.get<unsigned>(kKsChainStateWords);
+    c.chain = (!c.plan && conv3d_ks_chain_enabled()) ? &chain : nullptr;
     DT out = conv_block(c, ms_src, no_src(), g0, P.smoothing, F, 3, 1, 0);
     DT pushed[4];
     for (int i = 0; i < 4; ++i) {
@@ -855,7 +886,10 @@ static DT regularization_trunk(Ctx& c, const PdsRegularizationParams& P, const f
         DT up = deconv_block(c, out.src(), no_src(), out.g, P.expansion[i][0], cin / 2, 4);
         out = conv_block(c, up.src(), pushed[3 - i].src(), up.g, P.expansion[i][1], cin / 2, 3, 1, 0);
     }
-    return deconv_block(c, out.src(), no_src(), out.g, P.upsample_half, F / 2, 4);
+    DT half = deconv_block(c, out.src(), no_src(), out.g, P.upsample_half, F / 2, 4);
+    c.flush_chain();
+    c.chain = nullptr;
+    return half;
 }
 
 bool upsample_full_valu_supported(int cin);
@@ -1290,6 +1324,11 @@ int pds_probe_end(float* ms, int* workgroups, int capacity) {
     return n;
 }
 const char* pds_last_error(void) { return g_error; }
+
+int pds_debug_chain_stamps(unsigned* ticks, int capacity) {
+    PDS_REQUIRE(ticks && capacity > 0, "chain stamps: bad arguments");
+    return ks_chain_debug_stamps(ticks, capacity);
+}
 
 int pds_subpixel_map_fwd(const float* similarities, float* disparities, int batch, int planes, int height,
                          int width, int half_support_window, int disparity_step, pds_stream_t stream) {

@@ -226,7 +226,8 @@ struct KsChain {
         unsigned char bytes[384];
     } storage[12];            // opaque phases (conv3d_ks.hip: KsPhase)
 };
-constexpr int kKsChainSyncWords = 64;   // unsigned words of device memory the chain kernel synchronises through
+constexpr int kKsChainSyncWords = 64;     // unsigned words of device memory the chain kernel synchronises through ...
+constexpr int kKsChainStateWords = 2048;  // ... at the head of this many words of state (counters + the phase table)
 bool conv3d_ks_chain_enabled();
 // `taken` = the layer went into the chain (otherwise: launch it the usual way, after flushing the chain)
 int conv3d_ks_chain_add(KsChain& chain, const ConvLayer& L, const KsChainFold& fold, bool* taken);
@@ -468,37 +469,62 @@ __device__ __forceinline__ void block_amax_record(float m, float* __restrict__ r
 // (conv3d_ks.hip): lane l sums the records l, l + 64, ... in order, one shuffle reduction, lane 0 finishes -- the same
 // order wherever it runs, so both paths give the same bits.  Biased variance, eps 1e-5 (torch.nn.InstanceNorm defaults,
 // network_blocks.py:58,72,85).  g: group index; c = (g / inner) % channels its channel.
+// B groups at a time (g, g + gstride, ...; the first `valid` of them exist): the B record streams are independent, so a
+// lane has B (x the unroll factor) loads in flight instead of one group's -- what matters where ONE workgroup folds a
+// whole layer (the chain kernel's last arriver).  Per group the order of the additions is the same for every B.
+template <int B>
+__device__ __forceinline__ void in_finalize_groups(const double* __restrict__ partials, int g, int gstride, int valid,
+                                                   int per_group, double count, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, int channels, int inner,
+                                                   float* __restrict__ scale, float* __restrict__ shift,
+                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                   unsigned* __restrict__ nonfinite, int lane) {
+    const double2* p[B];
+    double s[B], q[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        // (a missing group re-reads the first one: no branch in the load loop; its result is dropped)
+        p[b] = reinterpret_cast<const double2*>(partials) + (size_t)(b < valid ? g + b * gstride : g) * per_group;
+        s[b] = q[b] = 0.0;
+    }
+#pragma unroll 4
+    for (int i = lane; i < per_group; i += 64) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const double2 r = p[b][i];
+            s[b] += r.x;
+            q[b] += r.y;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const double sum = wave_sum(s[b]), sq = wave_sum(q[b]);
+        if (lane == 0 && b < valid) {
+            const int gb = g + b * gstride;
+            const double mean = sum / count;
+            double var = sq / count - mean * mean;
+            // a NaN / inf reached this layer (or it overflowed): counted in host-mapped memory, pds_nonfinite_statistics()
+            if (nonfinite && !(fabs(mean) < 1.7e308 && fabs(var) < 1.7e308)) atomicAdd_system(nonfinite, 1u);
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + kInEps);
+            const int c = (gb / inner) % channels;
+            const double sc = (gamma ? (double)gamma[c] : 1.0) * rstd;  // no affine: embedding.py:32
+            scale[gb] = (float)sc;
+            shift[gb] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
+            if (mean_out) {  // kept for the backward pass
+                mean_out[gb] = (float)mean;
+                rstd_out[gb] = (float)rstd;
+            }
+        }
+    }
+}
 __device__ __forceinline__ void in_finalize_group(const double* __restrict__ partials, int g, int per_group, double count,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   int channels, int inner, float* __restrict__ scale,
                                                   float* __restrict__ shift, float* __restrict__ mean_out,
                                                   float* __restrict__ rstd_out, unsigned* __restrict__ nonfinite, int lane) {
-    const double2* p = reinterpret_cast<const double2*>(partials) + (size_t)g * per_group;
-    double s = 0.0, q = 0.0;
-#pragma unroll 4
-    for (int i = lane; i < per_group; i += 64) {
-        const double2 r = p[i];
-        s += r.x;
-        q += r.y;
-    }
-    s = wave_sum(s);
-    q = wave_sum(q);
-    if (lane == 0) {
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        // a NaN / inf reached this layer (or it overflowed): counted in host-mapped memory, pds_nonfinite_statistics()
-        if (nonfinite && !(fabs(mean) < 1.7e308 && fabs(var) < 1.7e308)) atomicAdd_system(nonfinite, 1u);
-        if (var < 0.0) var = 0.0;
-        const double rstd = 1.0 / sqrt(var + kInEps);
-        const int c = (g / inner) % channels;
-        const double sc = (gamma ? (double)gamma[c] : 1.0) * rstd;  // no affine: embedding.py:32
-        scale[g] = (float)sc;
-        shift[g] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
-        if (mean_out) {  // kept for the backward pass
-            mean_out[g] = (float)mean;
-            rstd_out[g] = (float)rstd;
-        }
-    }
+    in_finalize_groups<1>(partials, g, 0, 1, per_group, count, gamma, beta, channels, inner, scale, shift, mean_out, rstd_out,
+                          nonfinite, lane);
 }
 // Range certificate of the normalised tensor (Src::bound): a group of `count` values with unit (biased) variance has no
 // z-score beyond sqrt(count - 1), so |gamma| sqrt(count) + |beta| bounds every value.  One wave, every lane calls it.

@@ -87,6 +87,7 @@ __device__ __forceinline__ float ks_row16_sum(float v) {
 // ---- how an item of work is ordered against its producers ---------------------------------------------------------
 // Stand-alone launch: the kernel boundary orders everything, scalar loads of the folded InstanceNorm are fine.
 struct KsAlone {
+    __device__ __forceinline__ void mark(unsigned) const {}
     __device__ __forceinline__ void before_staging() const {}
     __device__ __forceinline__ float coef(const float* p) const { return *p; }
 };
@@ -94,16 +95,26 @@ struct KsAlone {
 // polls the producer phase's `ready` word (relaxed, agent scope), ONE agent-scope acquire drops this CU's stale L1 lines,
 // the barrier publishes that to the other waves, then plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).  The
 // folded coefficients must not travel through the scalar cache, which no fence of this kernel invalidates.
+#ifndef PDS_KS_POLL_TIMEOUT_TICKS
+#define PDS_KS_POLL_TIMEOUT_TICKS 200000000ll   // 2 s of the 100 MHz clock
+#endif
+constexpr long long kKsPollTimeoutTicks = PDS_KS_POLL_TIMEOUT_TICKS;
 struct KsInLaunch {
     const unsigned* ready;     // nullptr: the phase has no in-launch producer
     unsigned* nonfinite;       // host-mapped error counter (pds_nonfinite_statistics): a poll that times out counts here
+    unsigned* marks;           // debug builds (-DPDS_KS_CHAIN_MARK): the workgroup's progress word, tools/chain_debug.py
+    __device__ __forceinline__ void mark(unsigned stage) const {
+#ifdef PDS_KS_CHAIN_MARK
+        if (threadIdx.x == 0) __hip_atomic_store(marks, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
     __device__ __forceinline__ void before_staging() const {
         if (!ready) return;    // (kernel argument: uniform)
         if (threadIdx.x == 0) {
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > 400000000ll) {   // 4 s of the 100 MHz clock: never hang the GPU, report instead
+                if (wall_clock64() - t0 > kKsPollTimeoutTicks) {   // never hang the GPU, report instead
                     if (nonfinite) atomicAdd_system(nonfinite, 1u << 20);
                     break;
                 }
@@ -175,7 +186,9 @@ __device__ __forceinline__ void ks_item(const KsArgs& A, const int tile, const i
                 for (int m = 0; m < MBW; ++m) af[ks][t][m] = wl[((size_t)ks * G::TAPS + t) * tap_stride + m * 64];
     }
     // (in-launch producers: the weights above are already on their way while this waits)
+    sync.mark(0x20);
     sync.before_staging();
+    sync.mark(0x21);
     // X: power-of-two operand scales -- as from the sources' range certificates (few records: every wave reduces them
     // itself, no barrier), 1 / ws from the packed weights' tail
     float ascale = 1.f, unscale = 1.f;
@@ -279,6 +292,7 @@ __device__ __forceinline__ void ks_item(const KsArgs& A, const int tile, const i
         }
     }
 
+    sync.mark(0x22);
     // ---- K loop: this wave's NKS groups of four channels, all taps ------------------------------------------------------
     f32x4 acc[MBW][R][NB];
 #pragma unroll
@@ -341,7 +355,9 @@ __device__ __forceinline__ void ks_item(const KsArgs& A, const int tile, const i
     }
 
     // ---- the four partial sums meet in LDS; wave w finishes the accumulators with index == w (mod 4) -------------------
+    sync.mark(0x23);
     __syncthreads();                                   // every wave is done with its staging region
+    sync.mark(0x24);
     f32x4* red = reinterpret_cast<f32x4*>(lds);        // [KSPLIT waves][NACC][64 lanes]
 #pragma unroll
     for (int m = 0; m < MBW; ++m)
@@ -395,6 +411,7 @@ __device__ __forceinline__ void ks_item(const KsArgs& A, const int tile, const i
                 }
             }
 
+    sync.mark(0x25);
     // ---- statistics: one record per (workgroup, channel [, parity class]) ------------------------------------------------
     if (A.partials) {
         __syncthreads();                               // the reduction scratch has been read
@@ -439,9 +456,10 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The persistent CHAIN kernel (round 6): a run of consecutive K-split layers of the hourglass -- at 960x540, D = 192 the
-// eleven layers of levels 1-3 (regularization.py:22-26, 48-52: contraction 1-3, expansion 0-1 and the transposed
-// convolution of expansion 2) -- as ONE launch instead of eleven launches + eleven in_finalize launches.
+// The persistent CHAIN kernel (round 6; opt-in, see conv3d_ks_chain_enabled): a run of consecutive K-split layers of the
+// hourglass -- at 960x540, D = 192 the eleven layers of levels 1-3 (regularization.py:22-26, 48-52: contraction 1-3,
+// expansion 0-1 and the transposed convolution of expansion 2) -- as ONE launch instead of eleven launches + eleven
+// in_finalize launches.
 //
 //   work list   every phase (layer) is a list of tickets; a ticket is 8 / KSPLIT items (4-wave configurations run two
 //               items side by side in the 8-wave workgroup).  Workgroups draw tickets from ONE atomic counter, in order.
@@ -456,8 +474,9 @@ __global__ __launch_bounds__(64 * KSPLIT) void conv3d_ks_kernel(const KsArgs A) 
 //               stores ready[p].  Consumers: one lane polls ready[p] relaxed, ONE agent acquire, barrier, plain loads;
 //               folded coefficients by agent-scope loads (never through the scalar cache).
 //               (MI355X_MICROARCH.md, "inter-workgroup visibility"; cdna_hip_programming.md Guideline 16.)
-//   state       the counters are zeroed by a hipMemsetAsync node ahead of every launch.
-constexpr int kKsChainMax = 11;            // (11 phases x 336 bytes + header: the kernel arguments stay under 4 KB)
+//   state       the phase table lives in device memory next to the counters; a one-workgroup launch ahead of every chain
+//               launch writes it and zeroes the counters (never a left-over of an earlier, possibly failed, launch).
+constexpr int kKsChainMax = 11;            // (the set-up kernel takes the table by value: 11 phases x 336 bytes + header < 4 KB)
 constexpr int kKsChainThreads = 512;
 constexpr int kKsSyncWords = kKsChainSyncWords;   // [0] head, [16 + p] done, [32 + p] ready, [48 + p] time stamps (debug)
 
@@ -509,14 +528,56 @@ __host__ __device__ constexpr int ks_cfg_id(int mode, int nb, int cin) {
 
 // one out-of-line function per configuration: compiled once each (the thirty bodies inlined into one kernel took the
 // compiler five minutes and the register allocator 5 KB of scratch per lane)
+#ifdef PDS_KS_CHAIN_MARK
+#define PDS_KS_MARK(stage) do { if (tid == 0) __hip_atomic_store(C.sync + 1024 + blockIdx.x, (unsigned)(stage) | ((unsigned)ticket << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define PDS_KS_MARK(stage) do {} while (0)
+#endif
+// (function arguments arrive in vector registers: the wave-uniform ones are moved back to scalar registers, so that the
+// phase description -- a table in device memory, written by ks_chain_setup_kernel -- is read with scalar loads)
+template <class T>
+__device__ __forceinline__ T* ks_uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
 template <int MODE, int NB, int MBW, int KSPLIT, int NKS, bool X>
-__device__ __attribute__((noinline)) void ks_chain_item(const KsArgs* A, int tile, int mb0, int nb, float* region, int gwave,
-                                                        int gtid, bool active, const unsigned* ready, unsigned* nonfinite) {
-    ks_item<MODE, 1, 1, NB, MBW, KSPLIT, NKS, X>(*A, tile, mb0, nb, region, gwave, gtid, active, KsInLaunch{ready, nonfinite});
+__device__ __attribute__((noinline)) void ks_chain_item(const KsArgs* __restrict__ A, int tile, int mb0, int nb, int region_floats,
+                                                        int gwave, int gtid, int active, const unsigned* ready,
+                                                        unsigned* nonfinite, unsigned* marks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // the phase description through the CONSTANT address space: scalar loads into scalar registers (written by the set-up
+    // launch, never during this one), so buffer descriptors and weight pointers derived from it are wave-uniform -- read
+    // through the generic pointer every field was a flat vector load and every buffer load sat in a waterfall loop
+    typedef const unsigned __attribute__((address_space(4))) * ConstWords;
+    ConstWords src = reinterpret_cast<ConstWords>(reinterpret_cast<unsigned long long>(ks_uniform_ptr(A)));
+    alignas(8) unsigned words[sizeof(KsArgs) / sizeof(unsigned)];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(KsArgs) / sizeof(unsigned)); ++i) words[i] = src[i];
+    const KsArgs& args = *reinterpret_cast<const KsArgs*>(words);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    mb0 = __builtin_amdgcn_readfirstlane(mb0);
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    gwave = __builtin_amdgcn_readfirstlane(gwave);
+    active = __builtin_amdgcn_readfirstlane(active);
+    region_floats = __builtin_amdgcn_readfirstlane(region_floats);
+    ks_item<MODE, 1, 1, NB, MBW, KSPLIT, NKS, X>(args, tile, mb0, nb, lds + region_floats, gwave, gtid, active != 0,
+                                                 KsInLaunch{ks_uniform_ptr(ready), ks_uniform_ptr(nonfinite), ks_uniform_ptr(marks)});
 }
 
-__global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const KsChainArgs C) {
+// writes the phase table of a launch into device memory and zeroes its synchronisation words (one small launch ahead of
+// the chain kernel: a by-value table in the chain kernel's own arguments cannot be handed to out-of-line functions
+// without a private copy per lane)
+__global__ __launch_bounds__(256) void ks_chain_setup_kernel(const KsChainArgs C, unsigned* __restrict__ table,
+                                                             unsigned* __restrict__ sync) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&C);
+    for (int i = threadIdx.x; i < (int)(sizeof(KsChainArgs) / sizeof(unsigned)); i += 256) table[i] = src[i];
+    for (int i = threadIdx.x; i < kKsSyncWords; i += 256) sync[i] = 0u;
+}
+
+__global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const KsChainArgs* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const KsChainArgs& C = *table;
     // (all LDS in the one dynamic array: the control words live behind the item regions)
     int* ctl = reinterpret_cast<int*>(lds + (160 * 1024 - 64) / sizeof(float));
     const int tid = threadIdx.x;
@@ -531,6 +592,8 @@ __global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const 
         const int ticket = __builtin_amdgcn_readfirstlane(ctl[0]);
         __syncthreads();   // (ctl[0] is rewritten by the next draw / the last-arriver flag below)
         if (ticket >= total) break;
+        if (ticket == 0 && tid == 0) C.sync[47] = (unsigned)wall_clock64();   // (debug: start stamp)
+        PDS_KS_MARK(1);
         int p = 0;
         while (ticket >= C.first[p + 1]) ++p;
         const KsPhase& P = C.ph[p];
@@ -540,24 +603,33 @@ __global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const 
         const bool active = item < P.items;
         item = min(item, P.items - 1);
         const int tile = item % P.A.tiles, mg = (item / P.A.tiles) % P.mgroups, nb = item / (P.A.tiles * P.mgroups);
-        float* region = lds + (size_t)sub * P.lds_stride;
+        const int region = sub * P.lds_stride;
         const int gwave = wave - sub * P.ksplit, gtid = tid - sub * P.ksplit * 64;
         const unsigned* wait_for = p > 0 ? ready + (p - 1) : nullptr;
+#ifdef PDS_KS_CHAIN_TRACE
+        if (tid == 0) printf("wg %d ticket %d phase %d cfg %d item %d tile %d mg %d\n", (int)blockIdx.x, ticket, p, P.cfg, item, tile, mg);
+#endif
         switch (P.cfg) {
 #define PDS_KS_CASE(MODE, NB, MBW, KSPLIT, NKS, X, CIN)                                                              \
     case ks_cfg_id(MODE, NB, CIN):                                                                                   \
         ks_chain_item<MODE, NB, MBW, KSPLIT, NKS, X>(&P.A, tile, mg * MBW, nb, region, gwave, gtid, active, wait_for, \
-                                                     C.nonfinite);                                                   \
+                                                     C.nonfinite, C.sync + 1024 + blockIdx.x);                       \
         break;
             PDS_KS_CHAIN_CONFIGS(PDS_KS_CASE)
 #undef PDS_KS_CASE
             default: break;
         }
+#ifdef PDS_KS_CHAIN_TRACE
+        if (tid == 0) printf("wg %d ticket %d item done\n", (int)blockIdx.x, ticket);
+#endif
+        PDS_KS_MARK(3);
         // ---- publish this ticket; the workgroup that completes the phase folds its InstanceNorm --------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
         __syncthreads();
         if (tid == 0) {
+#ifndef PDS_KS_ABL_NOFENCE   // (timing ablation builds only: results are wrong without the release)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restated where the compiler cannot drop it: Guideline 16 pitfall 12)
             const unsigned old = __hip_atomic_fetch_add(done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old + 1u == (unsigned)P.tickets;
@@ -567,12 +639,23 @@ __global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const 
         __syncthreads();
         const int last = __builtin_amdgcn_readfirstlane(ctl[0]);
         __syncthreads();
+        PDS_KS_MARK(4);
         if (last) {
+            PDS_KS_MARK(5);
+#ifndef PDS_KS_ABL_NOFOLD    // (timing ablation builds only)
             if (P.scale) {
+#else
+            if (false) {
+#endif
                 const int lane = tid & 63;
-                for (int g = wave; g < P.groups; g += kKsChainThreads / 64)
-                    in_finalize_group(P.A.partials, g, P.per_group, P.count, P.gamma, P.beta, P.channels, 1, P.scale,
-                                      P.shift, P.mean, P.rstd, C.nonfinite, lane);
+                // (four groups of a wave at a time: this one workgroup folds the whole layer while every other waits)
+                constexpr int kWaves = kKsChainThreads / 64, kBatch = 4;
+                for (int g = wave; g < P.groups; g += kWaves * kBatch) {
+                    const int left = (P.groups - g + kWaves - 1) / kWaves;
+                    in_finalize_groups<kBatch>(P.A.partials, g, kWaves, left < kBatch ? left : kBatch, P.per_group, P.count,
+                                               P.gamma, P.beta, P.channels, 1, P.scale, P.shift, P.mean, P.rstd, C.nonfinite,
+                                               lane);
+                }
                 if (wave == 0 && P.bound) in_finalize_bound(P.gamma, P.beta, P.channels, P.count, P.bound, lane);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -582,7 +665,15 @@ __global__ __launch_bounds__(kKsChainThreads) void conv3d_ks_chain_kernel(const 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 C.sync[48 + p] = (unsigned)wall_clock64();     // (debug: phase completion stamps, 100 MHz)
                 __hip_atomic_store(ready + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PDS_KS_CHAIN_TRACE
+                printf("wg %d phase %d READY\n", (int)blockIdx.x, p);
+#endif
             }
+            // NOT redundant: without a barrier between this lane-0 block and the lane-0 block at the head of the loop (the
+            // next draw) the compiler threads the two together across the back edge -- lane 0 leaves the loop body early,
+            // the other lanes of its wave run ahead into the next iteration's barriers and the workgroup never meets again
+            // (found on hardware, round 6: every phase's last arriver hung here)
+            __syncthreads();
         }
     }
 }
@@ -935,10 +1026,17 @@ int ks_chain_append(KsChain& chain, const KsLaunch& K, const KsChainFold& fold) 
 }
 }  // namespace
 
+// OFF by default: measured SLOWER than one launch + in_finalize per layer (round 6, 960x540 D = 192, the eleven layers of
+// levels 1-3: 706 us against 280 us of kernels + 60 us of in_finalize launches + ~45 us of boundaries; without its release
+// fences 620, without the in-launch InstanceNorm fold 493, without both 394 -- docs/LAB_NOTES.md, round 6).  A layer of
+// this network ends in a reduction over its whole output, so every phase boundary is a grid-wide hand-off: publish, fold
+// by ONE workgroup, notify, acquire cost more inside a launch than a kernel boundary + a 5 us launch that folds with one
+// wave per channel.  PDS_CONV3D_KS_CHAIN=1 (with PDS_DEBUG_SWITCHES=1) selects it; bit-identical results
+// (tools/chain_check.py, tests/test_gpu_chain.py).
 bool conv3d_ks_chain_enabled() {
-    static const bool on = []() {  // PDS_CONV3D_KS_CHAIN=0: one launch + in_finalize per layer (A/B, the bit-exactness reference)
+    static const bool on = []() {
         const char* e = debug_switch("PDS_CONV3D_KS_CHAIN");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     return on;
 }
@@ -965,6 +1063,23 @@ int deconv3d_ks_chain_add(KsChain& chain, const DeconvLayer& L, const KsChainFol
     return 0;
 }
 
+// debugging / profiling aid (pds_debug_chain_stamps): the synchronisation words and phase count of the last chain launch
+static unsigned* g_last_chain_sync = nullptr;
+static int g_last_chain_phases = 0;
+int ks_chain_debug_stamps(unsigned* out, int capacity) {
+    if (!g_last_chain_sync) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return set_error(-1, "chain stamps: hipDeviceSynchronize failed");
+    unsigned words[kKsSyncWords];
+    if (hipMemcpy(words, g_last_chain_sync, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess)
+        return set_error(-1, "chain stamps: hipMemcpy failed");
+    const int n = g_last_chain_phases < capacity ? g_last_chain_phases : capacity;
+    for (int i = 0; i < n; ++i) out[i] = words[48 + i] - words[47];   // ticks since the first ticket was drawn
+    // (behind them, when there is room: the raw words -- head, done[], ready[] -- for debugging a stuck chain)
+    if (capacity >= n + kKsSyncWords)
+        for (int i = 0; i < kKsSyncWords; ++i) out[n + i] = words[i];
+    return n;
+}
+
 int conv3d_ks_chain_launch(KsChain& chain, unsigned* sync_words, hipStream_t s) {
     if (chain.count == 0) return 0;
     if (!sync_words) return set_error(-1, "conv3d_ks chain: no synchronisation words");
@@ -979,6 +1094,8 @@ int conv3d_ks_chain_launch(KsChain& chain, unsigned* sync_words, hipStream_t s) 
     for (int p = chain.count; p <= kKsChainMax; ++p) C.first[p] = t;
     C.sync = sync_words;
     C.nonfinite = nonfinite_counter(s);
+    g_last_chain_sync = sync_words;
+    g_last_chain_phases = chain.count;
     chain.count = 0;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     static int cu_count = 256;
@@ -990,11 +1107,17 @@ int conv3d_ks_chain_launch(KsChain& chain, unsigned* sync_words, hipStream_t s) 
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
             cu_count = n;
     }
-    if (hipMemsetAsync(sync_words, 0, kKsSyncWords * sizeof(unsigned), s) != hipSuccess)
-        return set_error(-1, "conv3d_ks chain: hipMemsetAsync failed");
+    static_assert(sizeof(KsChainArgs) % sizeof(unsigned) == 0 &&
+                      sizeof(KsChainArgs) <= (kKsChainStateWords - kKsChainSyncWords) * sizeof(unsigned),
+                  "the chain's state carve does not hold the phase table");
+    unsigned* table = sync_words + kKsSyncWords;
+    C.sync = sync_words;
+    hipLaunchKernelGGL(ks_chain_setup_kernel, dim3(1), dim3(256), 0, s, C, table, sync_words);
+    if (int rc = check_launch("conv3d_ks_chain_setup")) return rc;
     const int grid = t < cu_count ? t : cu_count;    // one 8-wave workgroup per CU (256 registers per lane, 160 KB of LDS)
     const int probe = probe_before("conv3d_ks_chain", s);
-    hipLaunchKernelGGL(conv3d_ks_chain_kernel, dim3(grid), dim3(kKsChainThreads), 160 * 1024, s, C);
+    hipLaunchKernelGGL(conv3d_ks_chain_kernel, dim3(grid), dim3(kKsChainThreads), 160 * 1024, s,
+                       reinterpret_cast<const KsChainArgs*>(table));
     probe_after(probe, grid, s);
     return check_launch("conv3d_ks_chain");
 }

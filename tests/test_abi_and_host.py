@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol(hip_library):
         assert hasattr(raw, name), 'libpds_hip.so does not export %s' % name
         assert name in _lib.SIGNATURES, 'python binding lacks %s' % name
     assert sorted(_lib.SIGNATURES) == names
-    assert hip_library.pds_abi_version() == 5
+    assert hip_library.pds_abi_version() == 6
 
 
 def test_argument_validation_needs_no_gpu(hip_library):
