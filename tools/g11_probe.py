@@ -18,7 +18,7 @@ for i, (name, p) in enumerate(net.named_parameters()):
     top = float(w64.abs().max()) + 1e-30
     rows.append((float((mine-w64).abs().max())/top, float((w32-w64).abs().max())/top, float(g['grad_reference_vs_fp64_rel'][i]), name))
 rows.sort(reverse=True)
-print('PDS_X3', os.environ.get('PDS_X3'))
+print('PDS_X3', os.environ.get('PDS_X3'), '(honoured only with PDS_DEBUG_SWITCHES=1:', os.environ.get('PDS_DEBUG_SWITCHES'), ')')
 for r in rows[:12]: print('%.2e mine  %.2e ref  %.2e ref(full)  %s' % r)
 q = [r for r in rows if r[2] < 1e-3]
 print('qualifying', len(q), 'worst mine %.2e' % max(r[0] for r in q), 'ratio max %.1f' % max(r[0]/max(r[1],1e-9) for r in q))
