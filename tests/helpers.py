@@ -58,3 +58,17 @@ def host_descriptors(net, image):
     padded = pds_oracle.pad_to_multiple(image)[0]
     with torch.no_grad():
         return pds_oracle.embedding(params, '_embedding', padded)
+
+
+def flip_allowance(params, ld, rd, shortcut, maximum_disparity, disparity_fp32, slack=2):
+    """How many arg-max flips a result may show against the oracle's fp32 disparity, DERIVED from this run instead of a
+    constant: the oracle is run once more in fp64 on the same inputs; its own fp32 run flips F pixels
+    against that truth, and a result that is no further from the truth than the reference (F + slack flips against fp64)
+    can differ from the fp32 run at no more than F + (F + slack) pixels (a pixel differs from the fp32 run only if one of
+    the two differs from the truth).  Returns (allowance against the fp32 oracle, fp64 disparity, F)."""
+    from oracle import pds_oracle
+    with torch.no_grad():
+        truth = pds_oracle.hot_path(pds_oracle.cast_params(params, torch.float64), ld.double(), rd.double(),
+                                    shortcut.double(), maximum_disparity)
+    reference_flips = int(((disparity_fp32.detach().double().cpu() - truth).abs() > 0.5).sum())
+    return 2 * reference_flips + slack, truth, reference_flips

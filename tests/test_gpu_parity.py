@@ -296,7 +296,11 @@ def test_config1_hot_path_vs_golden(dev):
     print('config1 disparity', rep)
     flipped = round(rep['flips'] * disparity.numel())
     assert rep['mae_noflip'] <= 1e-4, rep
-    assert flipped <= 3, rep
+    # allowance from the same-run fp64 arbiter (helpers.flip_allowance), not a constant
+    allowed, _, ref_flips = helpers.flip_allowance({k: v.cpu() for k, v in net.state_dict().items()}, ld, rd, shortcut, 63,
+                                                   g['disparity'], slack=2)
+    print('config1: reference fp32 flips vs fp64 %d -> allowance %d, seen %d' % (ref_flips, allowed, flipped))
+    assert flipped <= allowed, rep
     # raw MAE: 1e-3 (north_star) with no flip; every flipped arg-max may add its own jump (at most 63 px / 32 768 px)
     assert rep['mae'] <= TOL_DISPARITY_MAE + flipped * 63.0 / disparity.numel(), rep
     p32 = {k: v.cpu() for k, v in net.state_dict().items()}
@@ -359,7 +363,11 @@ def test_config2_full_size_vs_oracle_and_golden(dev):
     #                                               test_config2_fp64_arbiter
     rep = helpers.disparity_report(disparity, disp_o)
     print('config2 disparity vs oracle', rep)
-    assert round(rep['flips'] * disparity.numel()) <= 8, rep
+    # allowance from the same-run fp64 arbiter (helpers.flip_allowance): 2 x the reference's own fp32-vs-fp64 flips + 2
+    allowed, _, ref_flips = helpers.flip_allowance(p, ld, rd, shortcut, 191, disp_o)
+    print('config2: reference fp32 flips vs fp64 %d -> allowance %d, seen %d' %
+          (ref_flips, allowed, round(rep['flips'] * disparity.numel())))
+    assert round(rep['flips'] * disparity.numel()) <= allowed, rep
     assert rep['mae_noflip'] <= 1e-4, rep
     assert rep['mae'] <= TOL_DISPARITY_MAE, rep
     # the committed sub-sample of the reference's own output (2 160 pixels: one ~100 px flip alone is 0.046 of MAE):
@@ -372,7 +380,7 @@ def test_config2_full_size_vs_oracle_and_golden(dev):
     _, _, fused = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     rep_f = helpers.disparity_report(fused, disp_o)
     print('config2 fused disparity vs oracle', rep_f)
-    assert round(rep_f['flips'] * fused.numel()) <= 8 and rep_f['mae_noflip'] <= 1e-4, rep_f
+    assert round(rep_f['flips'] * fused.numel()) <= allowed and rep_f['mae_noflip'] <= 1e-4, rep_f
     assert rep_f['mae'] <= TOL_DISPARITY_MAE, rep_f
     # BASELINE configs[2] at full size: the 48 planes as 2 / 4 / 8 shards of 24 / 12 / 6 planes (what the ranks of
     # distributed.ShardedMatching compute, here one after the other on this GPU); the gathered signatures must equal
@@ -433,7 +441,9 @@ def test_config4_kitti_shape_batch(dev):
     _, _, disparity = run_hot_path(net, dev, ld, rd, shortcut, fuse=True)
     rep = helpers.disparity_report(disparity, disp_o)
     print('config4 disparity vs oracle', rep)
-    assert round(rep['flips'] * disparity.numel()) <= 12 and rep['mae_noflip'] <= 1e-4, rep   # 983 040 pixels
+    allowed, _, ref_flips = helpers.flip_allowance(p, ld, rd, shortcut, 255, disp_o)   # (983 040 pixels)
+    print('config4: reference fp32 flips vs fp64 %d -> allowance %d' % (ref_flips, allowed))
+    assert round(rep['flips'] * disparity.numel()) <= allowed and rep['mae_noflip'] <= 1e-4, rep
     assert rep['mae'] <= TOL_DISPARITY_MAE, rep
     out = net._size_adapter.unpad(disparity)
     assert out.shape == (2, 375, 1242)
@@ -496,7 +506,9 @@ def test_config4_full_batch_values(dev):
         assert helpers.maxdiff(cost_sub[b:b + 1], cost_o[:, ::8, ::16, ::16]) <= TOL_COST_MAX, b
         rep = helpers.disparity_report(disparity[b:b + 1], disp_o)
         print('config4 batch entry', b, rep)
-        assert round(rep['flips'] * disp_o.numel()) <= 6 and rep['mae_noflip'] <= 1e-4, rep
+        allowed, _, ref_flips = helpers.flip_allowance(params, ld[b:b + 1], rd[b:b + 1], sc[b:b + 1], 255, disp_o)
+        print('config4 batch entry', b, 'reference fp32 flips vs fp64 %d -> allowance %d' % (ref_flips, allowed))
+        assert round(rep['flips'] * disp_o.numel()) <= allowed and rep['mae_noflip'] <= 1e-4, rep
         assert rep['mae'] <= TOL_DISPARITY_MAE, rep
 
 
