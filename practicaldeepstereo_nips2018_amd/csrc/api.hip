@@ -168,6 +168,7 @@ DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvB
     else if (allow_mfma && conv2d_mfma_supported(L)) kind = conv2d_wino_eligible(L) ? 4 : 2;
     else if (allow_mfma && conv3d_t8_supported(L)) kind = 6;   // persistent z-Toeplitz kernel, no weight packing
     else if (allow_mfma && conv3d_ks_supported(L)) kind = 7;   // inner levels: K split over the waves
+    else if (allow_mfma && conv3d_nx_supported(L)) kind = 10;  // 16-channel quarter-resolution layers: fp16-split operands
     else if (allow_mfma && conv3d_mfma_supported(L)) kind = 3;
     if (kind == 2)
         L.packed = c.get<float>(conv2d_mfma_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
@@ -175,6 +176,7 @@ DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvB
         L.packed = c.get<float>(conv2d_wino_packed_floats(in.c, cout) * (L.plane_weight_sets > 0 ? L.plane_weight_sets : 1));
     if (kind == 3) L.packed = c.get<float>(conv3d_mfma_packed_floats(o.g, in.c, stride));
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
+    if (kind == 10) L.packed = c.get<float>(conv3d_nx_packed_floats(in.c, cout));
     if (kind == 9) L.packed = c.get<float>(conv2d_x3_packed_floats(in.c));
     // (conv2d_t8 / conv2d_t8w read planar tensors only: nothing but conv2d_x3 takes or writes the blocked layout)
     if ((a.cb8 || b.cb8 || L.out_cb8) && !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
@@ -199,6 +201,7 @@ DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvB
                                      : kind == 3 ? launch_conv3d_mfma(L, c.s)
                                                  : kind == 6 ? launch_conv3d_t8(L, c.s)
                                                              : kind == 7 ? launch_conv3d_ks(L, c.s)
+                                                             : kind == 10 ? launch_conv3d_nx(L, c.s)
                                                                          : kind == 8 ? launch_conv2d_t8(L, c.s)
                                                                                      : kind == 9 ? launch_conv2d_x3(L, c.s) : launch_conv_direct(L, c.s);
     };
@@ -211,8 +214,9 @@ DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvB
                                     : kind == 9 ? conv2d_x3_tiles(L)
                                     : kind == 3 ? conv3d_mfma_tiles(o.g, in.c, stride)
                                     : kind == 6 ? conv3d_t8_records(o.g)
-                                    : kind == 7 ? conv3d_ks_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
-        const bool volume_records = kind == 3 || kind == 6 || kind == 7;   // [(n, c)][record] instead of [(n, c, d)][tile]
+                                    : kind == 7 ? conv3d_ks_tiles(o.g)
+                                    : kind == 10 ? conv3d_nx_tiles(o.g) : conv_direct_tiles_for(o.g, stride);
+        const bool volume_records = kind == 3 || kind == 6 || kind == 7 || kind == 10;   // [(n, c)][record] instead of [(n, c, d)][tile]
         const size_t records = (size_t)o.g.n * o.g.c * (volume_records ? 1 : o.g.d) * tiles;
         L.partials = c.get<double>(records * 2);
         const int groups = o.g.n * o.g.c * (per_plane ? o.g.d : 1);

@@ -33,6 +33,10 @@ int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma
 bool conv3d_mfma_supported(const ConvLayer& L);
 int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
 size_t conv3d_mfma_packed_floats(const Geom& out_g, int cin, int stride);
+int launch_conv3d_nx(const ConvLayer& L, hipStream_t s);          // conv3d_nx.hip (16 -> 16 channels, quarter resolution, fp16 split)
+bool conv3d_nx_supported(const ConvLayer& L);
+int conv3d_nx_tiles(const Geom& out_g);
+size_t conv3d_nx_packed_floats(int cin, int cout);
 int launch_conv3d_t8(const ConvLayer& L, hipStream_t s);          // conv3d_t8.hip (8 -> 8 channels, stride 1)
 bool conv3d_t8_supported(const ConvLayer& L);
 int conv3d_t8_records(const Geom& out_g);
