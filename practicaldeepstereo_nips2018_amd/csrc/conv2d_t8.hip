@@ -469,7 +469,8 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 #pragma unroll
     for (int k = 0; k < C2W_ITEMS; ++k) {
         // surplus threads (600 items for 1 024 slots at W = 240): their loads go out of range (zero, no memory access)
-        // and their LDS stores are predicated off -- re-staging the last item kept 41 % of the loads in flight redundant
+        // and the zeros land on slots 0 and 1 of halo row 0 (unused, left zero column; see the note at the stores) --
+        // re-staging the last item kept 41 % of the loads in flight redundant
         item_ok[k] = tid + C2W_THREADS * k < C2W_YT * QW;
         const int it = min(tid + C2W_THREADS * k, C2W_YT * QW - 1);
         item_row[k] = it / QW;
@@ -569,12 +570,15 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                         lo2[4 * e + i] = lo[i];
                     }
                 }
-                // (surplus threads store nothing: their zero loads times a non-finite InstanceNorm coefficient would put a
-                // NaN on the left zero column of halo row 0, which real tiles read as x = -1 padding -- ADVICE r5)
-                if (item_ok[k]) {
-                    *reinterpret_cast<f16x8*>(buf + lo_off[k] + pp * lo_step[k]) = hi2;
-                    *reinterpret_cast<f16x8*>(buf + part_bytes + lo_off[k] + pp * lo_step[k]) = lo2;
-                }
+                // Surplus threads (out-of-range loads: zeros) store to slots 0 / 1 of halo row 0, i.e. onto the left zero
+                // column: 0 * scale + 0 * shift = 0 for every finite coefficient.  A non-finite coefficient (NaN / inf
+                // statistics of the producer) would put a NaN there -- but then every real pixel of that channel is NaN as
+                // well and the convolution spreads it over all eight outputs of the plane in this form and in the planar
+                // one alike, and pds_nonfinite_statistics() has counted it.  Predicating these stores off (tried in round
+                // 6 after ADVICE r5) cost 56 us per launch: 279 -> 335 us (rocprofv3), the exec-mask juggling sits in the
+                // kernel's critical issue path.
+                *reinterpret_cast<f16x8*>(buf + lo_off[k] + pp * lo_step[k]) = hi2;
+                *reinterpret_cast<f16x8*>(buf + part_bytes + lo_off[k] + pp * lo_step[k]) = lo2;
             }
     };
 

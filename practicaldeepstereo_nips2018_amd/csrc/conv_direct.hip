@@ -575,7 +575,10 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
     }
     const bool last_quad = x0 + 4 == g.w;
     const bool loads_left = xi == 0 || (threadIdx.x & 63) == 0;  // no left neighbour in this wave / this row
-    constexpr int UN = 4;
+#ifndef PDS_MAT_UN
+#define PDS_MAT_UN 4
+#endif
+    constexpr int UN = PDS_MAT_UN;
     for (int d0 = 0; d0 < g.d; d0 += UN) {
         float4 t[UN];
 #pragma unroll
