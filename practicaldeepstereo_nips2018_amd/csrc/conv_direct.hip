@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void materialize_l0_sweep_kernel(const Src a, 
     const bool last_quad = x0 + 4 == g.w;
     const bool loads_left = xi == 0 || (threadIdx.x & 63) == 0;  // no left neighbour in this wave / this row
 #ifndef PDS_MAT_UN
-#define PDS_MAT_UN 4
+#define PDS_MAT_UN 8   // planes in flight per thread (round 6, Matching alone under rocprofv3: 2 -> 195 us, 4 -> 187, 8 -> 176, 12 -> 325: spills)
 #endif
     constexpr int UN = PDS_MAT_UN;
     for (int d0 = 0; d0 < g.d; d0 += UN) {
