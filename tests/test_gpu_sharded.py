@@ -6,6 +6,8 @@ pds_matching_fwd(d_begin, d_count), one all-gather reassembles the signatures, t
 a side stream.  Every result must equal the unsharded hot path bit for bit."""
 import os
 import socket
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -13,6 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def free_port():
@@ -104,3 +107,18 @@ def test_sharded_hot_path_two_ranks_on_one_gpu(hip_library):
             p.join(10)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert all(results.get(r) for r in range(2)), dict(results)
+
+
+def test_rccl_single_rank_preflight(hip_library):
+    """The collectives pre-flight on a REAL RCCL communicator (one rank: the only RCCL group a 1-GPU box can form): all-reduce,
+    every all-gather form on the exact shards of configs[2] / configs[3], and RCCL's own rank count through the
+    communicator handle (ncclCommCount; `collectives.nranks_seen` of the bench line) -- tools/nccl_single_rank_check.py."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'nccl_single_rank_check.py')], cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode(errors='replace')
+    lines = [l for l in text.splitlines() if l.startswith('PREFLIGHT')]
+    assert out.returncode == 0 and lines, text[-2000:]
+    assert "'gather_mode': 'coalesced'" in lines[-1] and "'nranks_seen': 1" in lines[-1], lines[-1]
+    assert "[1, 8, 48, 144, 240]" in lines[-1] and "[4, 8, 64, 96, 320]" in lines[-1], lines[-1]
