@@ -406,12 +406,18 @@ __global__ __launch_bounds__(C2_THREADS, 2) void conv2d_t8_kernel(const C2Args A
 //               padding (written once; the image row starts at slot 2 so that a lane's four pixels are 16-byte aligned), rows outside the image are zero through the range check of the buffer loads.
 //   pipeline    two register sets: chunk g + 1 is split / written while chunk g is multiplied, chunks g + 2 and g + 3
 //               are in flight (a thread loads two (row, aligned quad) items x 4 channels x 2 sources per chunk).
-constexpr int C2W_THREADS = 512, C2W_TY = 8, C2W_YT = C2W_TY + 2, C2W_ITEMS = 2;
+// Round 6: tile height (8 or 6 rows) and staging items per thread are template parameters.  At W = 240 an 8-row tile has
+// 10 x 60 = 600 staging items for 512 threads: six of the eight waves issued a second set of eight 16-byte loads (and
+// converted its zeros) for nothing -- a build that staged only the first 512 items ran 279 -> 238 us (LAB_NOTES, round 5) --
+// and three attempts to let them skip it spilled.  A 6-row tile has 8 x 60 = 480 items: ONE item per thread, half the
+// staging registers; its fourth row pair does not exist, so waves 3 and 7 only stage.
+constexpr int C2W_THREADS = 512;
 constexpr int C2W_MAXW = 352;   // LDS: 48 KB of weights + 4 x 10 x (W + 4) x 8 bytes <= 160 KB
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool TWO, int NBH>
+template <bool TWO, int NBH, int C2W_TY, int C2W_ITEMS>
 __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args A) {
+    constexpr int C2W_YT = C2W_TY + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* abuf = lds;                           // [96 fragments][64 lanes][4 x fp16]
     unsigned char* ibuf = lds + C2_ABYTES;               // [2][hi | lo][10 rows][W + 2][4 x fp16]
@@ -691,7 +697,9 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
                 for (int j = 0; j < NBH; ++j) {
                     float t = acc[j][r] * SC.unscale;
                     if (A.lrelu) t = fmaxf(t, t * kLeakySlope);
-                    const bool ok = y < A.H && 16 * (half * NBH + j) + n16 < A.W;
+                    // (6-row tiles: the fourth row pair belongs to the next tile -- its waves multiplied whatever lies behind
+                    // the eight halo rows and store nothing)
+                    const bool ok = 2 * pair < C2W_TY && y < A.H && 16 * (half * NBH + j) + n16 < A.W;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), ro,
                                                           ok ? out_lane + (h ? out_c1 : 0u) + 64u * j : ~0u, row_bytes, 0);
                 }
@@ -755,22 +763,23 @@ bool c2t8_wide(const ConvLayer& L) {
     }();
     if (!on) return false;
     if (!L.a.scale || (L.b.p && L.b.scale)) return false;            // (source a normalised, source b plain or absent)
-    return (L.in.w & 3) == 0 && L.in.w >= 64 && L.in.w <= C2W_MAXW && L.in.h >= C2W_TY;
+    return (L.in.w & 3) == 0 && L.in.w >= 64 && L.in.w <= C2W_MAXW && L.in.h >= 8;
 }
 
-template <bool TWO, int NBH>
+template <bool TWO, int NBH, int TY, int ITEMS>
 int launch_c2t8w(C2Args& A, hipStream_t s) {
     A.tiles_x = 1;
-    A.tiles_y = (A.H + C2W_TY - 1) / C2W_TY;
+    A.tiles_y = (A.H + TY - 1) / TY;
     A.tiles = A.N * A.D * A.tiles_y;
-    // (+ 256 bytes of slack: column blocks past the end of the last row are read, never used)
-    const size_t lds_bytes = (size_t)C2_ABYTES + 2 * 2 * (size_t)C2W_YT * (A.W + 4) * 8 + 256;
+    // (+ two halo rows and 256 bytes of slack: column blocks past the end of the last row -- and, with 6-row tiles, the
+    // rows of the non-existent fourth row pair -- are read, never used)
+    const size_t lds_bytes = (size_t)C2_ABYTES + 2 * 2 * (size_t)(TY + 2) * (A.W + 4) * 8 + 2 * (size_t)(A.W + 4) * 8 + 256;
     static std::atomic<unsigned> attr_done{0};   // one bit per device
     static int cus[32] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8w_kernel<TWO, NBH>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8w_kernel<TWO, NBH, TY, ITEMS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         int n = 0;
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -779,9 +788,20 @@ int launch_c2t8w(C2Args& A, hipStream_t s) {
     int wgs = cus[dev & 31] / 8 * 8;
     if (wgs > A.tiles) wgs = (A.tiles + 7) / 8 * 8;
     const int probe = probe_before("conv2d_t8w", s);
-    hipLaunchKernelGGL((conv2d_t8w_kernel<TWO, NBH>), dim3(wgs), dim3(C2W_THREADS), lds_bytes, s, A);
+    hipLaunchKernelGGL((conv2d_t8w_kernel<TWO, NBH, TY, ITEMS>), dim3(wgs), dim3(C2W_THREADS), lds_bytes, s, A);
     probe_after(probe, A.tiles, s);
     return check_launch("conv2d_t8w");
+}
+
+// tile height of the full-width form: 6 rows where that brings the staging items of a tile (halo rows x quads of columns)
+// down to one per thread (W <= 256), else 8 (PDS_CONV2D_T8W_ROWS=8 | 6 forces one, A/B)
+int c2t8w_rows(int w) {
+    static const int forced = []() {
+        const char* e = debug_switch("PDS_CONV2D_T8W_ROWS");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 8 || forced == 6) return forced;
+    return 8 * (w >> 2) <= C2W_THREADS ? 6 : 8;
 }
 
 // the bare 64 -> 8 convolution (no statistics wanted), plain Matching layer without the layer-0 riders
@@ -817,8 +837,11 @@ int launch_conv2d_t8(const ConvLayer& L, hipStream_t s) {
         return set_error(-1, "conv2d_t8: a source without a range bound");
     if (c2t8_wide(L)) {
         const int blocks = (A.W + 15) / 16, nbh = (blocks + 1) / 2;
-        if (nbh <= 8) return L.b.p ? launch_c2t8w<true, 8>(A, s) : launch_c2t8w<false, 8>(A, s);
-        return L.b.p ? launch_c2t8w<true, 11>(A, s) : launch_c2t8w<false, 11>(A, s);
+        const int rows = c2t8w_rows(A.W), items = ((rows + 2) * (A.W >> 2) + C2W_THREADS - 1) / C2W_THREADS;
+        if (nbh <= 8 && rows == 6 && items == 1)
+            return L.b.p ? launch_c2t8w<true, 8, 6, 1>(A, s) : launch_c2t8w<false, 8, 6, 1>(A, s);
+        if (nbh <= 8) return L.b.p ? launch_c2t8w<true, 8, 8, 2>(A, s) : launch_c2t8w<false, 8, 8, 2>(A, s);
+        return L.b.p ? launch_c2t8w<true, 11, 8, 2>(A, s) : launch_c2t8w<false, 11, 8, 2>(A, s);
     }
     const bool na = L.a.scale != nullptr, nb2 = L.b.p && L.b.scale;
     if (L.b.p) {

@@ -25,6 +25,7 @@ SWITCHES = [
     {'PDS_DECONV_CELL_X': '0'},     # exact-fp32 MFMAs in the dense-cell transposed convolutions
     {'PDS_CONV2D_T8': '0'},         # generic kernel for the 64 -> 8 signature convolution
     {'PDS_CONV2D_T8W': '0'},        # ... its 16 x 32-tile form instead of the full-width one
+    {'PDS_CONV2D_T8W_ROWS': '8'},   # ... 8-row tiles (two staging items per thread) where round 6 takes 6-row tiles
     {'PDS_WINO_ROWS6': '0'},        # 4-row tiles in every Winograd launch (before the 6-row form of the small launches)
     {'PDS_CONV3D_KSX': '0'},        # exact-fp32 MFMAs in every K-split layer of the deep hourglass levels (round 5)
     {'PDS_CONV3D_KS_LIMIT': '1000'},   # the K-split kernel only for the two deepest levels of the hourglass
