@@ -144,17 +144,10 @@ template <int T>
 static void launch_t(const float* sim, float* disp, int batch, int planes, size_t px, int lo, int hi, int step,
                      hipStream_t s) {
     // pixels per lane: 16-byte loads are the widest, but the sweep is a chain of dependent steps per lane, so what fills
-    // the memory pipes is the number of waves: two pixels per lane (8-byte loads, twice the waves) measured fastest
-    // (PDS_SUBPIXEL_VEC=1|2|4 selects another width for A/B)
-    static const int vec_pref = []() {
-        const char* e = debug_switch("PDS_SUBPIXEL_VEC");
-        return e ? atoi(e) : 2;
-    }();
-    if (px % 4 == 0 && vec_pref == 4) {
-        dim3 grid((unsigned)((px / 4 + 255) / 256), batch);
-        hipLaunchKernelGGL((subpixel_map_kernel<T, 4>), grid, dim3(256), 0, s, sim, disp, planes, px, lo, hi,
-                           (float)step);
-    } else if (px % 2 == 0 && vec_pref >= 2) {
+    // the memory pipes is the number of waves: two pixels per lane (8-byte loads, twice the waves) measured fastest in
+    // rounds 3-5; the four-pixel form and its switch (PDS_SUBPIXEL_VEC) were retired in round 6.  One pixel per lane
+    // serves odd pixel counts.
+    if (px % 2 == 0) {
         dim3 grid((unsigned)((px / 2 + 255) / 256), batch);
         hipLaunchKernelGGL((subpixel_map_kernel<T, 2>), grid, dim3(256), 0, s, sim, disp, planes, px, lo, hi,
                            (float)step);

@@ -30,8 +30,6 @@ SWITCHES = [
     {'PDS_CONV3D_KSX': '0'},        # exact-fp32 MFMAs in every K-split layer of the deep hourglass levels (round 5)
     {'PDS_CONV3D_KS_LIMIT': '1000'},   # the K-split kernel only for the two deepest levels of the hourglass
     {'PDS_CONV3D_NX': '0'},         # exact-fp32 kernel for the 16-channel quarter-resolution layers (before round 6)
-    {'PDS_SUBPIXEL_VEC': '1'},      # pixels per lane of the stand-alone SubpixelMap kernel
-    {'PDS_SUBPIXEL_VEC': '4'},
 ]
 
 
