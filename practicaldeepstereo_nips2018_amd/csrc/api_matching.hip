@@ -181,12 +181,14 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     // tensor between the two convolutions of a residual block (produced and consumed by conv2d_x3 alone); level 2 (opt-in,
     // PDS_MATCHING_CB8=2): in addition the first 64 -> 64 launch forms its input t1 = LeakyReLU(B + shift_d(H)) while it stages it, from the
     // channel-blocked layer-1 planes (misc.hip: l1_blocked_kernel) -- l1_combine only computes t1's statistics, the 425 MB
-    // round trip of t1 through HBM is gone.  Bit-identical; measured NEUTRAL (l1_combine 109 -> 63 us without its stores, + 20 us
-    // for the re-layout, + 11 us on the launch; 410 vs 408.5 pairs/s in a same-box A/B), so level 1 stays the default
+    // round trip of t1 through HBM is gone.  Bit-identical (l1_combine 109 -> 63 us without its stores, + 20 us for the re-layout,
+    // + 11 us on the launch).  Round 5 measured it neutral with 20-step timed regions (410 vs 408.5 pairs/s); with the 400-step
+    // regions of round 6 it is a small, repeatable gain -- 435.7 / 436.2 against 433.6 / 432.3 pairs/s and 2.603 / 2.609 against
+    // 2.627 / 2.635 ms per sequential pair, interleaved on one box -- so level 2 is the default now
     const int cb8_level = [&]() {
         static const int level = []() {   // PDS_MATCHING_CB8=0: planar NCDHW everywhere (A/B, tests)
             const char* e = debug_switch("PDS_MATCHING_CB8");
-            return e ? atoi(e) : 1;
+            return e ? atoi(e) : 2;   // (round 6: level 2 by default, see the note above)
         }();
         if (!(F == 64 && h % 16 == 0 && w % 16 == 0)) return 0;
         ConvLayer probe;   // would conv2d_x3 serve these layers in its fp16 form (PDS_X3 / PDS_X3_FP16 may say no)?
