@@ -94,3 +94,38 @@ def single_process_initial():
     import practicaldeepstereo_nips2018_amd as pds
     torch.manual_seed(0)
     return [p.detach().clone() for p in pds.PdsNetwork.default(MAX_DISPARITY).parameters()]
+
+
+def _run_bench_two_ranks(extra):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), both ranks on
+    cuda:0 through gloo (the box has one GPU); returns the parsed JSON line rank 0 printed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--share-device', '--backend',
+           'gloo'] + extra
+    out = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [l for l in out.stdout.decode(errors='replace').splitlines() if l.startswith('{')]
+    assert out.returncode == 0 and lines, out.stderr.decode(errors='replace')[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_train_line_two_ranks(hip_library):
+    """`bench.py --train` with world > 1 died on an undefined name right after its timed steps and never
+    printed its line.  The config-5 line of two ranks: one JSON line, weak scaling, replicas in sync."""
+    line = _run_bench_two_ranks(['--train', '--steps', '2', '--warmup', '1'])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['unit'] == 'pairs/s', line
+    assert line['value'] > 0 and line['replicas_in_sync'] is True, line
+    assert line['config']['collectives']['gather_mode'] in ('separate', 'single', 'coalesced'), line
+
+
+def test_bench_sharded_line_two_ranks(hip_library):
+    """The disparity-sharded line of two ranks (configs[2] with N = 2): bit-identical to the unsharded hot path, latency and
+    replica modes reported beside it, the collectives pre-flight recorded."""
+    line = _run_bench_two_ranks(['--steps', '8', '--warmup', '2', '--windows', '2'])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['sharded_equals_unsharded'] is True, line
+    assert line['latency_mode']['ms_per_frame'] > 0 and line['replica_mode']['value'] > 0, line
+    shards = line['config']['collectives']['gather_forms_tried']
+    assert '[1, 8, 24, 144, 240]' in shards and '[4, 8, 32, 96, 320]' in shards, shards
