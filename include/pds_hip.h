@@ -64,7 +64,9 @@ int pds_probe_end(float* ms, int* workgroups, int capacity);
  * layers the K-split kernel serves) run as ONE persistent launch whose workgroups walk the layer list (conv3d_ks.hip:
  * conv3d_ks_chain_kernel).  Synchronises the device and writes, for every layer of the LAST such launch of this
  * process, the time at which it was complete (InstanceNorm folded) in ticks of the 100 MHz device clock since the
- * first ticket of the launch was drawn; returns the number of layers (0: no such launch yet) or a negative error code. */
+ * first ticket of the launch was drawn; returns the number of layers (0: no such launch yet) or a negative error code.
+ * (The chain kernel never hangs the GPU: a workgroup whose producer layer does not report within 2 s stops waiting and
+ * adds 2^20 to the counter behind pds_nonfinite_statistics -- the results of that launch are then garbage, and visible as such.) */
 int pds_debug_chain_stamps(unsigned* ticks, int capacity);
 
 /* ------------------------------------------------------------------------------------
