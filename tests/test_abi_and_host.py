@@ -206,3 +206,35 @@ def test_workspace_commits_its_key_only_after_success(monkeypatch):
     ws.get(1024, None)                               # scratch use forgets the weights
     assert ws.get_resident(1024, None, 'k1')[1] is False
     assert ws.get_resident(1024, None, None)[1] is False   # no key: never resident
+
+
+def test_bench_host_helpers(tmp_path, monkeypatch):
+    """bench.py's host-side helpers that need no GPU: the kernel-switch gate (PDS_X3 must be ignored without
+    PDS_DEBUG_SWITCHES=1, as the library ignores it) and the shader-clock sampler's sysfs parser."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    monkeypatch.setenv('PDS_X3', '0')
+    monkeypatch.delenv('PDS_DEBUG_SWITCHES', raising=False)
+    sys.modules.pop('bench', None)
+    bench = importlib.import_module('bench')
+    assert bench.X3 is True and bench.CONV64_EXECUTED_PEAK == bench.BF16_MFMA_PEAK_TFLOPS   # the variable is ignored
+    monkeypatch.setenv('PDS_DEBUG_SWITCHES', '1')
+    sys.modules.pop('bench', None)
+    bench = importlib.import_module('bench')
+    assert bench.X3 is False and bench.CONV64_EXECUTED_PEAK == bench.FP32_MFMA_PEAK_TFLOPS     # armed: honoured
+    sys.modules.pop('bench', None)
+    # pp_dpm_sclk: the level marked '*' is the current clock; several cards -> the busiest (highest) one
+    a, b = tmp_path / 'a', tmp_path / 'b'
+    a.write_text('0: 132Mhz\n1: 2100Mhz *\n')
+    b.write_text('0: 132Mhz *\n1: 2400Mhz\n')
+    sampler = bench.ClockSampler()
+    sampler._files = [str(a), str(b)]
+    assert sampler._read_sysfs() == 2100.0
+    sampler._files = [str(tmp_path / 'missing')]
+    assert sampler._read_sysfs() is None
+    sampler.samples = [2100.0, 2400.0, 2000.0]
+    sampler.source = 'test'
+    summary = sampler.summary()
+    assert summary['sclk_mhz_min'] == 2000.0 and summary['sclk_mhz_median'] == 2100.0 and summary['sclk_mhz_max'] == 2400.0
