@@ -158,9 +158,6 @@ DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvB
         L.l1_edge = extra->l1_edge;
         L.l1_P = extra->l1_P;
         L.l1_d0 = extra->l1_d0;
-        L.l1_sum = extra->l1_sum;
-        L.l1_bound = extra->l1_bound;
-        L.l1_bound_n = extra->l1_bound_n;
     }
     o.cb8 = L.out_cb8 != 0;
     // kernel choice: 0 = direct VALU, 2 = conv2d MFMA (kd 1), 3 = conv3d MFMA (kd 3), 4 = conv2d MFMA in the
@@ -181,10 +178,8 @@ DT conv_block(Ctx& c, const Src& a, const Src& b, const Geom& in, const PdsConvB
     if (kind == 7) L.packed = c.get<float>(conv3d_ks_packed_floats(in.c, cout, 27));
     if (kind == 10) L.packed = c.get<float>(conv3d_nx_packed_floats(in.c, cout));
     if (kind == 9) L.packed = c.get<float>(conv2d_x3_packed_floats(in.c));
-    // (conv2d_x3 takes and writes the blocked layout; conv2d_t8w takes it for a normalised source b, round 6)
-    const bool t8w_cb8 = kind == 8 && !a.cb8 && !L.out_cb8 && b.p && b.cb8 && b.scale && conv2d_t8w_takes(in.h, in.w) && a.scale;
-    if ((a.cb8 || b.cb8 || L.out_cb8) && !t8w_cb8 &&
-        !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
+    // (conv2d_t8 / conv2d_t8w read planar tensors only: nothing but conv2d_x3 takes or writes the blocked layout)
+    if ((a.cb8 || b.cb8 || L.out_cb8) && !(kind == 9 && !b.p && conv2d_x3_cb8_ok(L, a.cb8 != 0, L.out_cb8 != 0))) {
         c.run(set_error(-1, "conv_block: a channel-blocked tensor reached a kernel that does not take it"));
         return o;
     }

@@ -29,7 +29,6 @@ int conv2d_x3_tiles(const ConvLayer& L);   // statistics records per plane (depe
 size_t conv2d_x3_packed_floats(int cin);
 int launch_conv2d_t8(const ConvLayer& L, hipStream_t s);          // conv2d_t8.hip (64 -> 8 channels, bare)
 bool conv2d_t8_supported(const ConvLayer& L);
-bool conv2d_t8w_takes(int h, int w);   // would the full-width form (the one that takes two normalised sources) serve planes of h x w?
 int launch_conv3d_mfma(const ConvLayer& L, hipStream_t s);        // conv3d_mfma.hip
 bool conv3d_mfma_supported(const ConvLayer& L);
 int conv3d_mfma_tiles(const Geom& out_g, int cin, int stride);
@@ -237,9 +236,6 @@ struct ConvExtra {
     const float* l1H = nullptr;
     unsigned l1_bstride = 0, l1_hstride = 0, l1_edge = 0;
     int l1_P = 0, l1_d0 = 0;
-    int l1_sum = 0;                    // the blocked planes are layer 0's: input = norm(a) + A[x] + G[x - d] (ConvLayer::l1_sum)
-    const float* l1_bound = nullptr;
-    int l1_bound_n = 0;
     bool matching_extras() const { return l0A || side_out || plane_weight_sets > 0; }
 };
 

@@ -279,22 +279,6 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
                                      d_count, t1.scale, t1.shift, t1.mean, t1.rstd, c.s, t1.bound));
         }
     }
-    // Round 6 (PDS_MATCHING_NOX1, two blocks): the first residual sum x1 = norm(t2) + x0 is not needed as a tensor by the
-    // 64 -> 8 layer -- its input norm(t4) + x1 is three terms, and the share of x0 factorises exactly like layer 1 did:
-    // W8 * x0 = B8 + shift_d(H8) + column corrections, with B8 / H8 = the 64 -> 8 convolution of the layer-0 planes A / G
-    // (two planes instead of D').  conv2d_t8w reads norm(t4) and norm(t2); x0_term_add_kernel adds the rest (misc.hip)
-    const int nox1 = [&]() {
-        static const int level = []() {
-            const char* e = debug_switch("PDS_MATCHING_NOX1");
-            return e ? atoi(e) : 0;
-        }();
-        const bool ok = columns && P.residual_blocks == 2 && P.signature_features == 8 && F == 64 && (w & 3) == 0 &&
-                        conv2d_t8w_takes(h, w);
-        // level 2: in addition the 64 -> 64 launch behind the sum forms it while it stages its input (conv2d_x3.hip: X3In<3>)
-        // from norm(t2) and the channel-blocked layer-0 planes -- the materialising pass is gone
-        return ok ? ((level >= 2 && !on_the_fly) ? 1 : level) : 0;
-    }();
-    fly.out_cb8 = nox1 >= 2;   // (level 2: t2 channel-blocked -- both its consumers take it so)
     DT t2 = on_the_fly ? conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1, nullptr, true, nullptr, nullptr, &fly)
                        : conv_block(c, t1.src(), none, g, P.blocks[1], F, 1, 1, 1);
     if (P.residual_blocks == 1) {
@@ -307,47 +291,18 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
     // buffer is dead once t2 exists, t2's once the residual sum is formed.
     // x_r = norm(t2) + x_{r-1} is a plain tensor: the kernel that forms it records its largest magnitudes, the range
     // certificate of the fp16-split kernels behind it (conv2d_x3, conv2d_t8)
-    float *y8 = nullptr, *cr8 = nullptr, *cr08 = nullptr;
-    if (nox1 >= 1) {
-        float* wcol8 = c.get<float>(9 * (size_t)F * 8);
-        cr8 = c.get<float>((size_t)batch * 8 * h * d_count * 2);
-        cr08 = c.get<float>((size_t)batch * 8 * h);
-        y8 = c.get<float>((size_t)batch * 8 * 2 * h * (w + 2));
-        if (c.before_packing()) c.run(launch_column_weights(P.last.weight, F, 0, F, 8, wcol8, c.s));
-        if (!c.plan) {
-            c.run(launch_l1_column_terms(y3 + (size_t)h * l0_rs, g2buf + (size_t)h * l0_rs, wcol8, cr8, cr08, l0_cstride,
-                                         l0_rs, l0_pad, batch, F, 8, h, w, d_begin, d_count, c.s));
-            c.run(launch_conv8_planes(y3, wcol8, y8, batch, F, h, w + 2, c.s));
-        }
-    }
     DT cur;
     cur.g = g;
     cur.raw = t1.raw;   // x1 = norm(t2) + x0 overwrites t1
-    ConvExtra sum;      // level 2: the source of the launch behind the sum
-    if (nox1 >= 2) {
-        sum = fly;      // the blocked layer-1 planes are dead: their buffers take the layer-0 planes (same sizes, same addressing)
-        sum.l1_sum = 1;
-        sum.l1_bound_n = l1_blocked_records(batch, F, h, w, fly.l1_P, d_count);
-        float* rec = c.get<float>(sum.l1_bound_n);
-        sum.l1_bound = rec;
-        if (!c.plan)
-            c.run(launch_l1_blocked(y3, nullptr, nullptr, const_cast<float*>(fly.l1B), const_cast<float*>(fly.l1H), batch, F, h,
-                                    w, fly.l1_P, d_begin, d_count, c.s, g2buf + (size_t)h * l0_rs, rec));
-    } else {
-        carve_amax(c, cur, materialize_l0_records(g));
-        if (!c.plan)
-            c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur.raw, c.s, cur.bound));
-    }
-    const DT t2_first = t2;
-    // (t2's buffer is free from here on unless the last layer reads it; at level 2 the sum's buffer is never written)
-    float* spare_a = nox1 >= 2 ? t1.raw : (nox1 == 1 ? c.get<float>(g.numel()) : t2.raw);
+    carve_amax(c, cur, materialize_l0_records(g));
+    if (!c.plan)
+        c.run(launch_materialize_l0(t2.src(), g, l0A, l0G, l0G2, l0_cstride, l0_rs, d_begin, cur.raw, c.s, cur.bound));
+    float* spare_a = t2.raw;                        // free from here on
     float* spare_b = c.get<float>(g.numel());
     for (int r = 1; r < P.residual_blocks; ++r) {
         ConvExtra blocked;
-        if (r == 1 && nox1 >= 2) blocked = sum;
         blocked.out_cb8 = cb8_level >= 1;
-        t1 = conv_block(c, (r == 1 && nox1 >= 2) ? t2_first.src() : cur.src(), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a, true,
-                        nullptr, nullptr, &blocked);
+        t1 = conv_block(c, cur.src(), none, g, P.blocks[2 * r], F, 1, 1, 1, spare_a, true, nullptr, nullptr, &blocked);
         t2 = conv_block(c, t1.src(), none, g, P.blocks[2 * r + 1], F, 1, 1, 1, spare_b);
         if (r + 1 < P.residual_blocks) {
             DT nxt;                                 // t1 is dead: x_{r+1} = norm(t2) + x_r goes there
@@ -359,11 +314,7 @@ static void matching_pipeline(Ctx& c, const PdsMatchingParams& P, const float* l
             cur = nxt;
         }
     }
-    if (nox1 >= 1) {
-        conv_block(c, t2.src(), t2_first.src(), g, P.last, P.signature_features, 1, 1, 1, signatures);
-        if (!c.plan) c.run(launch_x0_term_add(y8, cr8, cr08, signatures, batch, 8, h, w, d_begin, d_count, c.s));
-    } else
-        conv_block(c, t2.src(), cur.src(), g, P.last, P.signature_features, 1, 1, 1, signatures);
+    conv_block(c, t2.src(), cur.src(), g, P.last, P.signature_features, 1, 1, 1, signatures);
 }
 
 static void operation_pipeline(Ctx& c, const PdsMatchingParams& P, const float* concatenated, float* signature,

@@ -184,11 +184,6 @@ struct ConvLayer {
     const float* l1H = nullptr;
     unsigned l1_bstride = 0, l1_hstride = 0, l1_edge = 0;
     int l1_P = 0, l1_d0 = 0;
-    // round 6: the blocked planes are the layer-0 planes A / G (misc.hip: l1_blocked_kernel with G2) and the layer's input is
-    // norm(a) + A[x] + G[x - d], the first residual sum; l1_bound: the blocked planes' range records
-    int l1_sum = 0;
-    const float* l1_bound = nullptr;
-    int l1_bound_n = 0;
 };
 
 // direct VALU convolution, any channel count
@@ -341,22 +336,13 @@ int launch_l1_column_terms(const float* G, const float* G2, const float* wcol, f
                            int d_count, hipStream_t s);
 int launch_l1_weights2(const float* w1, const float* b1, float* w2, float* bias2, int cout, int channels,
                        hipStream_t s);
-// round 6 (PDS_MATCHING_NOX1): B8 / H8 = the 64 -> 8 convolution of the layer-0 planes, and their sum per disparity plane
-// (+ column corrections) added to the signatures -- the share of the never-stored x0 in the last Matching layer
-int launch_conv8_planes(const float* x, const float* wcol, float* y8, int batch, int channels, int h, int w2, hipStream_t s);
-int launch_x0_term_add(const float* y8, const float* corr, const float* corr0, float* out, int batch, int cout, int h, int w,
-                       int d_begin, int d_count, hipStream_t s);
 // layer-1 planes B / H (y4 [n][C][2][h][w + 2]) + column corrections -> the channel-blocked form conv2d_x3 stages its first
 // launch from (ConvLayer::l1B): sizes in floats per (batch entry, channel group); pad = zero columns left of H
 __host__ __device__ size_t l1_blocked_b_floats(int h, int w);
 __host__ __device__ size_t l1_blocked_h_floats(int h, int w, int pad, int d_count);
 __host__ __device__ size_t l1_blocked_edge_offset_floats(int h, int w, int pad);
-// G2 (plane 1 of the G2 buffer, y3's layout) + amax (l1_blocked_records floats): the layer-0 planes A / G instead, for the
-// residual sum formed by conv2d_x3's staging (ConvLayer::l1_sum)
 int launch_l1_blocked(const float* y4, const float* corr, const float* corr0, float* Bc, float* Hx, int batch, int channels,
-                      int h, int w, int pad, int d_begin, int d_count, hipStream_t s, const float* G2 = nullptr,
-                      float* amax = nullptr);
-int l1_blocked_records(int batch, int channels, int h, int w, int pad, int d_count);
+                      int h, int w, int pad, int d_begin, int d_count, hipStream_t s);
 
 // small utility: zero-pad one column on the left ([.., w] -> [.., w+1]); split conv0 weights
 int launch_pad_left1(const float* in, float* out, size_t rows, int w, hipStream_t s);

@@ -415,13 +415,8 @@ constexpr int C2W_THREADS = 512;
 constexpr int C2W_MAXW = 352;   // LDS: 48 KB of weights + 4 x 10 x (W + 4) x 8 bytes <= 160 KB
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// BN: source b carries a deferred InstanceNorm as well (round 6: the fused Matching chain without a materialised first
-// residual sum feeds the layer norm(t4) + norm(t2); the share of x0 is added behind the launch, misc.hip: x0_term_add_kernel)
-// BCB: source b is channel-blocked ([N][D][C / 8][H][W][8], Src::cb8): a chunk's four channels of a pixel are 16 contiguous
-// bytes, an item's loads are one per pixel instead of one per channel -- the same count, the registers transposed
-template <bool TWO, int NBH, int C2W_TY, int C2W_ITEMS, bool BN = false, bool BCB = false>
+template <bool TWO, int NBH, int C2W_TY, int C2W_ITEMS>
 __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args A) {
-    static_assert(!BCB || (TWO && C2_KC == 4), "a blocked second source: four channels per chunk");
     constexpr int C2W_YT = C2W_TY + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* abuf = lds;                           // [96 fragments][64 lanes][4 x fp16]
@@ -506,11 +501,9 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
     unsigned goff[C2W_ITEMS], goff_n[C2W_ITEMS];   // byte offsets inside (channel 0 of the chunk, plane 0); ~0: padding
     float inside[C2W_ITEMS], inside_n[C2W_ITEMS];
     int sbase = 0, sbase_n = 0;
-    int sbase_b = 0, sbase_b_n = 0;   // BCB: byte offset of (batch, plane) in the channel-blocked source b
     int gidx = 0, gidx_n = 0;
     const int stride_a = A.a.per_plane ? A.D : 1;
-    const int stride_b = (BN && A.b.per_plane) ? A.D : 1;   // (both sources are tensors of this chain: the same statistics grouping)
-    auto prepare = [&](int local, unsigned* off, float* in, int& sb, int& gi, int& sbb) {
+    auto prepare = [&](int local, unsigned* off, float* in, int& sb, int& gi) {
         const TilePos P = tile_pos(local);
 #pragma unroll
         for (int k = 0; k < C2W_ITEMS; ++k) {
@@ -520,31 +513,23 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
             off[k] = ok ? (unsigned)((size_t)y * A.W + item_col[k]) * 4u : ~0u;
         }
         sb = (int)(((size_t)P.nb * C2_CIN * A.D + P.d) * plane * sizeof(float));
-        if constexpr (BCB) sbb = (int)(((size_t)P.nb * A.D + P.d) * C2_CIN * plane * sizeof(float));
         gi = A.a.per_plane ? P.nb * C2_CIN * A.D + P.d : P.nb * C2_CIN;
     };
 
     f32x4 va[2][C2W_ITEMS][C2_KC], vb[2][C2W_ITEMS][C2_KC];
     float vs[2][C2_KC], vh[2][C2_KC];
-    float vs2[2][BN ? C2_KC : 1], vh2[2][BN ? C2_KC : 1];
     float inside_regs[2][C2W_ITEMS];
     auto fetch = [&](int g, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
         const int c0 = (g % C2_CHUNKS) * C2_KC;
         const int soff = __builtin_amdgcn_readfirstlane(sbase + c0 * cbytes);
-        // (blocked b: group c0 / 8 of the plane, channel c0 % 8 of the pixel's 32 bytes)
-        const int soff_b = BCB ? __builtin_amdgcn_readfirstlane(sbase_b + (c0 >> 3) * (int)(plane * 32) + (c0 & 7) * 4) : 0;
 #pragma unroll
         for (int k = 0; k < C2W_ITEMS; ++k) {
-            const unsigned goff_b = BCB ? (goff[k] == ~0u ? ~0u : goff[k] * 8u) : 0u;
 #pragma unroll
             for (int ch = 0; ch < C2_KC; ++ch) {
                 va[SET][k][ch] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, goff[k], soff + ch * cbytes, 0));
-                if constexpr (BCB)   // vb[.][.][pixel] = the pixel's four channels
-                    vb[SET][k][ch] = __builtin_bit_cast(
-                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, goff_b == ~0u ? ~0u : goff_b + 32u * ch, soff_b, 0));
-                else if (TWO)
+                if (TWO)
                     vb[SET][k][ch] = __builtin_bit_cast(
                         f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, goff[k], soff + ch * cbytes, 0));
             }
@@ -555,10 +540,6 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
             const int gi = __builtin_amdgcn_readfirstlane(gidx + (c0 + ch) * stride_a);
             vs[SET][ch] = A.a.scale[gi];
             vh[SET][ch] = A.a.shift[gi];
-            if constexpr (BN) {   // (stride_a == stride_b is required of the caller: one index serves both)
-                vs2[SET][ch] = A.b.scale[gi];
-                vh2[SET][ch] = A.b.shift[gi];
-            }
         }
     };
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -566,16 +547,11 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
         constexpr int SET = decltype(set_c)::value;
         // the activation scale rides in the folded coefficients, multiplied here and not where they are loaded (a scalar
         // load touched in fetch() is waited for on the spot: +27 us per launch)
-        float cs[C2_KC], chs[C2_KC], cs2[C2_KC];
+        float cs[C2_KC], chs[C2_KC];
 #pragma unroll
         for (int ch = 0; ch < C2_KC; ++ch) {
             cs[ch] = vs[SET][ch] * SC.as;
             chs[ch] = vh[SET][ch] * SC.as;
-            cs2[ch] = SC.as;
-            if constexpr (BN) {
-                cs2[ch] = vs2[SET][ch] * SC.as;
-                chs[ch] = (vh[SET][ch] + vh2[SET][ch]) * SC.as;
-            }
         }
 #pragma unroll
         for (int k = 0; k < C2W_ITEMS; ++k)
@@ -589,7 +565,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
 #pragma unroll
                     for (int ch = 0; ch < C2_KC; ++ch) {
                         float t = cs[ch] * va[SET][k][ch][px];
-                        if (TWO) t = fmaf(cs2[ch], BCB ? vb[SET][k][px][ch] : vb[SET][k][ch][px], t);
+                        if (TWO) t = fmaf(SC.as, vb[SET][k][ch][px], t);
                         v[ch] = fmaf(chs[ch], inside_regs[SET][k], t);   // (the shift vanishes in the padding rows)
                     }
                     f16x4 hi, lo;
@@ -626,7 +602,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
         const int gf = min(g, total_chunks - 1);
         if (gf / C2_CHUNKS != fetched_tile) {
             fetched_tile = gf / C2_CHUNKS;
-            prepare(fetched_tile, goff, inside, sbase, gidx, sbase_b);
+            prepare(fetched_tile, goff, inside, sbase, gidx);
         }
         fetch(gf, set_c);
     };
@@ -654,7 +630,7 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
         }
         const int gf = min(g + 3, total_chunks - 1);
         const bool new_tile = gf / C2_CHUNKS != fetched_tile;
-        if (new_tile) prepare(gf / C2_CHUNKS, goff_n, inside_n, sbase_n, gidx_n, sbase_b_n);
+        if (new_tile) prepare(gf / C2_CHUNKS, goff_n, inside_n, sbase_n, gidx_n);
         fetched_tile = gf / C2_CHUNKS;
 
         // ---- branch-free body ----------------------------------------------------------------------------------------
@@ -674,7 +650,6 @@ __global__ __launch_bounds__(C2W_THREADS, 2) void conv2d_t8w_kernel(const C2Args
             goff[k] = new_tile ? goff_n[k] : goff[k];
         }
         sbase = new_tile ? sbase_n : sbase;
-        if constexpr (BCB) sbase_b = new_tile ? sbase_b_n : sbase_b;
         gidx = new_tile ? gidx_n : gidx;
         fetch(gf, set_c);
 #ifdef PDS_C2W_TIMING
@@ -787,22 +762,11 @@ bool c2t8_wide(const ConvLayer& L) {
         return !(e && e[0] == '0');
     }();
     if (!on) return false;
-    if (!L.a.scale) return false;                                    // source a normalised; source b plain, normalised or absent
-    if (L.b.p && L.b.scale && L.a.per_plane != L.b.per_plane) return false;   // (one coefficient index serves both)
+    if (!L.a.scale || (L.b.p && L.b.scale)) return false;            // (source a normalised, source b plain or absent)
     return (L.in.w & 3) == 0 && L.in.w >= 64 && L.in.w <= C2W_MAXW && L.in.h >= 8;
 }
 
-bool conv2d_t8w_takes(int h, int w) {
-    ConvLayer L;
-    float one = 0.f;
-    L.a.p = &one;
-    L.a.scale = &one;
-    L.in.h = h;
-    L.in.w = w;
-    return c2t8_enabled() && c2t8_wide(L);
-}
-
-template <bool TWO, int NBH, int TY, int ITEMS, bool BN = false, bool BCB = false>
+template <bool TWO, int NBH, int TY, int ITEMS>
 int launch_c2t8w(C2Args& A, hipStream_t s) {
     A.tiles_x = 1;
     A.tiles_y = (A.H + TY - 1) / TY;
@@ -815,7 +779,7 @@ int launch_c2t8w(C2Args& A, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (DeviceOnce once{attr_done}) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8w_kernel<TWO, NBH, TY, ITEMS, BN, BCB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_t8w_kernel<TWO, NBH, TY, ITEMS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         int n = 0;
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -824,7 +788,7 @@ int launch_c2t8w(C2Args& A, hipStream_t s) {
     int wgs = cus[dev & 31] / 8 * 8;
     if (wgs > A.tiles) wgs = (A.tiles + 7) / 8 * 8;
     const int probe = probe_before("conv2d_t8w", s);
-    hipLaunchKernelGGL((conv2d_t8w_kernel<TWO, NBH, TY, ITEMS, BN, BCB>), dim3(wgs), dim3(C2W_THREADS), lds_bytes, s, A);
+    hipLaunchKernelGGL((conv2d_t8w_kernel<TWO, NBH, TY, ITEMS>), dim3(wgs), dim3(C2W_THREADS), lds_bytes, s, A);
     probe_after(probe, A.tiles, s);
     return check_launch("conv2d_t8w");
 }
@@ -874,23 +838,11 @@ int launch_conv2d_t8(const ConvLayer& L, hipStream_t s) {
     if (c2t8_wide(L)) {
         const int blocks = (A.W + 15) / 16, nbh = (blocks + 1) / 2;
         const int rows = c2t8w_rows(A.W), items = ((rows + 2) * (A.W >> 2) + C2W_THREADS - 1) / C2W_THREADS;
-        if (L.b.p && L.b.cb8) {   // (only behind a deferred InstanceNorm: the fused Matching chain's t2)
-            if (!L.b.scale) return set_error(-1, "conv2d_t8w: a channel-blocked source b without a deferred InstanceNorm");
-            if (nbh <= 8 && rows == 6 && items == 1) return launch_c2t8w<true, 8, 6, 1, true, true>(A, s);
-            if (nbh <= 8) return launch_c2t8w<true, 8, 8, 2, true, true>(A, s);
-            return launch_c2t8w<true, 11, 8, 2, true, true>(A, s);
-        }
-        if (L.b.p && L.b.scale) {
-            if (nbh <= 8 && rows == 6 && items == 1) return launch_c2t8w<true, 8, 6, 1, true>(A, s);
-            if (nbh <= 8) return launch_c2t8w<true, 8, 8, 2, true>(A, s);
-            return launch_c2t8w<true, 11, 8, 2, true>(A, s);
-        }
         if (nbh <= 8 && rows == 6 && items == 1)
             return L.b.p ? launch_c2t8w<true, 8, 6, 1>(A, s) : launch_c2t8w<false, 8, 6, 1>(A, s);
         if (nbh <= 8) return L.b.p ? launch_c2t8w<true, 8, 8, 2>(A, s) : launch_c2t8w<false, 8, 8, 2>(A, s);
         return L.b.p ? launch_c2t8w<true, 11, 8, 2>(A, s) : launch_c2t8w<false, 11, 8, 2>(A, s);
     }
-    if (L.a.cb8 || (L.b.p && L.b.cb8)) return set_error(-1, "conv2d_t8: only the full-width form takes a channel-blocked source (b)");
     const bool na = L.a.scale != nullptr, nb2 = L.b.p && L.b.scale;
     if (L.b.p) {
         if (na) return nb2 ? launch_c2t8<true, true, true>(A, s) : launch_c2t8<true, true, false>(A, s);

@@ -123,11 +123,6 @@ struct X3Args {
     const float* __restrict__ l1H;
     unsigned l1_bstride, l1_hstride, l1_edge;
     int l1_P, l1_d0;
-    // l1_sum (round 6): the blocked planes hold the LAYER-0 planes A / G and the input is the residual sum norm(a) + A[x] +
-    // G[x - d] (a = t2, planar); bound2: range records of the blocked planes (|x0| <= 2 max)
-    int l1_sum;
-    const float* __restrict__ bound2;
-    int bound2_n;
     // fp16 form: the power-of-two operand scales (header comment).  ascale is computed by every workgroup from the
     // source's range certificate, 1 / ws was left behind the tile-queue counters by the weight packing.
     const float* __restrict__ bound;
@@ -176,30 +171,6 @@ struct X3In<2> {
         for (int c = 0; c < 4; ++c) q[c] = h[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 };
-
-// first residual sum of the fused Matching chain formed while it is staged (round 6, X3Args::l1_sum): x1 = norm(t2) + x0 with
-// t2 channel-blocked (four 16-byte loads, the addressing of X3In<1>) and x0 = A[x] + G[x - d] from the channel-blocked
-// layer-0 planes (eight 16-byte loads, the addressing of X3In<2>) -- materialize_l0_sweep's 2 x 425 MB pass is gone.  (With a
-// planar t2 -- sixteen dword loads on top of the eight -- the launch took 477 us against 350: the staging waves' memory
-// instructions, not their bytes, are what a stage waits for.)
-template <>
-struct X3In<3> {
-    f32x4 t[4], q[4], h[4];
-    __device__ __forceinline__ float get(int c) const { return t[c >> 2][c & 3]; }
-    __device__ __forceinline__ float x0(int c) const {   // (an instruction of its own: never contracted into the fma behind it)
-        float v;
-        asm("v_add_f32 %0, %1, %2" : "=v"(v) : "v"(q[c >> 2][c & 3]), "v"(h[c >> 2][c & 3]));
-        return v;
-    }
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = q[c] = h[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-};
-
-// the registers that receive a pixel's channel-blocked source values
-__device__ __forceinline__ f32x4 (&x3_cb8_regs(X3In<1>& x))[4] { return x.q; }
-__device__ __forceinline__ f32x4 (&x3_cb8_regs(X3In<3>& x))[4] { return x.t; }
 
 // One lane draws the next tile: its home queue first, then the others (work stealing).  Virtual tile id =
 // plane * tiles + tile, or -1 when every queue is empty.  Queue q holds the planes p = q (mod 8): all their full tiles
@@ -661,12 +632,12 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     // kSetLoads = loads every stage issues: 2 coefficients (NORM), 16 inputs, W_ITERS weight pieces; a wait for "at most
     // kSetLoads outstanding" therefore covers the whole older set (vector-memory results return in order; other
     // memory operations in between only make the wait stricter).
-    constexpr int kInLoads = CBI == 3 ? 12 : (CBI == 2 ? 8 : (CBI == 1 ? 4 : 16));
+    constexpr int kInLoads = CBI == 2 ? 8 : (CBI == 1 ? 4 : 16);
     constexpr int kSetLoads = kInLoads + W_ITERS + (NORM ? 2 : 0);
     auto request_inputs = [&](X3In<CBI>& x, const Tile& tl, int ks, int third) {
         const int y = tl.y0 - 1 + third * THIRD_ROWS + prow, xx = tl.x0 - 1 + pcol;
         const int yc = min(max(y, 0), A.H - 1), xc = min(max(xx, 0), A.W - 1);
-        if constexpr (CBI == 2 || CBI == 3) {
+        if constexpr (CBI == 2) {
             // B at column x + 2 of its row; H[x - d] at column x - d + 2 + l1_P of the zero-padded row (0 for x - d < -2), or,
             // where l1_combine adds a column correction (x = 0 at d = 0; x = w - 2, w - 1 at d >= 1), the edge entry that
             // holds H + correction: a per-lane choice of the offset, the same eight loads for every lane
@@ -694,12 +665,9 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
                          : "v"(boffB), "v"(boffH), "s"(b_lo), "s"(b_hi), "s"(h_lo), "s"(h_hi), "s"(A.l1_bstride),
                            "s"(A.l1_hstride)
                          : "memory", "s60", "s61", "scc");
-        }
-        if constexpr (CBI == 2) {
-        } else if constexpr (CBI == 1 || CBI == 3) {
+        } else if constexpr (CBI == 1) {
             // groups 2 ks and 2 ks + 1 of plane (n, d) of [N][D][C / 8][H][W][8]: the pixel's 32 bytes in each, two 16-byte
             // loads per group -- the base walks in s[60:61] as below
-            f32x4(&dst)[4] = x3_cb8_regs(x);
             const float* src = A.a.p + (((size_t)(tl.n * A.D + tl.d) * (A.Cin >> 3) + 2 * ks) * plane) * 8;   // uniform
             const unsigned boff = (unsigned)(yc * A.W + xc) * 32u;
             const unsigned long long base = reinterpret_cast<unsigned long long>(src);
@@ -708,7 +676,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
                          "global_load_dwordx4 %0, %4, s[60:61]\n\tglobal_load_dwordx4 %1, %4, s[60:61] offset:16\n\t"
                          "s_add_u32 s60, s60, %7\n\ts_addc_u32 s61, s61, 0\n\t"
                          "global_load_dwordx4 %2, %4, s[60:61]\n\tglobal_load_dwordx4 %3, %4, s[60:61] offset:16"
-                         : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])
+                         : "=&v"(x.q[0]), "=&v"(x.q[1]), "=&v"(x.q[2]), "=&v"(x.q[3])
                          : "v"(boff), "s"(base_lo), "s"(base_hi), "s"(step)
                          : "memory", "s60", "s61", "scc");
         } else {
@@ -735,13 +703,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     // every value of a set passes through this statement before its first use: the wait cannot be scheduled after a
     // consumer, and no consumer before it
     auto await_set = [&](X3In<CBI>& x, u32x4 (&w)[W_ITERS], float& cs, float& ch) {
-        if constexpr (CBI == 3) {
-            asm volatile("s_waitcnt vmcnt(%12)"
-                         : "+v"(x.t[0]), "+v"(x.t[1]), "+v"(x.t[2]), "+v"(x.t[3]), "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]),
-                           "+v"(x.h[0]), "+v"(x.h[1]), "+v"(x.h[2]), "+v"(x.h[3])
-                         : "n"(kSetLoads)
-                         : "memory");
-        } else if constexpr (CBI == 2) {
+        if constexpr (CBI == 2) {
             asm volatile("s_waitcnt vmcnt(%8)"
                          : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]), "+v"(x.h[0]), "+v"(x.h[1]), "+v"(x.h[2]), "+v"(x.h[3])
                          : "n"(kSetLoads)
@@ -789,10 +751,6 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
                 const int c = 2 * pr;
                 float r0 = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : x3_mul(x[c], A.ascale);
                 float r1 = NORM ? x3_fma(cs[c >> 2][(c & 3) + 1], x[c + 1], ch[c >> 2][(c & 3) + 1]) : x3_mul(x[c + 1], A.ascale);
-                if constexpr (CBI == 3) {   // + as * x0: the sum is rounded once, as materialize_l0_sweep's norm(t2) + (A + G) was
-                    r0 = x3_fma(A.ascale, xs.x0(c), r0);
-                    r1 = x3_fma(A.ascale, xs.x0(c + 1), r1);
-                }
                 r0 = inimg ? r0 : 0.f;
                 r1 = inimg ? r1 : 0.f;
                 unsigned hi, lo;
@@ -837,7 +795,6 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
             continue;
 #endif
             float r = NORM ? x3_fma(cs[c >> 2][c & 3], x[c], ch[c >> 2][c & 3]) : (P == 2 ? x3_mul(x[c], A.ascale) : x[c]);
-            if constexpr (CBI == 3) r = x3_fma(A.ascale, xs.x0(c), r);
             r = inimg ? r : 0.f;
             if constexpr (P == 3) {
                 // truncation split: hi = top 16 bits, remainder exact; three parts carry all 24 significand bits
@@ -939,13 +896,7 @@ __device__ __forceinline__ void x3_staging_waves(const X3Args& A, unsigned char*
     int nxt_id = -1;
     int tpar = 0;             // coefficient table of the current tile
     auto await_all = [&](X3In<CBI>& x, u32x4 (&w)[W_ITERS], float& cs, float& ch) {
-        if constexpr (CBI == 3) {
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(x.t[0]), "+v"(x.t[1]), "+v"(x.t[2]), "+v"(x.t[3]), "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]),
-                           "+v"(x.h[0]), "+v"(x.h[1]), "+v"(x.h[2]), "+v"(x.h[3])
-                         :
-                         : "memory");
-        } else if constexpr (CBI == 2) {
+        if constexpr (CBI == 2) {
             asm volatile("s_waitcnt vmcnt(0)"
                          : "+v"(x.q[0]), "+v"(x.q[1]), "+v"(x.q[2]), "+v"(x.q[3]), "+v"(x.h[0]), "+v"(x.h[1]), "+v"(x.h[2]), "+v"(x.h[3])
                          :
@@ -1068,9 +1019,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_x3_kernel(const X3Args A0) 
     A.unscale = 1.f;
     if constexpr (P == 2) {
         // operand scales of the fp16 form: the source's range certificate -> as; 1 / ws from the packed weights' tail
-        float bound = block_bound(A.bound, A.bound_n, reinterpret_cast<float*>(lds + X3Cfg<P>::LDS_RED));
-        if constexpr (CBI == 3)   // |norm(t2) + A + G| <= bound(t2) + 2 max(|A|, |G|, |G2|)
-            bound += 2.f * block_bound(A.bound2, A.bound2_n, reinterpret_cast<float*>(lds + X3Cfg<P>::LDS_RED));
+        const float bound = block_bound(A.bound, A.bound_n, reinterpret_cast<float*>(lds + X3Cfg<P>::LDS_RED));
         // (wave-uniform: kept in scalar registers, the MFMA waves have no vector registers to spare)
         A.ascale = __builtin_bit_cast(
             float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_scale(bound, kHalfTarget))));
@@ -1139,16 +1088,14 @@ static int x3_launch(const ConvLayer& L, X3Args& A, int workgroups, hipStream_t 
     if (DeviceOnce once{attr_done}) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, true, CBI, CBO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if constexpr (CBI < 2)   // (the on-the-fly sources always sit behind a deferred InstanceNorm)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false, CBI, CBO>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_x3_kernel<P, false, CBI, CBO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     }
     // (planes * tiles rides along as the "workgroups" of the probe record: it tells a 48-plane layer from a small one)
     const int probe = probe_before(P == 2 ? "conv2d_x3<fp16>" : "conv2d_x3<bf16>", s);
-    if (L.a.scale || CBI >= 2)
+    if (L.a.scale)
         hipLaunchKernelGGL((conv2d_x3_kernel<P, true, CBI, CBO>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
-    else if constexpr (CBI < 2)
-        hipLaunchKernelGGL((conv2d_x3_kernel<P, false, CBI, CBO>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
+    else hipLaunchKernelGGL((conv2d_x3_kernel<P, false, CBI, CBO>), dim3(workgroups), dim3(THREADS), C::LDS_BYTES, s, A);
     probe_after(probe, A.planes * A.tiles, s);
     return check_launch("conv2d_x3");
 }
@@ -1229,16 +1176,9 @@ int launch_conv2d_x3(const ConvLayer& L, hipStream_t s) {
     A.l1_edge = L.l1_edge;
     A.l1_P = L.l1_P;
     A.l1_d0 = L.l1_d0;
-    A.l1_sum = L.l1_sum;
-    A.bound2 = L.l1_bound;
-    A.bound2_n = L.l1_bound_n;
     if (L.l1B) {   // layer-1 planes formed on the fly (always behind the deferred InstanceNorm of t1)
-        if (!fp16 || !L.a.scale || (A.in_cb8 != 0) != (L.l1_sum != 0) || !conv2d_x3_cb8_ok(L, true, A.out_cb8 != 0))
+        if (!fp16 || !L.a.scale || A.in_cb8 || !conv2d_x3_cb8_ok(L, true, A.out_cb8 != 0))
             return set_error(-1, "conv2d_x3: the layer-1 source needs the fp16 form, a deferred InstanceNorm and whole tiles");
-        if (L.l1_sum) {   // ... or the layer-0 planes joining norm(a), a channel-blocked: the first residual sum formed while it is staged
-            if (!A.bound2 || A.bound2_n <= 0) return set_error(-1, "conv2d_x3: the residual-sum source without a range bound");
-            return A.out_cb8 ? x3_launch<2, 3, true>(L, A, workgroups, s) : x3_launch<2, 3, false>(L, A, workgroups, s);
-        }
         return A.out_cb8 ? x3_launch<2, 2, true>(L, A, workgroups, s) : x3_launch<2, 2, false>(L, A, workgroups, s);
     }
     if (A.in_cb8 || A.out_cb8) {

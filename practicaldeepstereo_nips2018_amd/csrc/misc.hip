@@ -757,143 +757,6 @@ __global__ __launch_bounds__(256) void l1_combine_kernel(const float* __restrict
     }
 }
 
-// ---- round 6: the share of the never-stored x0 = A + shift_d(G) in the 64 -> 8 layer -----------------------------------
-// The fused chain's last layer reads norm(t4) + norm(t2) + x0 (api_matching.hip: PDS_MATCHING_NOX1).  W8 * x0 factorises
-// exactly as layer 1 did: B8 = W8 * A, H8 = W8 * G (two planes instead of D'), + the column corrections of
-// l1_column_terms_kernel.  conv8_planes_kernel forms B8 / H8; x0_term_add_kernel adds B8[x] + H8[x - d] + corrections to
-// the signatures conv2d_t8w has written (read + write of the 8-channel output: 2 x 53 MB at config 2, against the 2 x 425 MB
-// of the residual-sum pass it replaces).
-
-// y8 [n][8][2][h][W2] = 3 x 3 convolution (zero padding at the borders of the W2-wide planes, no bias) of x [n][C][2][h][W2]
-// with the weights in column_weights_kernel's layout [dx][C][dy][8].  A workgroup owns 64 pixels of one plane; its four
-// waves split the input channels (weights through scalar loads, 8 output channels per thread) and meet in LDS.
-__global__ __launch_bounds__(256) void conv8_planes_kernel(const float* __restrict__ x, const float* __restrict__ wcol,
-                                                           float* __restrict__ y8, int C, int h, int W2) {
-    __shared__ float red[4][8][64];
-    const int lane = threadIdx.x & 63;
-    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.y >> 1, pl = blockIdx.y & 1;
-    const int pix = blockIdx.x * 64 + lane;
-    const bool live = pix < h * W2;
-    const int y = live ? pix / W2 : 0, xx = live ? pix - y * W2 : 0;
-    const size_t plane = (size_t)h * W2;
-    float acc[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-    const int per = (C + 3) / 4;
-    const int ic_end = (part + 1) * per < C ? (part + 1) * per : C;
-    for (int ic = part * per; ic < ic_end; ++ic) {
-        const float* src = x + ((size_t)(n * C + ic) * 2 + pl) * plane;
-        float v[3][3];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int yy = y + dy - 1, xc = xx + dx - 1;
-                const bool ok = live && yy >= 0 && yy < h && xc >= 0 && xc < W2;
-                const float t = src[ok ? (size_t)yy * W2 + xc : 0];
-                v[dy][dx] = ok ? t : 0.f;
-            }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const float* wk = wcol + (((size_t)dx * C + ic) * 3 + dy) * 8;   // uniform: scalar loads
-#pragma unroll
-                for (int o = 0; o < 8; ++o) acc[o] = fmaf(wk[o], v[dy][dx], acc[o]);
-            }
-    }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) red[part][o][lane] = acc[o];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int o = 2 * part + k;
-        const float t = (red[0][o][lane] + red[1][o][lane]) + (red[2][o][lane] + red[3][o][lane]);
-        if (live) y8[((size_t)(n * 8 + o) * 2 + pl) * plane + pix] = t;
-    }
-}
-
-int launch_conv8_planes(const float* x, const float* wcol, float* y8, int batch, int channels, int h, int w2, hipStream_t s) {
-    hipLaunchKernelGGL(conv8_planes_kernel, dim3((h * w2 + 63) / 64, batch * 2), dim3(256), 0, s, x, wcol, y8, channels, h, w2);
-    return check_launch("conv8_planes");
-}
-
-// out[nc][dl][y][x] += B8[y][x] + H8[y][x - d] + column corrections (the terms l1_combine_kernel<COLS> adds, without its
-// LeakyReLU and statistics).  One thread owns four consecutive x of one row for all planes; the H window slides by one
-// column per plane as in l1_combine_kernel.  blockIdx.z selects a segment of UN planes, all in flight at once (one
-// thread walking all D' planes was latency-bound: 51 us for 2 x 53 MB).  w % 4 == 0.
-template <int UN>
-__global__ __launch_bounds__(256) void x0_term_add_kernel(const float* __restrict__ y8, const float* __restrict__ corr,
-                                                          const float* __restrict__ corr0, float* __restrict__ out, int h,
-                                                          int w, int d_begin, int d_count) {
-    const int nc = blockIdx.y, W2 = w + 2, xq = w / 4;
-    const size_t px = (size_t)h * w;
-    const float* Bp = y8 + (size_t)nc * 2 * h * W2;
-    const float* Hp = Bp + (size_t)h * W2;
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    const bool active = qi < h * xq;
-    const int y = active ? qi / xq : 0, xi = active ? qi - y * xq : 0, xb = xi * 4;
-    const size_t row = (size_t)y * W2;
-    const bool loads_left = xi == 0 || (threadIdx.x & 63) == 0;
-    float bq[4], hw[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        bq[k] = active ? Bp[row + xb + k + 2] : 0.f;
-        const int u = xb + k - (d_begin + (int)blockIdx.z * UN);
-        hw[k] = (active && u >= -2) ? Hp[row + u + 2] : 0.f;
-    }
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    float* po = out + (size_t)nc * d_count * px + (size_t)y * w + xb;
-    {
-        const int d0 = blockIdx.z * UN;
-        f32x4 old[UN];
-#pragma unroll
-        for (int j = 0; j < UN; ++j)
-            old[j] = (active && d0 + j < d_count) ? *reinterpret_cast<const f32x4*>(po + (size_t)(d0 + j) * px)
-                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < UN; ++j) {
-            const int dl = d0 + j, d = d_begin + dl;
-            if (dl >= d_count) break;
-            float tk[4] = {hw[0], hw[1], hw[2], hw[3]};
-            if (d == 0) {
-                if (active && xb == 0) tk[0] += corr0[(size_t)nc * h + y];
-            } else if (active && xb + 4 > w - 2) {
-                const float2 cv = *reinterpret_cast<const float2*>(corr + (((size_t)nc * h + y) * d_count + dl) * 2);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int x = xb + k;
-                    if (x >= w - 2 && x < w) tk[k] += x == w - 2 ? cv.x : cv.y;
-                }
-            }
-            f32x4 r;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) r[k] = old[j][k] + (bq[k] + tk[k]);
-            if (active) *reinterpret_cast<f32x4*>(po + (size_t)dl * px) = r;
-            const float from_left = __builtin_bit_cast(
-                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hw[3]), 0x138, 0xf, 0xf, true));
-            hw[3] = hw[2];
-            hw[2] = hw[1];
-            hw[1] = hw[0];
-            hw[0] = from_left;
-            if (loads_left) {
-                const int u = xb - (d + 1);
-                hw[0] = (active && u >= -2) ? Hp[row + u + 2] : 0.f;
-            }
-        }
-    }
-}
-
-int launch_x0_term_add(const float* y8, const float* corr, const float* corr0, float* out, int batch, int cout, int h, int w,
-                       int d_begin, int d_count, hipStream_t s) {
-    if (w & 3) return set_error(-1, "x0_term_add: width %d is not a multiple of four", w);
-    constexpr int kPlanes = 8;
-    const dim3 grid((h * (w / 4) + 255) / 256, batch * cout, (d_count + kPlanes - 1) / kPlanes);
-    hipLaunchKernelGGL(x0_term_add_kernel<kPlanes>, grid, dim3(256), 0, s, y8, corr, corr0, out, h, w, d_begin, d_count);
-    return check_launch("x0_term_add");
-}
-
 // ---- the layer-1 planes, channel-blocked for conv2d_x3's staging (round 5) --------------------------------------------
 // per (batch entry, channel group of 8):
 //   Bc  [h][w + 2][8]                     Bc[y][x + 2] = B[c][y][x]                            (y4's own column convention)
@@ -907,29 +770,22 @@ __host__ __device__ size_t l1_blocked_h_floats(int h, int w, int pad, int d_coun
     return l1_blocked_edge_offset_floats(h, w, pad) + (size_t)d_count * h * 2 * 8;
 }
 
-// G2 / amax (round 6): the same re-layout of the LAYER-0 planes A / G (y3 has y4's layout) for the residual sum that conv2d_x3
-// forms while it stages (X3In<3>): no corrections -- the edge entries are G itself except the right-most image column of the
-// planes d >= 1, which reads G2 (the right descriptor's dx = +1 taps do not exist there) -- and one range record per workgroup
 __global__ __launch_bounds__(256) void l1_blocked_kernel(const float* __restrict__ y4, const float* __restrict__ corr,
                                                          const float* __restrict__ corr0, float* __restrict__ Bc,
                                                          float* __restrict__ Hx, int C, int h, int w, int pad, int d_begin,
-                                                         int d_count, const float* __restrict__ G2, float* __restrict__ amax) {
+                                                         int d_count) {
     // grid: x = items of one (batch entry, channel group), y = batch entry * groups + group; one thread = one 32-byte slot
-    __shared__ float red[4];
     const int W2 = w + 2, HW = pad + w + 2;
     const int nb = h * W2, nh = h * HW, ne = d_count * h * 2;
     const int item = blockIdx.x * 256 + threadIdx.x;
-    const bool live = item < nb + nh + ne;
+    if (item >= nb + nh + ne) return;
     const int ng = blockIdx.y, groups = C / 8, n = ng / groups, g = ng % groups;
     const size_t plane = (size_t)h * W2;
     const float* Bp = y4 + ((size_t)(n * C + g * 8) * 2) * plane;   // channel stride 2 planes
     const float* Hp = Bp + plane;
     float v[8];
-    float* dst = nullptr;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = 0.f;
-    if (!live) {
-    } else if (item < nb) {
+    float* dst;
+    if (item < nb) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = Bp[(size_t)c * 2 * plane + item];
         dst = Bc + (size_t)ng * l1_blocked_b_floats(h, w) + (size_t)item * 8;
@@ -945,13 +801,7 @@ __global__ __launch_bounds__(256) void l1_blocked_kernel(const float* __restrict
             const size_t nc = (size_t)n * C + g * 8 + c;
             const float* hrow = Hp + (size_t)c * 2 * plane + (size_t)y * W2;
             float t = 0.f;
-            if (G2) {
-                const float* g2row = G2 + ((size_t)(n * C + g * 8 + c) * 2) * plane + (size_t)y * W2;
-                const int u = w - 2 + slot - d;
-                if (d == 0) t = slot == 0 ? hrow[2] : 0.f;
-                else if (slot == 0) t = u >= -2 ? hrow[u + 2] : 0.f;
-                else t = u >= -1 ? g2row[u + 2] : 0.f;
-            } else if (d == 0) {
+            if (d == 0) {
                 if (slot == 0) t = hrow[2] + corr0[nc * h + y];
             } else {
                 const int u = w - 2 + slot - d;
@@ -963,31 +813,15 @@ __global__ __launch_bounds__(256) void l1_blocked_kernel(const float* __restrict
               (size_t)i * 8;
     }
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if (live) {
-        reinterpret_cast<f32x4*>(dst)[0] = f32x4{v[0], v[1], v[2], v[3]};
-        reinterpret_cast<f32x4*>(dst)[1] = f32x4{v[4], v[5], v[6], v[7]};
-    }
-    if (amax) {
-        float m = 0.f, poison = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            m = fmaxf(m, fabsf(v[c]));
-            poison = fmaf(v[c], 0.f, poison);   // a NaN / inf anywhere makes the record +inf
-        }
-        block_amax_record(poison == poison ? m : __builtin_inff(), amax + (size_t)blockIdx.y * gridDim.x + blockIdx.x, red);
-    }
-}
-
-static int l1_blocked_items(int h, int w, int pad, int d_count) { return h * (w + 2) + h * (pad + w + 2) + d_count * h * 2; }
-int l1_blocked_records(int batch, int channels, int h, int w, int pad, int d_count) {
-    return (l1_blocked_items(h, w, pad, d_count) + 255) / 256 * batch * (channels / 8);
+    reinterpret_cast<f32x4*>(dst)[0] = f32x4{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<f32x4*>(dst)[1] = f32x4{v[4], v[5], v[6], v[7]};
 }
 
 int launch_l1_blocked(const float* y4, const float* corr, const float* corr0, float* Bc, float* Hx, int batch, int channels,
-                      int h, int w, int pad, int d_begin, int d_count, hipStream_t s, const float* G2, float* amax) {
-    const int items = l1_blocked_items(h, w, pad, d_count);
+                      int h, int w, int pad, int d_begin, int d_count, hipStream_t s) {
+    const int items = h * (w + 2) + h * (pad + w + 2) + d_count * h * 2;
     hipLaunchKernelGGL(l1_blocked_kernel, dim3((items + 255) / 256, batch * (channels / 8)), dim3(256), 0, s, y4, corr, corr0,
-                       Bc, Hx, channels, h, w, pad, d_begin, d_count, G2, amax);
+                       Bc, Hx, channels, h, w, pad, d_begin, d_count);
     return check_launch("l1_blocked");
 }
 
